@@ -1,0 +1,298 @@
+"""
+Golden-vector generator (TEST INFRASTRUCTURE; runs only in the authoring container).
+
+Imports the *reference's own* model code from /root/reference (read-only) with three stub
+modules for packages that are absent from this image and records inputs,
+parameters, outputs and gradients at tiny sizes into ``tests/golden/*.npz``.  Nothing from
+/root/reference is copied: the fixtures are data only.
+
+Stubs:
+  * ``omegaconf``            -- names only (never called on the model path).
+  * ``torch_geometric``      -- names only (edges are precomputed inputs; no sampling).
+  * ``rotary_embedding_torch`` -- a *working* restatement of RotaryEmbedding(dim)
+        .rotate_queries_or_keys (third-party, version unpinned: "rope: third-party,
+        unpinned").  The reference's SDPA / eigvalsh / GEMM run through the real torch.
+
+Usage:  python oracle/make_goldens.py     (needs /root/reference)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("GAOT_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from gaot_3d_amd.data import (MeshBatch, coalesce_edges, knn_edges_bruteforce, latent_grid,  # noqa: E402
+                              radius_edges_bruteforce)
+
+
+def install_stubs():
+    om = types.ModuleType("omegaconf")
+
+    class OmegaConf:  # noqa
+        pass
+
+    class DictConfig:  # noqa
+        pass
+
+    om.OmegaConf, om.DictConfig = OmegaConf, DictConfig
+    sys.modules["omegaconf"] = om
+
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+    tgn = types.ModuleType("torch_geometric.nn")
+    tgu = types.ModuleType("torch_geometric.utils")
+
+    class Batch:  # noqa
+        pass
+
+    def _absent(*a, **k):
+        raise RuntimeError("torch_geometric stub: graph construction is not available here")
+
+    tgd.Batch = Batch
+    tgn.knn = _absent
+    tgn.radius = _absent
+    tgu.coalesce = _absent
+    tgu.dropout_edge = _absent
+    tg.data, tg.nn, tg.utils = tgd, tgn, tgu
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.data": tgd,
+                        "torch_geometric.nn": tgn, "torch_geometric.utils": tgu})
+
+    rot = types.ModuleType("rotary_embedding_torch")
+
+    def rotate_half(x):
+        x = x.reshape(*x.shape[:-1], -1, 2)
+        x1, x2 = x.unbind(dim=-1)
+        return torch.stack((-x2, x1), dim=-1).reshape(*x.shape[:-2], -1)
+
+    def apply_rotary_emb(freqs, t, start_index=0, scale=1.0, seq_dim=-2):
+        rot_dim = freqs.shape[-1]
+        end = start_index + rot_dim
+        tl, tm, tr = t[..., :start_index], t[..., start_index:end], t[..., end:]
+        tm = (tm * freqs.cos() * scale) + (rotate_half(tm) * freqs.sin() * scale)
+        return torch.cat((tl, tm, tr), dim=-1)
+
+    class RotaryEmbedding(nn.Module):
+        def __init__(self, dim, theta=10000):
+            super().__init__()
+            freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].float() / dim))
+            self.freqs = nn.Parameter(freqs, requires_grad=False)
+
+        def forward(self, t):
+            f = torch.einsum("..., f -> ... f", t.type(self.freqs.dtype), self.freqs)
+            return f.repeat_interleave(2, dim=-1)
+
+        def rotate_queries_or_keys(self, t, seq_dim=-2, offset=0):
+            seq_len = t.shape[seq_dim]
+            pos = torch.arange(seq_len, device=t.device, dtype=self.freqs.dtype) + offset
+            return apply_rotary_emb(self.forward(pos), t, seq_dim=seq_dim)
+
+    rot.RotaryEmbedding, rot.apply_rotary_emb = RotaryEmbedding, apply_rotary_emb
+    sys.modules["rotary_embedding_torch"] = rot
+
+
+def save(name, meta, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    flat = {"__meta__": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
+    for k, v in arrays.items():
+        flat[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def grads_of(module):
+    return {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+
+
+# ------------------------------------------------------------------------------------------
+def variable_degree_graph(phys, lat, radius, heavy_token, n_heavy, gen):
+    """radius graph with empty latent rows and one row of degree > 32 (no PyG cap)."""
+    phys = phys.clone()
+    phys[:n_heavy] = lat[heavy_token] + 0.25 * radius * (torch.rand(n_heavy, 3, generator=gen) - 0.5)
+    enc = radius_edges_bruteforce(phys, lat, radius, max_num_neighbors=None, centers="latent")
+    return phys, enc
+
+
+def model_case(name, seed, n_per_graph, latent_tokens, magno_kw, tr_kw, attn_kw, ffn_kw, graph, out_ch,
+               feats, token_box=None):
+    from src.model import init_model
+    from src.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from src.model.layers.magno import MAGNOConfig
+
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    lo, hi = token_box if token_box is not None else ((-1.0,) * 3, (1.0,) * 3)
+    lat = latent_grid(latent_tokens, lo, hi)
+    m = lat.shape[0]
+    nscales = len(magno_kw.get("scales", [1.0]))
+    samples = []
+    for n in n_per_graph:
+        pos = torch.rand(n, 3, generator=gen) * 2 - 1
+        s = MeshBatch()
+        for si in range(nscales):
+            if graph == "knn":
+                enc = knn_edges_bruteforce(pos, lat, 4 + si)
+                dec = enc.flip(0)
+            else:
+                pos, enc = variable_degree_graph(pos, lat, 0.45 * (1 + si), heavy_token=5, n_heavy=40, gen=gen)
+                knn = knn_edges_bruteforce(pos, lat, 3).flip(0)                    # [latent, phys]
+                rad = radius_edges_bruteforce(pos, lat, 0.5, None, centers="phys")  # [latent, phys]
+                dec = coalesce_edges(torch.cat([knn, rad], dim=1), n)
+            setattr(s, f"encoder_edge_index_s{si}", enc.to(torch.int32))
+            setattr(s, f"decoder_edge_index_s{si}", dec.to(torch.int32))
+        s.pos = pos
+        s.x = torch.randn(n, out_ch, generator=gen)
+        for a, w in feats.items():
+            if a != "pos":
+                setattr(s, a, torch.randn(n, w, generator=gen))
+        samples.append(s)
+    batch = MeshBatch.from_data_list(samples, m)
+    in_size = sum(feats.values())
+    attr = list(feats.keys()) if len(feats) > 1 else list(feats.keys())[0]
+
+    mc = MAGNOConfig(gno_coord_dim=3, lifting_channels=32, encoder_feature_attr=attr, precompute_edges=True,
+                     **magno_kw)
+    tc = TransformerConfig(attn_config=AttentionConfig(atten_dropout=0.0, **attn_kw),
+                           ffn_config=FFNConfig(**ffn_kw), **tr_kw)
+    cfg = types.SimpleNamespace(magno=mc, transformer=tc, latent_tokens=tuple(latent_tokens))
+    model = init_model(in_size, out_ch, "gaot_3d", cfg)
+    model.train()
+    # make biases / norm weights non-trivial so that a dropped bias shows up
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if p.requires_grad and (k.endswith("norm.weight") or k.endswith(".bias")):
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    tokens = lat if token_box is not None else None
+    enc_out = model.encoder(batch=batch, latent_tokens_pos=lat.repeat(len(samples), 1),
+                            latent_tokens_batch_idx=torch.arange(len(samples)).repeat_interleave(m))
+    proc_out = model.process(enc_out)
+    pred = model(batch=batch, tokens_pos=tokens) if tokens is not None else model(batch)
+    loss = nn.MSELoss()(pred, batch.x)
+    loss.backward()
+    arrays = {}
+    for k, v in model.state_dict().items():
+        arrays["sd/" + k] = v
+    for k in batch.keys():
+        v = getattr(batch, k)
+        if torch.is_tensor(v):
+            arrays["in/" + k] = v
+    if tokens is not None:
+        arrays["in/tokens_pos"] = tokens
+    arrays["out/encoder"] = enc_out
+    arrays["out/processor"] = proc_out
+    arrays["out/pred"] = pred
+    arrays["out/loss"] = loss
+    for k, g in grads_of(model).items():
+        arrays["grad/" + k] = g
+    meta = dict(name=name, seed=seed, num_graphs=len(samples), latent_tokens=list(latent_tokens),
+                in_size=in_size, out_size=out_ch, feats=feats,
+                magno=dict(gno_coord_dim=3, lifting_channels=32, encoder_feature_attr=attr,
+                           precompute_edges=True, **magno_kw),
+                transformer=dict(tr_kw), attn=dict(atten_dropout=0.0, **attn_kw), ffn=dict(ffn_kw),
+                rope_note="rope: third-party, unpinned" if tr_kw.get("positional_embedding") == "rope" else "",
+                nparams=sum(p.numel() for p in model.parameters()))
+    save(name, meta, arrays)
+
+
+def ops_case():
+    """Operator-level goldens: scatter, IntegralTransform variants, GeoEmbed variants."""
+    from src.model.layers.geoembed import GeometricEmbedding
+    from src.model.layers.integral_transform import IntegralTransform
+    from src.model.layers.utils.scatter_native import scatter_native
+
+    gen = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
+    lat = latent_grid((4, 4, 3))
+    pos = torch.rand(260, 3, generator=gen) * 2 - 1
+    pos, enc = variable_degree_graph(pos, lat, 0.45, heavy_token=9, n_heavy=45, gen=gen)
+    arrays = {"in/pos": pos, "in/lat": lat, "in/edge_index": enc.to(torch.int32)}
+    nq = lat.shape[0]
+    # scatter
+    src = torch.randn(enc.shape[1], 5, generator=gen)
+    arrays["in/scatter_src"] = src
+    for red in ("sum", "mean", "max", "min"):
+        arrays[f"out/scatter_{red}"] = scatter_native(src, enc[1].long(), dim=0, dim_size=nq, reduce=red)
+    # integral transform variants
+    f_y = torch.randn(pos.shape[0], 32, generator=gen)
+    arrays["in/f_y"] = f_y
+    variants = []
+    for tt in ("linear", "nonlinear", "nonlinear_kernelonly"):
+        for attn in (None, "cosine", "dot_product"):
+            tag = f"it_{tt}_{attn or 'noattn'}"
+            in_dim = 6 + (32 if tt != "linear" else 0)
+            it = IntegralTransform(channel_mlp_layers=[in_dim, 64, 64, 32], transform_type=tt,
+                                   use_attn=bool(attn), coord_dim=3, attention_type=attn or "cosine")
+            with torch.no_grad():
+                for p in it.parameters():
+                    if p.dim() == 1:
+                        p.add_(0.1 * torch.randn(p.shape, generator=gen))
+            f = f_y.clone().requires_grad_(True)
+            out = it(y_pos=pos, x_pos=lat, edge_index=enc, f_y=f)
+            w = torch.randn(out.shape, generator=gen)
+            (out * w).sum().backward()
+            arrays[f"in/{tag}/w"] = w
+            arrays[f"out/{tag}/out"] = out
+            arrays[f"grad/{tag}/f_y"] = f.grad
+            for k, v in it.state_dict().items():
+                arrays[f"sd/{tag}/{k}"] = v
+            for k, g in grads_of(it).items():
+                arrays[f"grad/{tag}/{k}"] = g
+            variants.append(dict(tag=tag, transform_type=tt, attn=attn))
+    # empty edge list (integral_transform.py:106-112)
+    it = IntegralTransform(channel_mlp_layers=[6, 64, 32])
+    arrays["out/it_empty"] = it(y_pos=pos, x_pos=lat, edge_index=torch.zeros(2, 0, dtype=torch.long), f_y=f_y)
+    # geoembed
+    for method, pooling in (("statistical", "max"), ("pointnet", "max"), ("pointnet", "mean")):
+        tag = f"geo_{method}_{pooling}"
+        ge = GeometricEmbedding(3, 32, method=method, pooling=pooling)
+        out = ge(pos, lat, enc)
+        w = torch.randn(out.shape, generator=gen)
+        (out * w).sum().backward()
+        arrays[f"in/{tag}/w"] = w
+        arrays[f"out/{tag}/out"] = out
+        for k, v in ge.state_dict().items():
+            arrays[f"sd/{tag}/{k}"] = v
+        for k, g in grads_of(ge).items():
+            arrays[f"grad/{tag}/{k}"] = g
+        if method == "statistical":
+            arrays["out/geo_stat_features"] = ge._compute_statistical_features_pyg(pos, lat, enc)
+    save("ops", dict(name="ops", variants=variants, nq=nq), arrays)
+
+
+def main():
+    assert os.path.isdir(REF), f"{REF} not present: goldens can only be regenerated in the authoring container"
+    install_stubs()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(4)
+    ops_case()
+    model_case("model_knn_abs", seed=1, n_per_graph=[200], latent_tokens=(4, 4, 4),
+               magno_kw=dict(use_geoembed=[True, False], mlp_type="linear", neighbor_strategy="knn", k_neighbors=4),
+               tr_kw=dict(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="absolute"),
+               attn_kw=dict(hidden_size=64, num_heads=2, num_kv_heads=2), ffn_kw=dict(hidden_size=128),
+               graph="knn", out_ch=1, feats={"pos": 3, "c": 3})
+    model_case("model_radius_rope", seed=2, n_per_graph=[150, 170], latent_tokens=(4, 4, 2),
+               magno_kw=dict(use_geoembed=[True, True], mlp_type="linear", neighbor_strategy=["radius", "bidirectional"]),
+               tr_kw=dict(patch_size=1, hidden_size=64, num_layers=3, positional_embedding="rope"),
+               attn_kw=dict(hidden_size=64, num_heads=2, num_kv_heads=1), ffn_kw=dict(hidden_size=128),
+               graph="radius", out_ch=4, feats={"pos": 3, "c": 2},
+               token_box=((-0.9, -0.8, -0.7), (0.9, 0.8, 0.7)))
+    model_case("model_channel_multiscale", seed=3, n_per_graph=[120], latent_tokens=(2, 4, 4),
+               magno_kw=dict(use_geoembed=False, mlp_type="channel", scales=[1.0, 2.0], use_scale_weights=True,
+                             in_gno_channel_mlp_hidden_layers=[64, 64], out_gno_channel_mlp_hidden_layers=[64]),
+               tr_kw=dict(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="rope",
+                          use_long_range_skip=False),
+               attn_kw=dict(hidden_size=64, num_heads=2, num_kv_heads=2), ffn_kw=dict(hidden_size=96),
+               graph="knn", out_ch=2, feats={"pos": 3})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""CPU: the oracle (oracle/gaot_oracle.py) against golden vectors captured from the reference.
+This is what pins the oracle; rope cases are 'third-party, unpinned'."""
+import sys
+
+import pytest
+import torch
+
+import golden_io as gio
+
+sys.path.insert(0, gio.os.path.join(gio.os.path.dirname(gio.GOLDEN_DIR), "..", "oracle"))
+import gaot_oracle as orc  # noqa: E402
+
+MODEL_CASES = ["model_knn_abs", "model_radius_rope", "model_channel_multiscale"]
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err:.3e}"
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_model_forward_backward(case):
+    meta, g = gio.load(case)
+    cfg = gio.ns_config(meta)
+    batch = gio.batch_from(meta, g["in"])
+    tokens = g["in"].get("tokens_pos")
+    sd = g["sd"]
+    nb = meta["num_graphs"]
+    lat = (sd["latent_tokens"] if tokens is None else tokens).repeat(nb, 1)
+    enc = orc.magno_encoder(sd, cfg.magno, batch, lat)
+    close(enc, g["out"]["encoder"])
+    proc = orc.process(sd, cfg.transformer, cfg.latent_tokens, g["out"]["encoder"])
+    close(proc, g["out"]["processor"])
+    pred, loss, grads = orc.train_step_grads(sd, cfg, batch, tokens)
+    close(pred, g["out"]["pred"])
+    close(loss, g["out"]["loss"], rtol=1e-5, atol=1e-7)
+    assert set(grads.keys()) == set(g["grad"].keys()), set(grads.keys()) ^ set(g["grad"].keys())
+    for k, gr in g["grad"].items():
+        close(grads[k], gr, rtol=1e-3, atol=1e-6)
+
+
+def test_scatter():
+    meta, g = gio.load("ops")
+    idx = g["in"]["edge_index"][1].long()
+    for red in ("sum", "mean", "max", "min"):
+        close(orc.scatter(g["in"]["scatter_src"], idx, meta["nq"], red), g["out"][f"scatter_{red}"], 1e-6, 1e-6)
+
+
+def test_integral_transform_variants():
+    meta, g = gio.load("ops")
+    pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
+    for v in meta["variants"]:
+        tag = v["tag"]
+        sd = {k: t.clone().requires_grad_(True) for k, t in gio.sub(g["sd"], tag).items()}
+        f = g["in"]["f_y"].clone().requires_grad_(True)
+        out = orc.integral_transform(sd, "", pos, lat, ei, f, v["transform_type"], bool(v["attn"]), 3,
+                                     v["attn"] or "cosine")
+        close(out, g["out"][f"{tag}/out"])
+        (out * g["in"][f"{tag}/w"]).sum().backward()
+        close(f.grad, g["grad"][f"{tag}/f_y"], 1e-3, 1e-6)
+        for k, gr in gio.sub(g["grad"], tag).items():
+            if k != "f_y":
+                close(sd[k].grad, gr, 1e-3, 1e-5)
+    sd = {"channel_mlp.fcs.0.weight": torch.zeros(64, 6), "channel_mlp.fcs.0.bias": torch.zeros(64),
+          "channel_mlp.fcs.1.weight": torch.zeros(32, 64), "channel_mlp.fcs.1.bias": torch.zeros(32)}
+    out = orc.integral_transform(sd, "", pos, lat, torch.zeros(2, 0, dtype=torch.long), g["in"]["f_y"])
+    close(out, g["out"]["it_empty"])
+
+
+def test_geoembed_variants():
+    meta, g = gio.load("ops")
+    pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
+    close(orc.geoembed_stat_features(pos, lat, ei), g["out"]["geo_stat_features"], 1e-4, 1e-5)
+    for method, pooling in (("statistical", "max"), ("pointnet", "max"), ("pointnet", "mean")):
+        tag = f"geo_{method}_{pooling}"
+        sd = {k: t.clone().requires_grad_(True) for k, t in gio.sub(g["sd"], tag).items()}
+        out = orc.geoembed(sd, "", pos, lat, ei, method, pooling)
+        close(out, g["out"][f"{tag}/out"])
+        (out * g["in"][f"{tag}/w"]).sum().backward()
+        for k, gr in gio.sub(g["grad"], tag).items():
+            close(sd[k].grad, gr, 1e-3, 1e-5)
