@@ -1,0 +1,71 @@
+"""ctypes binding of libgaot3d_hip.so (C ABI in include/gaot3d_hip.h).
+
+The library is built in-tree (``gaot_3d_amd/lib/libgaot3d_hip.so``) by ``__graft_entry__.build()`` /
+``make -C gaot_3d_amd/csrc``.  There is NO fallback: if the library is missing or a call fails the
+product raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgaot3d_hip.so")
+
+MAX_MLP_LAYERS = 5
+
+
+class GaotError(RuntimeError):
+    pass
+
+
+class MlpT(C.Structure):
+    _fields_ = [("n_hidden", C.c_int), ("hidden", C.c_int), ("channels", C.c_int),
+                ("weight", C.c_void_p * MAX_MLP_LAYERS), ("bias", C.c_void_p * MAX_MLP_LAYERS)]
+
+
+class MlpGradT(C.Structure):
+    _fields_ = [("weight", C.c_void_p * MAX_MLP_LAYERS), ("bias", C.c_void_p * MAX_MLP_LAYERS)]
+
+
+_lib = None
+
+_p, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/gaot3d_hip.h declares
+SIGNATURES = {
+    "gaot_abi_version": (_i, []),
+    "gaot_last_error": (C.c_char_p, []),
+    "gaot_csr_workspace_bytes": (_sz, [_i64, _i64]),
+    "gaot_csr_build": (_i, [_p, _i, _i64, _i, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "gaot_gno_fwd_workspace_bytes": (_sz, [_i64, _i]),
+    "gaot_gno_fwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
+    "gaot_gno_bwd_workspace_bytes": (_sz, [C.POINTER(MlpT), _i64]),
+    "gaot_gno_bwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p,
+                          C.POINTER(MlpGradT), _p, _sz, _p]),
+}
+
+
+def load():
+    """Load the shared library (once).  Raises GaotError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GaotError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C gaot_3d_amd/csrc` (there is no CPU/PyTorch fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gaot_abi_version() != 1:
+        raise GaotError("libgaot3d_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gaot_last_error()
+        raise GaotError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,61 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the GAOT-3D hot path.
+// Wave = 64 lanes everywhere in this library; nothing here is portable to 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "../../include/gaot3d_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+void gaot_set_error(const char* fmt, ...);
+
+#define GAOT_CHECK_ARG(cond, msg)                         \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            gaot_set_error("%s: %s", __func__, msg);      \
+            return GAOT_ERR_ARG;                          \
+        }                                                 \
+    } while (0)
+
+// clear any sticky error left by an earlier failed call of this thread
+#define GAOT_ENTER() (void)hipGetLastError()
+
+#define GAOT_LAUNCH_CHECK()                                                        \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            gaot_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return GAOT_ERR_LAUNCH;                                                \
+        }                                                                          \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Row of a 32x32 MFMA C/D tile held in register r (0..15) of a lane in half h (lane>>5):
+// row = (r&3) + 8*(r>>2) + 4*h ; column = lane&31.   (dtype independent on gfx950)
+__device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// exact-erf GELU (torch F.gelu default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,203 @@
+// Neighbour-list (CSR) builder: turns the PyG-style bipartite ``edge_index [2,E]`` the reference
+// feeds to IntegralTransform (reference src/model/layers/integral_transform.py:114-115: row 0 =
+// source index, row 1 = query index) into a list sorted by one of the two rows, so that the
+// torch_scatter-style segmented reductions (reference scatter_native.py:21-31) become contiguous
+// wavefront segmented sums with no atomics in the data path.
+//
+// Stable counting sort, all on device, no host sync:
+//   1. histogram of keys (int atomics, L2)         2. exclusive scan -> rowptr
+//   3. scatter edge ids through per-row cursors     4. per-row rank sort of the edge ids
+// Step 4 makes the order inside a row = original edge order, so every later floating-point
+// segmented sum is bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+template <typename IDX>
+__global__ void k_hist(const IDX* __restrict__ keys, int64_t E, int* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < E; i += stride) atomicAdd(&counts[(int)keys[i]], 1);
+}
+
+// ---- 3-phase exclusive scan over n ints (n up to ~2^31) -------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;  // per thread
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__global__ void k_scan_reduce(const int* __restrict__ in, int64_t n, int* __restrict__ block_sums) {
+    __shared__ int red[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        int64_t i = base + (int64_t)threadIdx.x * SCAN_ITEMS + j;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += red[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of block_sums in place
+__global__ void k_scan_blocksums(int* __restrict__ block_sums, int nb) {
+    __shared__ int carry;
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += SCAN_BLOCK) {
+        int i = base + threadIdx.x;
+        int v = (i < nb) ? block_sums[i] : 0;
+        int incl = v;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        const int c = carry;
+        if (i < nb) block_sums[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry = c + woff + incl;
+        __syncthreads();
+    }
+}
+
+// out[i] = exclusive prefix; also copies to cursor[i]; writes out[n] = total when i==n-1
+__global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* __restrict__ block_offs,
+                             int* __restrict__ out, int* __restrict__ cursor) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0;
+        s += v[j];
+    }
+    int incl = s;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = block_offs[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+    int run = off + incl - s;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) {
+            out[base + j] = run;
+            cursor[base + j] = run;
+        }
+        run += v[j];
+        if (base + j == n - 1) out[n] = run;
+    }
+}
+
+template <typename IDX>
+__global__ void k_fill(const IDX* __restrict__ keys, int64_t E, int* __restrict__ cursor, int* __restrict__ tmp) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < E; i += stride) {
+        int p = atomicAdd(&cursor[(int)keys[i]], 1);
+        tmp[p] = (int)i;
+    }
+}
+
+// G lanes cooperate on one row: rank sort of the (unique) edge ids of the row, then emit the
+// sorted id, the key and the other endpoint.  G in {8, 64}.
+template <typename IDX, int G>
+__global__ void k_row_sort(const IDX* __restrict__ keys, const IDX* __restrict__ other, int64_t Q,
+                           const int* __restrict__ rowptr, const int* __restrict__ tmp, int* __restrict__ perm,
+                           int* __restrict__ key_sorted, int* __restrict__ other_sorted) {
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    if (gid >= Q) return;
+    const int b = rowptr[gid], e = rowptr[gid + 1];
+    const int n = e - b;
+    for (int i = gl; i < n; i += G) {
+        const int id = tmp[b + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (tmp[b + j] < id) ? 1 : 0;
+        const int p = b + rank;
+        perm[p] = id;
+        key_sorted[p] = (int)gid;
+        other_sorted[p] = (int)other[id];
+    }
+}
+
+template <typename IDX>
+int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32_t* rowptr, int32_t* perm,
+                int32_t* key_sorted, int32_t* other_sorted, void* ws, hipStream_t st) {
+    const IDX* keys = edge_index + (sort_row ? E : 0);
+    const IDX* other = edge_index + (sort_row ? 0 : E);
+    const int64_t n = Q;  // counts has Q entries (+1 slot for the total)
+    const int nb = (int)ceil_div(n, SCAN_TILE);
+    int* counts = (int*)ws;                 // [Q+1]
+    int* cursor = counts + (Q + 1);         // [Q+1]
+    int* bsum = cursor + (Q + 1);           // [nb+1]
+    int* tmp = bsum + (nb + 1);             // [E]
+    hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(Q + 1), st);
+    if (E == 0) {
+        hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
+        return GAOT_OK;
+    }
+    const int tb = 256;
+    const int gb = (int)std::min<int64_t>(ceil_div(E, tb), 256 * 16);
+    hipLaunchKernelGGL((k_hist<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, counts);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum, rowptr, cursor);
+    hipLaunchKernelGGL((k_fill<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, cursor, tmp);
+    if (E / (Q > 0 ? Q : 1) >= 16) {
+        const int64_t threads = Q * 64;
+        hipLaunchKernelGGL((k_row_sort<IDX, 64>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted);
+    } else {
+        const int64_t threads = Q * 8;
+        hipLaunchKernelGGL((k_row_sort<IDX, 8>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted);
+    }
+    return GAOT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gaot_csr_workspace_bytes(int64_t num_edges, int64_t num_rows) {
+    const int64_t nb = ceil_div(num_rows, SCAN_TILE);
+    return sizeof(int) * (size_t)(2 * (num_rows + 1) + (nb + 1) + num_edges) + 64;
+}
+
+extern "C" int gaot_csr_build(const void* edge_index, int index_is_i64, int64_t num_edges, int sort_row,
+                              int64_t num_rows, int32_t* rowptr, int32_t* perm, int32_t* key_sorted,
+                              int32_t* other_sorted, void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_edges >= 0 && num_rows >= 0, "negative size");
+    GAOT_CHECK_ARG(num_edges < (int64_t)1 << 31 && num_rows < ((int64_t)1 << 31) - 1, "sizes must fit int32");
+    GAOT_CHECK_ARG(sort_row == 0 || sort_row == 1, "sort_row must be 0 or 1");
+    GAOT_CHECK_ARG(rowptr && workspace, "null pointer");
+    GAOT_CHECK_ARG(num_edges == 0 || (edge_index && perm && key_sorted && other_sorted), "null pointer");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_csr_workspace_bytes(num_edges, num_rows), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = index_is_i64 ? csr_build_t<int64_t>((const int64_t*)edge_index, num_edges, sort_row, num_rows, rowptr,
+                                                 perm, key_sorted, other_sorted, workspace, st)
+                          : csr_build_t<int32_t>((const int32_t*)edge_index, num_edges, sort_row, num_rows, rowptr,
+                                                 perm, key_sorted, other_sorted, workspace, st);
+    if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

@@ -1,0 +1,177 @@
+"""GPU parity: CSR builder and the fused GNO integral transform (fwd + bwd) through the C ABI,
+against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py) and the committed
+golden vectors.  Tolerances: outputs rtol 1e-4 / atol 1e-5, grads rtol 1e-3 / atol 1e-5."""
+import os
+import sys
+
+import pytest
+import torch
+
+import golden_io as gio
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import gaot_oracle as orc  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def report(name, a, b):
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    rel = err / (b.abs().max().item() + 1e-30) if a.numel() else 0.0
+    print(f"[parity] {name}: max_abs={err:.3e} max_rel_to_peak={rel:.3e}")
+    return err
+
+
+def close(name, a, b, rtol, atol):
+    a = a.detach().cpu()
+    b = b.detach().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    report(name, a, b)
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{name}: max abs err {(a - b).abs().max().item():.3e}"
+
+
+def rand_graph(n_src, n_dst, e, seed, empty_rows=True, heavy=True, dtype=torch.int64):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n_src, (e,), generator=g)
+    dst = torch.randint(0, n_dst, (e,), generator=g)
+    if empty_rows and e > 0:
+        m = dst % 7 == 3
+        dst[m] = (dst[m] + 1) % n_dst                          # some rows never hit
+    if heavy and e > 0:
+        dst[: e // 10] = n_dst // 2                            # one row with >> 32 edges
+    return torch.stack([src, dst]).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("e,nr", [(0, 5), (1, 1), (1000, 37), (50000, 4096), (200000, 70000)])
+def test_csr_build(dtype, e, nr):
+    from gaot_3d_amd import ops
+    ei = rand_graph(max(nr, 1) * 2, nr, e, seed=e + nr, dtype=dtype)
+    for sort_row, rows in ((1, nr), (0, max(nr, 1) * 2)):
+        s = ops.csr_build(ei.to(DEV), sort_row, rows)
+        torch.cuda.synchronize()
+        key = ei[sort_row].long()
+        order = torch.sort(key, stable=True).indices
+        cnt = torch.bincount(key, minlength=rows)
+        rowptr = torch.zeros(rows + 1, dtype=torch.long)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        assert torch.equal(s.rowptr.cpu().long(), rowptr)
+        assert torch.equal(s.perm.cpu().long(), order)              # stable: bit-exact permutation
+        assert torch.equal(s.key.cpu().long(), key[order])
+        assert torch.equal(s.other.cpu().long(), ei[1 - sort_row].long()[order])
+
+
+def _mlp_sd(layers, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i in range(len(layers) - 1):
+        bound = 1.0 / layers[i] ** 0.5
+        sd[f"channel_mlp.fcs.{i}.weight"] = (torch.rand(layers[i + 1], layers[i], generator=g) * 2 - 1) * bound
+        sd[f"channel_mlp.fcs.{i}.bias"] = (torch.rand(layers[i + 1], generator=g) * 2 - 1) * bound
+    return sd
+
+
+def _run_gno(sd, y_pos, x_pos, ei, f_y, w_out):
+    from gaot_3d_amd import ops
+    n = len([k for k in sd if k.endswith("weight")])
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(n)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(n)]
+    g = ops.build_graph(ei.to(DEV), y_pos.shape[0], x_pos.shape[0])
+    yd, xd, fd = y_pos.to(DEV), x_pos.to(DEV), f_y.to(DEV)
+    out = ops.gno_forward(ws, bs, yd, xd, fd, g)
+    gf, gw, gb = ops.gno_backward(ws, bs, yd, xd, fd, w_out.to(DEV), g)
+    torch.cuda.synchronize()
+    return out, gf, gw, gb
+
+
+def _oracle_gno(sd, y_pos, x_pos, ei, f_y, w_out):
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    f = f_y.clone().requires_grad_(True)
+    out = orc.integral_transform(sdr, "", y_pos, x_pos, ei, f)
+    (out * w_out).sum().backward()
+    return out.detach(), f.grad, sdr
+
+
+def _compare(sd, y_pos, x_pos, ei, f_y, w_out, tag):
+    out, gf, gw, gb = _run_gno(sd, y_pos, x_pos, ei, f_y, w_out)
+    ro, rgf, sdr = _oracle_gno(sd, y_pos, x_pos, ei, f_y, w_out)
+    close(f"{tag}/out", out, ro, 1e-4, 1e-5)
+    close(f"{tag}/grad_f", gf, rgf, 1e-3, 1e-5)
+    for i in range(len(gw)):
+        rw = sdr[f"channel_mlp.fcs.{i}.weight"].grad
+        rb = sdr[f"channel_mlp.fcs.{i}.bias"].grad
+        scale = max(1.0, rw.abs().max().item())
+        close(f"{tag}/grad_w{i}", gw[i] / scale, rw / scale, 1e-3, 1e-5)
+        close(f"{tag}/grad_b{i}", gb[i] / scale, rb / scale, 1e-3, 1e-5)
+
+
+def test_gno_golden_variable_degree():
+    """IntegralTransform 'linear' golden captured from the reference (empty rows + a >32-degree row)."""
+    meta, g = gio.load("ops")
+    tag = "it_linear_noattn"
+    sd = gio.sub(g["sd"], tag)
+    pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
+    w = g["in"][f"{tag}/w"]
+    out, gf, gw, gb = _run_gno(sd, pos, lat, ei, g["in"]["f_y"], w)
+    close("golden/out", out, g["out"][f"{tag}/out"], 1e-4, 1e-5)
+    close("golden/grad_f", gf, g["grad"][f"{tag}/f_y"], 1e-3, 1e-5)
+    gg = gio.sub(g["grad"], tag)
+    for i in range(len(gw)):
+        close(f"golden/grad_w{i}", gw[i], gg[f"channel_mlp.fcs.{i}.weight"], 1e-3, 1e-5)
+        close(f"golden/grad_b{i}", gb[i], gg[f"channel_mlp.fcs.{i}.bias"], 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("nh", [1, 2, 3, 4])
+def test_gno_random_graph(nh):
+    gen = torch.Generator().manual_seed(nh)
+    n_src, n_dst, e = 3000, 700, 20011
+    ei = rand_graph(n_src, n_dst, e, seed=10 + nh, dtype=torch.int32)
+    y = torch.rand(n_src, 3, generator=gen) * 2 - 1
+    x = torch.rand(n_dst, 3, generator=gen) * 2 - 1
+    f = torch.randn(n_src, 32, generator=gen)
+    w = torch.randn(n_dst, 32, generator=gen)
+    sd = _mlp_sd([6] + [64] * nh + [32], seed=nh)
+    _compare(sd, y, x, ei, f, w, f"rand_nh{nh}")
+
+
+def test_gno_knn_fixed_degree_and_flip():
+    """encoder-style knn graph (phys-major) and its flip (decoder): fixed degree on one side."""
+    from gaot_3d_amd.data import knn_edges_bruteforce, latent_grid
+    gen = torch.Generator().manual_seed(5)
+    lat = latent_grid((6, 6, 5))
+    pos = torch.rand(2000, 3, generator=gen) * 2 - 1
+    enc = knn_edges_bruteforce(pos, lat, 8).to(torch.int32)
+    f = torch.randn(2000, 32, generator=gen)
+    _compare(_mlp_sd([6, 64, 64, 64, 32], 1), pos, lat, enc, f, torch.randn(lat.shape[0], 32, generator=gen), "enc_knn")
+    fl = torch.randn(lat.shape[0], 32, generator=gen)
+    _compare(_mlp_sd([6, 64, 64, 32], 2), lat, pos, enc.flip(0).contiguous(), fl,
+             torch.randn(2000, 32, generator=gen), "dec_flip")
+
+
+def test_gno_empty_and_tiny():
+    sd = _mlp_sd([6, 64, 32], 3)
+    y = torch.rand(5, 3)
+    x = torch.rand(4, 3)
+    f = torch.randn(5, 32)
+    w = torch.randn(4, 32)
+    out, gf, gw, gb = _run_gno(sd, y, x, torch.zeros(2, 0, dtype=torch.int64), f, w)
+    assert out.abs().max().item() == 0.0 and gf.abs().max().item() == 0.0
+    assert all(t.abs().max().item() == 0.0 for t in gw + gb)
+    _compare(sd, y, x, torch.tensor([[0, 4, 2], [1, 1, 3]]), f, w, "tiny")
+
+
+def test_gno_deterministic():
+    """no float atomics anywhere: two runs are bit-identical"""
+    gen = torch.Generator().manual_seed(9)
+    ei = rand_graph(5000, 900, 60000, seed=3, dtype=torch.int32)
+    y = torch.rand(5000, 3, generator=gen)
+    x = torch.rand(900, 3, generator=gen)
+    f = torch.randn(5000, 32, generator=gen)
+    w = torch.randn(900, 32, generator=gen)
+    sd = _mlp_sd([6, 64, 64, 64, 32], 4)
+    a = _run_gno(sd, y, x, ei, f, w)
+    b = _run_gno(sd, y, x, ei, f, w)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v in zip(a[2] + a[3], b[2] + b[3]):
+        assert torch.equal(u, v)
