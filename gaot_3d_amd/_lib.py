@@ -43,6 +43,28 @@ SIGNATURES = {
     "gaot_gno_bwd_workspace_bytes": (_sz, [C.POINTER(MlpT), _i64]),
     "gaot_gno_bwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p,
                           C.POINTER(MlpGradT), _p, _sz, _p]),
+    "gaot_geoembed_stats_workspace_bytes": (_sz, []),
+    "gaot_geoembed_stats": (_i, [_p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "gaot_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
+    "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _i, _p]),
+    "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p]),
+    "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
+    "gaot_colsum_workspace_bytes": (_sz, [_i64, _i64]),
+    "gaot_colsum": (_i, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
+    "gaot_rope": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _p, _i, _p]),
+    "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
+    "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
+    "gaot_patchify": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "gaot_mse_workspace_bytes": (_sz, []),
+    "gaot_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "gaot_mse_bwd": (_i, [_p, _p, _i64, _p, _p, _p]),
+    "gaot_scale_mix_fwd": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
+    "gaot_scale_mix_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i64, _i, _p]),
 }
 
 

@@ -1,0 +1,173 @@
+// Statistical geometric embedding features (reference GeometricEmbedding.
+// _compute_statistical_features_pyg, src/model/layers/geoembed.py:99-182): per query node, from its
+// incident edges:  [N_i, mean dist, var dist, centroid - query (3), eigenvalues of the centred
+// covariance + 1e-6 I (3, descending)];  rows without neighbours are zeroed, then every column is
+// z-scored over ALL query rows (unbiased std; std < 1e-6 -> 1).
+//
+// The reference spends 6 scatter passes + a batched LAPACK eigvalsh; here: one sweep over the
+// row-sorted neighbour list (8 lanes per row, two passes per row: centroid, then covariance, all
+// sums in fp64), a cyclic Jacobi 3x3 eigen-solve in registers, a two-stage column reduction and a
+// normalise pass.  Inputs are coordinates only (no autograd), so the result is cacheable per sample.
+#include "common.h"
+
+namespace {
+
+constexpr int NF = 9;
+constexpr int G = 8;  // lanes per query row
+
+__device__ __forceinline__ double grp_sum(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq) {
+    if (fabs(apq) < 1e-300) return;
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    app -= t * apq;
+    aqq += t * apq;
+    apq = 0.0;
+    const double rp = c * arp - s * arq, rq = s * arp + c * arq;
+    arp = rp;
+    arq = rq;
+}
+
+__global__ void k_geo_raw(const float* __restrict__ src_pos, const float* __restrict__ q_pos,
+                          const int* __restrict__ rowptr, const int* __restrict__ src_sorted, int64_t Q,
+                          float* __restrict__ feat) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    if (row >= Q) return;  // whole groups exit together (G divides the block size)
+    const int b = rowptr[row], e = rowptr[row + 1];
+    const int n = e - b;
+    float out[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) out[i] = 0.f;
+    if (n > 0) {
+        const double qx = q_pos[row * 3 + 0], qy = q_pos[row * 3 + 1], qz = q_pos[row * 3 + 2];
+        double sd = 0, sd2 = 0, sx = 0, sy = 0, sz = 0;
+        for (int i = b + gl; i < e; i += G) {
+            const int s = src_sorted[i];
+            const float fx = src_pos[(int64_t)s * 3 + 0], fy = src_pos[(int64_t)s * 3 + 1], fz = src_pos[(int64_t)s * 3 + 2];
+            // distance as the reference computes it: fp32 difference, fp32 norm
+            const float dx = fx - (float)qx, dy = fy - (float)qy, dz = fz - (float)qz;
+            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+            sd += dist;
+            sd2 += (double)dist * (double)dist;
+            sx += fx; sy += fy; sz += fz;
+        }
+        sd = grp_sum(sd); sd2 = grp_sum(sd2); sx = grp_sum(sx); sy = grp_sum(sy); sz = grp_sum(sz);
+        const double inv = 1.0 / (double)n;
+        const double davg = sd * inv;
+        double dvar = sd2 * inv - davg * davg;
+        if (dvar < 0.0) dvar = 0.0;
+        const double cx = sx * inv, cy = sy * inv, cz = sz * inv;
+        double cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+        for (int i = b + gl; i < e; i += G) {
+            const int s = src_sorted[i];
+            const double ux = (double)src_pos[(int64_t)s * 3 + 0] - cx, uy = (double)src_pos[(int64_t)s * 3 + 1] - cy,
+                         uz = (double)src_pos[(int64_t)s * 3 + 2] - cz;
+            cxx += ux * ux; cxy += ux * uy; cxz += ux * uz; cyy += uy * uy; cyz += uy * uz; czz += uz * uz;
+        }
+        cxx = grp_sum(cxx); cxy = grp_sum(cxy); cxz = grp_sum(cxz); cyy = grp_sum(cyy); cyz = grp_sum(cyz); czz = grp_sum(czz);
+        double a00 = cxx * inv + 1e-6, a11 = cyy * inv + 1e-6, a22 = czz * inv + 1e-6;
+        double a01 = cxy * inv, a02 = cxz * inv, a12 = cyz * inv;
+#pragma unroll 1
+        for (int sweep = 0; sweep < 8; ++sweep) {
+            jacobi_rot(a00, a11, a01, a02, a12);
+            jacobi_rot(a00, a22, a02, a01, a12);
+            jacobi_rot(a11, a22, a12, a01, a02);
+        }
+        double l0 = a00, l1 = a11, l2 = a22, t;
+        if (l0 < l1) { t = l0; l0 = l1; l1 = t; }
+        if (l0 < l2) { t = l0; l0 = l2; l2 = t; }
+        if (l1 < l2) { t = l1; l1 = l2; l2 = t; }
+        out[0] = (float)n; out[1] = (float)davg; out[2] = (float)dvar;
+        out[3] = (float)(cx - qx); out[4] = (float)(cy - qy); out[5] = (float)(cz - qz);
+        out[6] = (float)l0; out[7] = (float)l1; out[8] = (float)l2;
+    }
+    if (gl == 0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) feat[row * NF + i] = out[i];
+    }
+}
+
+// per-block partial column sums (sum, sum of squares) in double
+__global__ void k_geo_colpart(const float* __restrict__ feat, int64_t Q, double* __restrict__ part) {
+    __shared__ double sm[4][2 * NF];
+    double s[NF], s2[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { s[i] = 0; s2[i] = 0; }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < Q; r += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const double v = feat[r * NF + i];
+            s[i] += v;
+            s2[i] += v * v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        s[i] = wave_sum_d(s[i]);
+        s2[i] = wave_sum_d(s2[i]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { sm[threadIdx.x >> 6][i] = s[i]; sm[threadIdx.x >> 6][NF + i] = s2[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NF)
+        part[(int64_t)blockIdx.x * 2 * NF + threadIdx.x] =
+            sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// stats[0..8] = mean, stats[9..17] = 1/std (1 if std < 1e-6)
+__global__ void k_geo_colfinal(const double* __restrict__ part, int nparts, int64_t Q, float* __restrict__ stats) {
+    const int i = threadIdx.x;
+    if (i >= NF) return;
+    double s = 0, s2 = 0;
+    for (int p = 0; p < nparts; ++p) { s += part[p * 2 * NF + i]; s2 += part[p * 2 * NF + NF + i]; }
+    const double mean = s / (double)Q;
+    double var = (Q > 1) ? (s2 - (double)Q * mean * mean) / (double)(Q - 1) : NAN;  // torch.std of one row = nan
+    if (var < 0) var = 0;
+    float sd = (float)sqrt(var);
+    if (sd < 1e-6f) sd = 1.f;
+    stats[i] = (float)mean;
+    stats[NF + i] = sd;
+}
+
+__global__ void k_geo_normalize(float* __restrict__ feat, int64_t Q, const float* __restrict__ stats) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * NF) return;
+    const int c = (int)(i % NF);
+    feat[i] = (feat[i] - stats[c]) / stats[NF + c];
+}
+
+}  // namespace
+
+extern "C" size_t gaot_geoembed_stats_workspace_bytes(void) { return sizeof(double) * 256 * 2 * NF + sizeof(float) * 2 * NF + 64; }
+
+extern "C" int gaot_geoembed_stats(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
+                                   const int32_t* src_sorted, int64_t num_queries, float* features, void* workspace,
+                                   size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_queries >= 0, "negative size");
+    if (num_queries == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && features && workspace, "null pointer");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    float* stats = (float*)(part + 256 * 2 * NF);
+    const int64_t threads = num_queries * G;
+    hipLaunchKernelGGL(k_geo_raw, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, source_pos, query_pos,
+                       rowptr_dst, src_sorted, num_queries, features);
+    const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
+    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);
+    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+                       num_queries, stats);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

@@ -1,0 +1,523 @@
+// HBM-bound row / element kernels of the latent Transformer and the model glue.  Each stands in
+// for a chain of ATen elementwise / reduction ops in the reference:
+//   rmsnorm      RMSNorm.forward                      src/model/layers/attn.py:174-178
+//   rope         rotate_queries_or_keys (1-D RoPE)    attn.py:118-120 (rotary_embedding_torch)
+//   swiglu       silu(w1 x) * w3 x                    attn.py:156
+//   act_bwd      autograd of F.gelu / ReLU            mlp.py:330-331, geoembed.py:37
+//   patchify     view/permute/contiguous              gaot_3d.py:199-202, 218-220
+//   mse          nn.MSELoss                           src/trainer/base.py:56
+//   colsum       bias gradients (sum over rows)
+// All reductions are two-stage in a fixed order (bit-reproducible), 16-byte vector accesses.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row, lanes stride the row in float4
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rmsnorm_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                              float* __restrict__ rstd, int64_t rows, int d, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    float ss = 0.f;
+    for (int i = lane; i < d / 4; i += 64) {
+        const float4 v = xr[i];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd) rstd[row] = r;
+    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    const float4* wr = reinterpret_cast<const float4*>(w);
+    for (int i = lane; i < d / 4; i += 64) {
+        const float4 v = xr[i], g = wr[i];
+        yr[i] = make_float4(v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w);
+    }
+}
+
+// dx = r*w*dy - x*r^3*mean(x*w*dy);  dw partial per block = sum_rows dy*x*r
+constexpr int RN_ROWS_PER_WAVE = 8;
+__global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                              const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dw_part,
+                              int64_t rows, int d) {
+    extern __shared__ float sm[];  // [4][d]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = d / 4;
+    const float4* wr = reinterpret_cast<const float4*>(w);
+    float4 dwacc[4];  // supports d <= 1024
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dwacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RN_ROWS_PER_WAVE;
+    for (int rr = 0; rr < RN_ROWS_PER_WAVE; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= rows) break;
+        const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+        const float4* gr = reinterpret_cast<const float4*>(dy + row * d);
+        const float r = rstd[row];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                const float4 v = xr[i], g = gr[i], ww = wr[i];
+                dot += v.x * g.x * ww.x + v.y * g.y * ww.y + v.z * g.z * ww.z + v.w * g.w * ww.w;
+            }
+        }
+        dot = wave_sum(dot);
+        const float c = dot * r * r * r / (float)d;
+        float4* dxr = reinterpret_cast<float4*>(dx + row * d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                const float4 v = xr[i], g = gr[i], ww = wr[i];
+                dxr[i] = make_float4(r * ww.x * g.x - v.x * c, r * ww.y * g.y - v.y * c, r * ww.z * g.z - v.z * c,
+                                     r * ww.w * g.w - v.w * c);
+                dwacc[j].x += g.x * v.x * r;
+                dwacc[j].y += g.y * v.y * r;
+                dwacc[j].z += g.z * v.z * r;
+                dwacc[j].w += g.w * v.w * r;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) reinterpret_cast<float4*>(sm + wave * d)[i] = dwacc[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256)
+        dw_part[(int64_t)blockIdx.x * d + i] = sm[i] + sm[d + i] + sm[2 * d + i] + sm[3 * d + i];
+}
+
+// out[n] = sum_{p<parts} part[p][n]   (fixed order)
+__global__ void k_reduce_parts(const float* __restrict__ part, int64_t parts, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int64_t p = 0; p < parts; ++p) s += part[p * n + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums of X[M][N] (ld): partial per row-chunk, then k_reduce_parts
+// ---------------------------------------------------------------------------------------------
+__global__ void k_colsum_part(const float* __restrict__ x, int64_t M, int64_t N, int64_t ld, int64_t rows_per_chunk,
+                              float* __restrict__ part) {
+    __shared__ float sm[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 columns x 8 row lanes
+    const int64_t n = (int64_t)blockIdx.x * 32 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = (r0 + rows_per_chunk < M) ? r0 + rows_per_chunk : M;
+    float s = 0.f;
+    if (n < N)
+        for (int64_t r = r0 + ry; r < r1; r += 8) s += x[r * ld + n];
+    sm[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += sm[j][cx];
+        part[(int64_t)blockIdx.y * N + n] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE, in place: rows of width ld; nheads heads of 32 starting at column col0.  pos = row % S.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rope(float* __restrict__ x, int64_t rows, int64_t ld, int col0, int nheads, int S,
+                       const float* __restrict__ freqs, float sign) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = rows * nheads * 16;
+    if (i >= n) return;
+    const int p = (int)(i % 16);
+    const int hd = (int)((i / 16) % nheads);
+    const int64_t row = i / (16 * nheads);
+    const float ang = (float)(row % S) * freqs[p];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    sn *= sign;
+    float2* px = reinterpret_cast<float2*>(x + row * ld + col0 + hd * 32 + 2 * p);
+    const float2 v = *px;
+    *px = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SwiGLU on a fused [rows][2F] buffer (a = cols 0..F-1 = w1 x, g = cols F..2F-1 = w3 x)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + __expf(-v)); }
+
+__global__ void k_swiglu_fwd(const float* __restrict__ ag, float* __restrict__ u, int64_t rows, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+    const int fv = F / 4;
+    if (i >= rows * fv) return;
+    const int64_t r = i / fv;
+    const int c = (int)(i % fv);
+    const float4 a = reinterpret_cast<const float4*>(ag + r * 2 * F)[c];
+    const float4 g = reinterpret_cast<const float4*>(ag + r * 2 * F + F)[c];
+    reinterpret_cast<float4*>(u + r * F)[c] =
+        make_float4(a.x * sigmoid_f(a.x) * g.x, a.y * sigmoid_f(a.y) * g.y, a.z * sigmoid_f(a.z) * g.z,
+                    a.w * sigmoid_f(a.w) * g.w);
+}
+
+__global__ void k_swiglu_bwd(const float* __restrict__ ag, const float* __restrict__ du, float* __restrict__ dag,
+                             int64_t rows, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int fv = F / 4;
+    if (i >= rows * fv) return;
+    const int64_t r = i / fv;
+    const int c = (int)(i % fv);
+    const float4 a = reinterpret_cast<const float4*>(ag + r * 2 * F)[c];
+    const float4 g = reinterpret_cast<const float4*>(ag + r * 2 * F + F)[c];
+    const float4 d = reinterpret_cast<const float4*>(du + r * F)[c];
+    auto f = [](float av, float gv, float dv, float& da, float& dg) {
+        const float s = sigmoid_f(av);
+        da = dv * gv * s * (1.f + av * (1.f - s));
+        dg = dv * av * s;
+    };
+    float4 da, dg;
+    f(a.x, g.x, d.x, da.x, dg.x);
+    f(a.y, g.y, d.y, da.y, dg.y);
+    f(a.z, g.z, d.z, da.z, dg.z);
+    f(a.w, g.w, d.w, da.w, dg.w);
+    reinterpret_cast<float4*>(dag + r * 2 * F)[c] = da;
+    reinterpret_cast<float4*>(dag + r * 2 * F + F)[c] = dg;
+}
+
+// dz = dh * act'(z)
+__global__ void k_act_bwd(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n,
+                          int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = z[i];
+    float d;
+    if (act == 1) d = gelu_grad_f(v);
+    else if (act == 2) d = v > 0.f ? 1.f : 0.f;
+    else if (act == 3) { const float s = sigmoid_f(v); d = s * (1.f + v * (1.f - s)); }
+    else d = 1.f;
+    dz[i] = dh[i] * d;
+}
+
+// out = a + alpha * b (b may be broadcast over rows with period `period` elements; period == n: plain)
+__global__ void k_axpy(const float* __restrict__ a, const float* __restrict__ b, float alpha, float* __restrict__ out,
+                       int64_t n, int64_t period) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = a[i] + alpha * b[i % period];
+}
+
+// ---------------------------------------------------------------------------------------------
+// patchify: tokens[b][(pd,ph,pw)][(i,j,k,c)] <-> grid[b][(pd*P+i, ph*P+j, pw*P+k)][c]; C % 4 == 0
+// ---------------------------------------------------------------------------------------------
+__global__ void k_patchify(const float* __restrict__ src, float* __restrict__ dst, int B, int Dd, int Hh, int Ww, int P,
+                           int C, int to_tokens) {
+    const int cv = C / 4;
+    const int64_t total = (int64_t)B * Dd * Hh * Ww * cv;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cv);
+    int64_t t = i / cv;                 // grid-order node index within the batch of grids
+    const int w = (int)(t % Ww); t /= Ww;
+    const int h = (int)(t % Hh); t /= Hh;
+    const int d = (int)(t % Dd);
+    const int b = (int)(t / Dd);
+    const int nH = Hh / P, nW = Ww / P, nD = Dd / P;
+    const int64_t tok = ((int64_t)(d / P) * nH + (h / P)) * nW + (w / P);
+    const int64_t within = ((int64_t)(d % P) * P + (h % P)) * P + (w % P);
+    const int64_t gidx = (((int64_t)b * Dd + d) * Hh + h) * Ww + w;
+    const int64_t tidx = (((int64_t)b * nD * nH * nW + tok) * P * P * P + within);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    if (to_tokens) d4[tidx * cv + c] = s4[gidx * cv + c];
+    else d4[gidx * cv + c] = s4[tidx * cv + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MSE: partial sums in double, fixed-order final; backward reads the upstream scalar from memory
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mse_part(const float* __restrict__ p, const float* __restrict__ t, int64_t n, double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)p[i] - (double)t[i];
+        s += d * d;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_mse_final(const double* __restrict__ part, int nparts, double inv_n, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nparts; ++i) s += part[i];
+        *loss = (float)(s * inv_n);
+    }
+}
+__global__ void k_mse_bwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                          const float* __restrict__ gscalar, float coef, float* __restrict__ dp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dp[i] = (p[i] - t[i]) * coef * (*gscalar);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// multi-scale mix: out[n][c] = sum_s softmax(logits[n][:])_s * x_s[n][c]   (reference magno.py:590-594)
+// 32 lanes per row (C == 32), two rows per wave
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_SCALES = 8;
+struct ScalePtrs { const float* x[MAX_SCALES]; float* dx[MAX_SCALES]; };
+
+__global__ void k_scale_mix_fwd(ScalePtrs p, int ns, const float* __restrict__ logits, float* __restrict__ out,
+                                float* __restrict__ wsave, int64_t n) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int c = threadIdx.x & 31;
+    if (row >= n) return;
+    float mx = -INFINITY;
+    for (int s = 0; s < ns; ++s) mx = fmaxf(mx, logits[row * ns + s]);
+    float den = 0.f;
+    for (int s = 0; s < ns; ++s) den += expf(logits[row * ns + s] - mx);
+    float acc = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const float w = expf(logits[row * ns + s] - mx) / den;
+        if (c == 0) wsave[row * ns + s] = w;
+        acc += w * p.x[s][row * 32 + c];
+    }
+    out[row * 32 + c] = acc;
+}
+
+__global__ void k_scale_mix_bwd(ScalePtrs p, int ns, const float* __restrict__ w, const float* __restrict__ dout,
+                                float* __restrict__ dlogits, int64_t n) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int c = threadIdx.x & 31;
+    if (row >= n) return;
+    const float g = dout[row * 32 + c];
+    float gs[MAX_SCALES];
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAX_SCALES; ++s) {
+        gs[s] = 0.f;
+        if (s < ns) {
+            float v = g * p.x[s][row * 32 + c];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            gs[s] = v;
+            const float ws = w[row * ns + s];
+            tot += ws * v;
+            p.dx[s][row * 32 + c] = ws * g;
+        }
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int s = 0; s < MAX_SCALES; ++s)
+            if (s < ns) dlogits[row * ns + s] = w[row * ns + s] * (gs[s] - tot);
+    }
+}
+
+unsigned blocks_for(int64_t n, int tb = 256) { return (unsigned)std::max<int64_t>(1, ceil_div(n, tb)); }
+
+}  // namespace
+
+extern "C" int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, int64_t rows, int dim,
+                                float eps, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(x && weight && y, "null pointer");
+    hipLaunchKernelGGL(k_rmsnorm_fwd, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, weight, y,
+                       rstd, rows, dim, eps);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim) {
+    return sizeof(float) * (size_t)(ceil_div(rows, 4 * RN_ROWS_PER_WAVE) * dim) + 64;
+}
+
+extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, float* dx,
+                                float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
+                                gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 1024, "dim must be a multiple of 4, <= 1024");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_rmsnorm_bwd_workspace_bytes(rows, dim), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        if (dweight) hipMemsetAsync(dweight, 0, sizeof(float) * dim, st);
+        return GAOT_OK;
+    }
+    GAOT_CHECK_ARG(x && weight && dy && rstd && dx && dweight && workspace, "null pointer");
+    const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
+                       dx, part, rows, dim);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N) {
+    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 256)));
+    return sizeof(float) * (size_t)(chunks * N) + 64;
+}
+
+extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, float* out, void* workspace,
+                           size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(M >= 0 && N >= 0, "negative size");
+    if (N == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(out, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        hipMemsetAsync(out, 0, sizeof(float) * N, st);
+        return GAOT_OK;
+    }
+    GAOT_CHECK_ARG(x && workspace && workspace_bytes >= gaot_colsum_workspace_bytes(M, N), "workspace too small");
+    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 256)));
+    const int64_t rpc = ceil_div(M, chunks);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
+                       rpc, part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N)), dim3(256), 0, st, part, chunks, N, out);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head_dim, int seq_len,
+                         const float* freqs, int inverse, gaot_stream_t stream) {
+    GAOT_ENTER();
+    if (head_dim != 32) {
+        gaot_set_error("gaot_rope: head_dim %d unsupported (only 32)", head_dim);
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    GAOT_CHECK_ARG(rows >= 0 && nheads > 0 && seq_len > 0 && ld % 2 == 0 && col0 % 2 == 0, "bad shape");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(x && freqs, "null pointer");
+    const int64_t n = rows * nheads * 16;
+    hipLaunchKernelGGL(k_rope, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, rows, ld, col0, nheads, seq_len,
+                       freqs, inverse ? -1.f : 1.f);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(ag && u, "null pointer");
+    hipLaunchKernelGGL(k_swiglu_fwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, u, rows, F);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(ag && du && dag, "null pointer");
+    hipLaunchKernelGGL(k_swiglu_bwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, du, dag,
+                       rows, F);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && act >= 0 && act <= 3, "bad argument");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(z && dh && dz, "null pointer");
+    hipLaunchKernelGGL(k_act_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, act);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period,
+                         gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && period > 0, "bad argument");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(a && b && out, "null pointer");
+    hipLaunchKernelGGL(k_axpy, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n, period);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_patchify(const float* src, float* dst, int B, int Dd, int Hh, int Ww, int P, int C, int to_tokens,
+                             gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(B > 0 && Dd > 0 && Hh > 0 && Ww > 0 && P > 0 && C > 0, "bad shape");
+    GAOT_CHECK_ARG(Dd % P == 0 && Hh % P == 0 && Ww % P == 0, "Dimensions must be divisible by patch size");
+    GAOT_CHECK_ARG(C % 4 == 0, "channels must be a multiple of 4");
+    GAOT_CHECK_ARG(src && dst, "null pointer");
+    const int64_t total = (int64_t)B * Dd * Hh * Ww * (C / 4);
+    hipLaunchKernelGGL(k_patchify, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, Dd, Hh, Ww, P,
+                       C, to_tokens);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" size_t gaot_mse_workspace_bytes(void) { return sizeof(double) * 1024 + 64; }
+
+extern "C" int gaot_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, void* workspace,
+                            size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n > 0, "empty input");
+    GAOT_CHECK_ARG(pred && target && loss && workspace && workspace_bytes >= gaot_mse_workspace_bytes(), "bad argument");
+    const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));
+    double* part = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_mse_part, dim3(nb), dim3(256), 0, st, pred, target, n, part);
+    hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, st, part, nb, 1.0 / (double)n, loss);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_mse_bwd(const float* pred, const float* target, int64_t n, const float* grad_loss, float* dpred,
+                            gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n > 0, "empty input");
+    GAOT_CHECK_ARG(pred && target && grad_loss && dpred, "null pointer");
+    hipLaunchKernelGGL(k_mse_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, grad_loss,
+                       (float)(2.0 / (double)n), dpred);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+
+extern "C" int gaot_scale_mix_fwd(const float* const* xs, int num_scales, const float* logits, float* out,
+                                  float* weights, int64_t n, int channels, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_scales >= 1 && num_scales <= MAX_SCALES, "1..8 scales supported");
+    if (channels != 32) {
+        gaot_set_error("gaot_scale_mix_fwd: channels %d unsupported (only 32)", channels);
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(xs && logits && out && weights, "null pointer");
+    ScalePtrs p{};
+    for (int s = 0; s < num_scales; ++s) p.x[s] = xs[s];
+    hipLaunchKernelGGL(k_scale_mix_fwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales, logits,
+                       out, weights, n);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_scale_mix_bwd(const float* const* xs, int num_scales, const float* weights, const float* dout,
+                                  float* const* dxs, float* dlogits, int64_t n, int channels, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_scales >= 1 && num_scales <= MAX_SCALES, "1..8 scales supported");
+    if (channels != 32) {
+        gaot_set_error("gaot_scale_mix_bwd: channels %d unsupported (only 32)", channels);
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(xs && weights && dout && dxs && dlogits, "null pointer");
+    ScalePtrs p{};
+    for (int s = 0; s < num_scales; ++s) { p.x[s] = xs[s]; p.dx[s] = dxs[s]; }
+    hipLaunchKernelGGL(k_scale_mix_bwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales,
+                       weights, dout, dlogits, n);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

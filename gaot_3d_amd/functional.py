@@ -1,0 +1,324 @@
+"""autograd.Function wrappers: forward AND backward of every hot-path operator run hand-written HIP
+kernels through the C ABI (gaot_3d_amd.ops).  PyTorch only owns the device buffers and chains the
+Functions.  Nothing here falls back to ATen math or to the CPU."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import GaotError
+
+Tensor = torch.Tensor
+
+
+def _w2d(w: Tensor) -> Tensor:
+    """nn.Linear [out,in] or Conv1d(k=1) [out,in,1] storage -> contiguous [out,in] view."""
+    if w.dim() == 3:
+        w = w[:, :, 0]
+    return w if w.is_contiguous() else w.contiguous()
+
+
+class LinearFn(Function):
+    """y = act(x W^T + b).  Stands in for nn.Linear (+ F.gelu / ReLU) and its autograd."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int, precision: Optional[int]):
+        w = _w2d(weight)
+        n, k = w.shape
+        if x.shape[-1] != k:
+            raise GaotError(f"linear: input has {x.shape[-1]} features, weight expects {k}")
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        m = x2.shape[0]
+        if act:
+            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, act, want_preact=True, precision=precision)
+        else:
+            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, 0, precision=precision), None
+        ctx.save_for_backward(x2, w, z)
+        ctx.act, ctx.has_bias, ctx.precision = act, bias is not None, precision
+        ctx.wshape, ctx.xshape = weight.shape, x.shape
+        return y.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, w, z = ctx.saved_tensors
+        n, k = w.shape
+        m = x2.shape[0]
+        dy2 = dy.reshape(m, n)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dz = ops.act_bwd(z, dy2, ctx.act) if ctx.act else dy2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dz, w, m, k, n, n, k, False, False, precision=ctx.precision).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(dz, x2, n, k, m, n, k, True, False, precision=ctx.precision).view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dz, m, n, n)
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act: Optional[str] = None, precision: Optional[int] = None):
+    return LinearFn.apply(x, weight, bias, ops.ACT[act], precision)
+
+
+class GnoFn(Function):
+    """Fused IntegralTransform (transform_type='linear', mean reduction)."""
+
+    @staticmethod
+    def forward(ctx, f_y: Tensor, y_pos: Tensor, x_pos: Tensor, graph, *params):
+        nl = len(params) // 2
+        ws = [_w2d(p) for p in params[0::2]]
+        bs = list(params[1::2])
+        f = f_y if f_y.is_contiguous() else f_y.contiguous()
+        out = ops.gno_forward(ws, bs, y_pos, x_pos, f, graph)
+        ctx.graph = graph
+        ctx.nl = nl
+        ctx.wshapes = [p.shape for p in params[0::2]]
+        ctx.save_for_backward(f, y_pos, x_pos, *ws, *bs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        saved = ctx.saved_tensors
+        f, y_pos, x_pos = saved[:3]
+        ws = list(saved[3:3 + ctx.nl])
+        bs = list(saved[3 + ctx.nl:])
+        d = dout if dout.is_contiguous() else dout.contiguous()
+        gf, gw, gb = ops.gno_backward(ws, bs, y_pos, x_pos, f, d, ctx.graph)
+        grads: List[Optional[Tensor]] = []
+        for l in range(ctx.nl):
+            grads += [gw[l].view(ctx.wshapes[l]), gb[l]]
+        return (gf, None, None, None, *grads)
+
+
+class RMSNormFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, eps: float):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, rstd = ops.rmsnorm_fwd(xc, weight, eps)
+        ctx.save_for_backward(xc, weight, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, w, rstd = ctx.saved_tensors
+        d = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd)
+        return dx, dw, None
+
+
+class AttentionFn(Function):
+    """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k."""
+
+    @staticmethod
+    def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int):
+        if freqs is not None:
+            qkv = qkv.clone()
+            ld = qkv.shape[1]
+            ops.rope_(qkv, b * s, ld, 0, h + hkv, s, freqs, False)  # q heads then k heads are adjacent columns
+        scale = 1.0 / (32 ** 0.5)
+        o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale)
+        ctx.save_for_backward(qkv, o, lse, freqs if freqs is not None else torch.empty(0, device=qkv.device))
+        ctx.dims = (b, s, h, hkv, scale, freqs is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o: Tensor):
+        qkv, o, lse, freqs = ctx.saved_tensors
+        b, s, h, hkv, scale, rope = ctx.dims
+        d = d_o if d_o.is_contiguous() else d_o.contiguous()
+        dqkv = ops.attn_bwd(qkv, o, d, lse, b, s, h, hkv, scale)
+        if rope:
+            ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
+        return dqkv, None, None, None, None, None
+
+
+class SwiGLUFn(Function):
+    @staticmethod
+    def forward(ctx, ag: Tensor, f: int):
+        ctx.save_for_backward(ag)
+        ctx.f = f
+        return ops.swiglu_fwd(ag, f)
+
+    @staticmethod
+    def backward(ctx, du: Tensor):
+        (ag,) = ctx.saved_tensors
+        d = du if du.is_contiguous() else du.contiguous()
+        return ops.swiglu_bwd(ag, d, ctx.f), None
+
+
+class AddFn(Function):
+    """a + b (b optionally broadcast over leading rows with `period` elements)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, period: Optional[int]):
+        ac = a if a.is_contiguous() else a.contiguous()
+        bc = b if b.is_contiguous() else b.contiguous()
+        ctx.period = period
+        return ops.axpy(ac, bc, 1.0, period)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        if ctx.period is not None and ctx.needs_input_grad[1]:
+            raise GaotError("AddFn: gradient of a broadcast addend is not needed on the hot path")
+        return g, (g if ctx.period is None else None), None
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    return AddFn.apply(a, b, None)
+
+
+class PatchifyFn(Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, b, d, h, w, p, c, to_tokens: bool):
+        ctx.args = (b, d, h, w, p, c, to_tokens)
+        xc = x if x.is_contiguous() else x.contiguous()
+        return ops.patchify(xc, b, d, h, w, p, c, to_tokens)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        b, d, h, w, p, c, to_tokens = ctx.args
+        gc = g if g.is_contiguous() else g.contiguous()
+        return ops.patchify(gc, b, d, h, w, p, c, not to_tokens), None, None, None, None, None, None, None
+
+
+class MSELossFn(Function):
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Tensor):
+        p = pred if pred.is_contiguous() else pred.contiguous()
+        t = target if target.is_contiguous() else target.contiguous()
+        if p.shape != t.shape:
+            raise GaotError(f"mse_loss: shape mismatch {tuple(p.shape)} vs {tuple(t.shape)}")
+        ctx.save_for_backward(p, t)
+        return ops.mse_fwd(p, t)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        p, t = ctx.saved_tensors
+        gl = g if g.is_contiguous() else g.contiguous()
+        return ops.mse_bwd(p, t, gl), None
+
+
+def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """nn.MSELoss() stand-in (reference src/trainer/base.py:56, used at stat.py:550)."""
+    return MSELossFn.apply(pred, target)
+
+
+class MultiLinearFn(Function):
+    """[x W_0^T | x W_1^T | ...] written into the column blocks of ONE buffer (bias-free), so the
+    separate q/k/v (and w1/w3) parameters of the reference feed one fused downstream kernel."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, precision: Optional[int], *weights: Tensor):
+        ws = [_w2d(w) for w in weights]
+        k = ws[0].shape[1]
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        m = x2.shape[0]
+        ntot = sum(w.shape[0] for w in ws)
+        out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
+        col = 0
+        for w in ws:
+            n = w.shape[0]
+            ops.gemm(x2, w, m, n, k, k, k, False, True, out=out[:, col:], ldc=ntot, precision=precision)
+            col += n
+        ctx.save_for_backward(x2, *ws)
+        ctx.precision, ctx.xshape, ctx.wshapes = precision, x.shape, [w.shape for w in weights]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x2, *ws = ctx.saved_tensors
+        m, k = x2.shape
+        d = dout if dout.is_contiguous() else dout.contiguous()
+        ntot = d.shape[1]
+        dx = None
+        dws = []
+        col = 0
+        for i, w in enumerate(ws):
+            n = w.shape[0]
+            blk = d[:, col:]
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(blk, w, m, k, n, ntot, k, False, False, residual=dx, ldr=k, precision=ctx.precision)
+            dws.append(ops.gemm(blk, x2, n, k, m, ntot, k, True, False, precision=ctx.precision).view(ctx.wshapes[i])
+                       if ctx.needs_input_grad[2 + i] else None)
+            col += n
+        return (dx.view(ctx.xshape) if dx is not None else None, None, *dws)
+
+
+def multi_linear(x: Tensor, weights, precision: Optional[int] = None) -> Tensor:
+    return MultiLinearFn.apply(x, precision, *weights)
+
+
+class CatLinearFn(Function):
+    """y = [x_0 | x_1 | ...] W^T + b without materialising the concatenation (reference: torch.cat then
+    nn.Linear -- magno.py:494,571-575,771-775): one GEMM per input against the matching column block of
+    W, chained through the residual input; the weight gradient is written block by block."""
+
+    @staticmethod
+    def forward(ctx, weight: Tensor, bias: Optional[Tensor], precision: Optional[int], *xs: Tensor):
+        w = _w2d(weight)
+        n, k = w.shape
+        xs2 = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        if sum(x.shape[1] for x in xs2) != k:
+            raise GaotError(f"cat_linear: inputs have {sum(x.shape[1] for x in xs2)} features, weight expects {k}")
+        m = xs2[0].shape[0]
+        y = None
+        col = 0
+        for i, x in enumerate(xs2):
+            ki = x.shape[1]
+            y = ops.gemm(x, w[:, col:], m, n, ki, ki, k, False, True, bias if i == 0 else None, 0, residual=y, ldr=n,
+                         precision=precision)
+            col += ki
+        ctx.save_for_backward(w, *xs2)
+        ctx.meta = (precision, weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        w, *xs = ctx.saved_tensors
+        precision, wshape, has_bias = ctx.meta
+        n, k = w.shape
+        d = dy if dy.is_contiguous() else dy.contiguous()
+        m = d.shape[0]
+        dw = torch.empty(n, k, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[0] else None
+        dxs = []
+        col = 0
+        for i, x in enumerate(xs):
+            ki = x.shape[1]
+            dxs.append(ops.gemm(d, w[:, col:], m, ki, n, n, k, False, False, precision=precision)
+                       if ctx.needs_input_grad[3 + i] else None)
+            if dw is not None:
+                ops.gemm(d, x, n, ki, m, n, ki, True, False, out=dw[:, col:], ldc=k, precision=precision)
+            col += ki
+        db = ops.colsum(d, m, n, n) if (has_bias and ctx.needs_input_grad[1]) else None
+        return (dw.view(wshape) if dw is not None else None, db, None, *dxs)
+
+
+def cat_linear(xs, weight, bias=None, precision: Optional[int] = None) -> Tensor:
+    return CatLinearFn.apply(weight, bias, precision, *xs)
+
+
+class ScaleMixFn(Function):
+    """sum_s softmax(logits)_s * x_s   (reference magno.py:590-594)"""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, *xs: Tensor):
+        xc = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        lg = logits if logits.is_contiguous() else logits.contiguous()
+        out, w = ops.scale_mix_fwd(xc, lg)
+        ctx.save_for_backward(w, *xc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        w, *xs = ctx.saved_tensors
+        d = dout if dout.is_contiguous() else dout.contiguous()
+        dxs, dlog = ops.scale_mix_bwd(xs, w, d)
+        return (dlog, *dxs)

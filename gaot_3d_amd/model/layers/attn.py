@@ -1,0 +1,203 @@
+"""Latent U-ViT Transformer with the reference's class names, config dataclasses and state_dict layout
+(src/model/layers/attn.py: configs :15-44, GroupQueryFlashAttention :51-135, FFN :137-165, RMSNorm
+:167-178, TransformerBlock :180-244, Transformer :246-325), computing through the HIP kernels:
+RMSNorm row kernel, MFMA GEMMs (q|k|v and w1|w3 written into one fused buffer each), RoPE, flash
+attention fwd/bwd, SwiGLU.  Time-conditional norm (use_conditional_norm) is outside the hot path."""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import functional as GF
+from ...utils.dataclass import shallow_asdict
+
+
+@dataclass
+class AttentionConfig:
+    hidden_size: int = 256
+    num_heads: int = 8
+    num_kv_heads: int = 8
+    use_conditional_norm: bool = False
+    cond_norm_hidden_size: int = 4
+    atten_dropout: float = 0.1
+    positional_embedding: str = "absolute"
+    H: Optional[int] = None
+    W: Optional[int] = None
+
+
+@dataclass
+class FFNConfig:
+    hidden_size: int = 1024
+    use_conditional_norm: bool = False
+    cond_norm_hidden_size: int = 4
+
+
+@dataclass
+class TransformerConfig:
+    patch_size: int = 8
+    hidden_size: int = 256
+    use_attn_norm: bool = True
+    use_ffn_norm: bool = True
+    norm_eps: float = 1e-6
+    num_layers: int = 3
+    positional_embedding: str = "absolute"
+    use_long_range_skip: bool = True
+    attn_config: AttentionConfig = field(default_factory=AttentionConfig)
+    ffn_config: FFNConfig = field(default_factory=FFNConfig)
+
+
+class RotaryEmbedding(nn.Module):
+    """Parameter container matching ``rotary_embedding_torch.RotaryEmbedding(dim)`` as the reference uses it
+    (attn.py:86-87): a non-trainable parameter ``freqs`` = 1/theta^(arange(0,dim,2)/dim).  The rotation itself
+    (interleaved pairs, position = flattened token index) is fused into the attention Function (csrc/rowops.hip
+    k_rope).  rope: third-party, unpinned."""
+
+    def __init__(self, dim, theta=10000):
+        super().__init__()
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].float() / dim))
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+
+
+class GroupQueryFlashAttention(nn.Module):
+    def __init__(self, input_size: int, output_size: int, hidden_size: int = 128, num_heads: int = 8,
+                 num_kv_heads: int = 4, use_conditional_norm: bool = False, cond_norm_hidden_size: int = 4,
+                 atten_dropout: float = 0.0, H: int = 64, W: int = 64, positional_embedding: str = "absolute"):
+        super().__init__()
+        assert hidden_size % num_heads == 0, f"hidden_size {hidden_size} must be divisible by num_heads {num_heads}"
+        assert num_heads % num_kv_heads == 0, f"num_heads {num_heads} must be divisible by num_kv_heads {num_kv_heads}"
+        if use_conditional_norm:
+            raise NotImplementedError("use_conditional_norm is not implemented on the HIP path")
+        self.num_heads = num_heads
+        self.num_kv_heads = num_kv_heads
+        self.num_repeat = num_heads // num_kv_heads
+        self.head_dim = hidden_size // num_heads
+        if self.head_dim != 32:
+            raise NotImplementedError(f"head_dim {self.head_dim}: the HIP attention kernels are built for head_dim 32")
+        self.atten_dropout = atten_dropout
+        kv_hidden = self.head_dim * num_kv_heads
+        self.q_proj = nn.Linear(input_size, hidden_size, bias=False)
+        self.k_proj = nn.Linear(input_size, kv_hidden, bias=False)
+        self.v_proj = nn.Linear(input_size, kv_hidden, bias=False)
+        self.o_proj = nn.Linear(hidden_size, output_size, bias=False)
+        self.correction = None
+        if positional_embedding == "rope":
+            self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
+
+    def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
+        if self.training and self.atten_dropout > 0.0:
+            raise NotImplementedError("attention dropout > 0 in training mode is not implemented on the HIP path; "
+                                      "set atten_dropout=0.0 (reference default 0.1, attn.py:22) or call .eval()")
+        b, s, _ = x.shape
+        qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
+        freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
+        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads)
+        y = GF.linear(o, self.o_proj.weight, None)
+        return y.view(b, s, -1)
+
+    @classmethod
+    def from_config(cls, input_size: int, output_size: int, config: AttentionConfig):
+        return cls(input_size, output_size, **shallow_asdict(config))
+
+
+class FFN(nn.Module):
+    def __init__(self, input_size: int, output_size: int, hidden_size: int = 256, use_conditional_norm: bool = False,
+                 cond_norm_hidden_size: int = 4):
+        super().__init__()
+        if use_conditional_norm:
+            raise NotImplementedError("use_conditional_norm is not implemented on the HIP path")
+        self.w1 = nn.Linear(input_size, hidden_size, bias=False)
+        self.w2 = nn.Linear(hidden_size, output_size, bias=False)
+        self.w3 = nn.Linear(input_size, hidden_size, bias=False)
+        self.correction = None
+        self.hidden = hidden_size
+
+    def forward(self, x, condition: Optional[float] = None):
+        shp = x.shape
+        ag = GF.multi_linear(x, [self.w1.weight, self.w3.weight])   # [rows, 2F] = [w1 x | w3 x]
+        u = GF.SwiGLUFn.apply(ag, self.hidden)
+        return GF.linear(u, self.w2.weight, None).view(*shp[:-1], -1)
+
+    @classmethod
+    def from_config(cls, input_size: int, output_size: int, config: FFNConfig):
+        return cls(input_size, output_size, **shallow_asdict(config))
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return GF.RMSNormFn.apply(x, self.weight, self.eps)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, input_size: int, output_size: int, use_attn_norm: bool = True, use_ffn_norm: bool = True,
+                 norm_eps: float = 1e-6, attn_config: AttentionConfig = None, ffn_config: FFNConfig = None,
+                 skip_connection: bool = False):
+        super().__init__()
+        attn_config = attn_config if attn_config is not None else AttentionConfig()
+        ffn_config = ffn_config if ffn_config is not None else FFNConfig()
+        self.attn = GroupQueryFlashAttention.from_config(input_size, attn_config.hidden_size, config=attn_config)
+        self.ffn = FFN.from_config(attn_config.hidden_size, output_size, config=ffn_config)
+        self.attn_norm = RMSNorm(input_size, eps=norm_eps) if use_attn_norm else None
+        self.ffn_norm = RMSNorm(attn_config.hidden_size, eps=norm_eps) if use_ffn_norm else None
+        self.skip_connection = skip_connection
+        if self.skip_connection:
+            self.skip_proj = nn.Linear(input_size + output_size, input_size)
+
+    def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
+                skip: Optional[torch.Tensor] = None):
+        if self.skip_connection and skip is not None:
+            b, s, d = x.shape
+            x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
+                              self.skip_proj.bias).view(b, s, -1)
+        h = x if self.attn_norm is None else self.attn_norm(x)
+        h = GF.add(x, self.attn(h, condition=condition, relative_positions=relative_positions))
+        h = h if self.ffn_norm is None else self.ffn_norm(h)
+        # NB: the second residual adds the *normalised* h (reference attn.py:226-229)
+        return GF.add(h, self.ffn(h, condition=condition))
+
+    @classmethod
+    def from_config(cls, input_size: int, output_size: int, skip_connection: bool = False,
+                    config: TransformerConfig = None):
+        config = config if config is not None else TransformerConfig()
+        config.attn_config.positional_embedding = config.positional_embedding
+        kwargs = shallow_asdict(config)
+        for k in ("num_layers", "hidden_size", "positional_embedding", "use_long_range_skip", "patch_size"):
+            kwargs.pop(k)
+        return cls(input_size, output_size, skip_connection=skip_connection, **kwargs)
+
+
+class Transformer(nn.Module):
+    def __init__(self, input_size: int, output_size: int, config: TransformerConfig = None):
+        super().__init__()
+        config = config if config is not None else TransformerConfig()
+        hidden = config.hidden_size
+        n = config.num_layers
+        self.use_long_range_skip = config.use_long_range_skip
+        self.input_proj = nn.Linear(input_size, hidden) if input_size != hidden else nn.Identity()
+        self.output_proj = nn.Linear(hidden, output_size) if hidden != output_size else nn.Identity()
+        self.encoder_layers = nn.ModuleList([TransformerBlock.from_config(hidden, hidden, False, config)
+                                             for _ in range(n // 2)])
+        self.middle_layer = TransformerBlock.from_config(hidden, hidden, False, config) if n % 2 == 1 else None
+        self.decoder_layers = nn.ModuleList([TransformerBlock.from_config(hidden, hidden, True, config)
+                                             for _ in range(n // 2)])
+
+    def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
+        if isinstance(self.input_proj, nn.Linear):
+            x = GF.linear(x, self.input_proj.weight, self.input_proj.bias)
+        skips = []
+        for layer in self.encoder_layers:
+            x = layer(x, condition=condition, relative_positions=relative_positions)
+            skips.append(x)
+        if self.middle_layer is not None:
+            x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
+        for layer in self.decoder_layers:
+            skip = skips.pop() if self.use_long_range_skip else None
+            x = layer(x, condition=condition, relative_positions=relative_positions, skip=skip)
+        if isinstance(self.output_proj, nn.Linear):
+            x = GF.linear(x, self.output_proj.weight, self.output_proj.bias)
+        return x

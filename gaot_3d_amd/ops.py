@@ -151,3 +151,205 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
                            _ptr(g.by_src.key), _ptr(g.by_src.other), _ptr(g.by_src.rowptr), e, g.num_src, g.num_dst,
                            _ptr(grad_f), C.byref(gs), _ptr(ws), ws.numel(), _stream()), "gaot_gno_bwd")
     return grad_f, gw, gb
+
+
+# ------------------------------------------------------------------------------------------------
+# precision switch: "fp32" = exact-fp32 MFMA everywhere (parity mode); "bf16" = bf16 operands with
+# fp32 accumulation for the dense GEMMs / attention (BASELINE config 1)
+# ------------------------------------------------------------------------------------------------
+_PRECISION = {"mode": 0}
+
+
+def set_precision(mode: str):
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {mode}")
+    _PRECISION["mode"] = 0 if mode == "fp32" else 1
+
+
+def get_precision() -> str:
+    return "bf16" if _PRECISION["mode"] else "fp32"
+
+
+ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3}
+
+
+def gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_trans: bool, b_trans: bool,
+         bias: Optional[Tensor] = None, act: int = 0, residual: Optional[Tensor] = None, ldr: int = 0,
+         want_preact: bool = False, out: Optional[Tensor] = None, ldc: Optional[int] = None,
+         precision: Optional[int] = None):
+    """Raw GEMM on 2-D row-major fp32 buffers (see include/gaot3d_hip.h: gaot_gemm)."""
+    lib = _lib.load()
+    dev = a.device
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=dev)
+        ldc = n
+    pre = torch.empty(m, n, dtype=torch.float32, device=dev) if want_preact else None
+    if want_preact and ldc != n:
+        raise GaotError("preact output requires a dense output")
+    nb = lib.gaot_gemm_workspace_bytes(m, n, k)
+    ws = _ws(nb, dev) if nb else None
+    prec = _PRECISION["mode"] if precision is None else precision
+    check(lib.gaot_gemm(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, ldc, int(a_trans), int(b_trans), _ptr(bias),
+                        act, _ptr(residual), ldr, _ptr(pre), prec, _ptr(ws), ws.numel() if ws is not None else 0,
+                        _stream()), "gaot_gemm")
+    return (out, pre) if want_preact else out
+
+
+def colsum(x: Tensor, m: int, n: int, ld: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.gaot_colsum_workspace_bytes(m, n), x.device)
+    check(lib.gaot_colsum(_ptr(x), m, n, ld, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_colsum")
+    return out
+
+
+def act_bwd(z: Tensor, dh: Tensor, act: int) -> Tensor:
+    lib = _lib.load()
+    dz = torch.empty_like(z)
+    check(lib.gaot_act_bwd(_ptr(z), _ptr(dh), _ptr(dz), z.numel(), act, _stream()), "gaot_act_bwd")
+    return dz
+
+
+def axpy(a: Tensor, b: Tensor, alpha: float = 1.0, period: Optional[int] = None) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    check(lib.gaot_axpy(_ptr(a), _ptr(b), float(alpha), _ptr(out), a.numel(), period or a.numel(), _stream()),
+          "gaot_axpy")
+    return out
+
+
+def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float):
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.gaot_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), rows, d, float(eps), _stream()),
+          "gaot_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor):
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = _ws(lib.gaot_rmsnorm_bwd_workspace_bytes(rows, d), x.device)
+    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx), _ptr(dw), rows, d, _ptr(ws),
+                               ws.numel(), _stream()), "gaot_rmsnorm_bwd")
+    return dx, dw
+
+
+def rope_(buf: Tensor, rows: int, ld: int, col0: int, nheads: int, seq_len: int, freqs: Tensor, inverse: bool):
+    lib = _lib.load()
+    check(lib.gaot_rope(_ptr(buf), rows, ld, col0, nheads, 32, seq_len, _ptr(freqs), int(inverse), _stream()),
+          "gaot_rope")
+
+
+def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float):
+    """qkv: [B*S, (h + 2*hkv)*32] fused projection output (q | k | v column blocks)."""
+    lib = _lib.load()
+    ld = qkv.shape[1]
+    dev = qkv.device
+    o = torch.empty(b * s, h * 32, dtype=torch.float32, device=dev)
+    lse = torch.empty(b, h, s, dtype=torch.float32, device=dev)
+    base = qkv.data_ptr()
+    q, k, v = C.c_void_p(base), C.c_void_p(base + 4 * h * 32), C.c_void_p(base + 4 * (h + hkv) * 32)
+    check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale),
+                            _PRECISION["mode"], _stream()), "gaot_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float) -> Tensor:
+    lib = _lib.load()
+    ld = qkv.shape[1]
+    dev = qkv.device
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
+    base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+    offk, offv = 4 * h * 32, 4 * (h + hkv) * 32
+    check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o), _ptr(d_o),
+                            _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
+                            C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
+                            float(scale), _PRECISION["mode"], _stream()), "gaot_attn_bwd")
+    return dqkv
+
+
+def swiglu_fwd(ag: Tensor, f: int) -> Tensor:
+    lib = _lib.load()
+    rows = ag.shape[0]
+    u = torch.empty(rows, f, dtype=torch.float32, device=ag.device)
+    check(lib.gaot_swiglu_fwd(_ptr(ag), _ptr(u), rows, f, _stream()), "gaot_swiglu_fwd")
+    return u
+
+
+def swiglu_bwd(ag: Tensor, du: Tensor, f: int) -> Tensor:
+    lib = _lib.load()
+    dag = torch.empty_like(ag)
+    check(lib.gaot_swiglu_bwd(_ptr(ag), _ptr(du), _ptr(dag), ag.shape[0], f, _stream()), "gaot_swiglu_bwd")
+    return dag
+
+
+def patchify(src: Tensor, b: int, d: int, h: int, w: int, p: int, c: int, to_tokens: bool) -> Tensor:
+    lib = _lib.load()
+    dst = torch.empty_like(src)
+    check(lib.gaot_patchify(_ptr(src), _ptr(dst), b, d, h, w, p, c, int(to_tokens), _stream()), "gaot_patchify")
+    return dst
+
+
+def mse_fwd(pred: Tensor, target: Tensor) -> Tensor:
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    ws = _ws(lib.gaot_mse_workspace_bytes(), pred.device)
+    check(lib.gaot_mse_fwd(_ptr(pred), _ptr(target), pred.numel(), _ptr(loss), _ptr(ws), ws.numel(), _stream()),
+          "gaot_mse_fwd")
+    return loss
+
+
+def mse_bwd(pred: Tensor, target: Tensor, grad_loss: Tensor) -> Tensor:
+    lib = _lib.load()
+    dp = torch.empty_like(pred)
+    check(lib.gaot_mse_bwd(_ptr(pred), _ptr(target), pred.numel(), _ptr(grad_loss), _ptr(dp), _stream()), "gaot_mse_bwd")
+    return dp
+
+
+def geoembed_stats(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> Tensor:
+    lib = _lib.load()
+    source_pos = _req(source_pos, torch.float32, "source_pos")
+    query_pos = _req(query_pos, torch.float32, "query_pos")
+    if source_pos.shape[1] != 3:
+        raise GaotError("geoembed statistical features: coord_dim must be 3 on the HIP path")
+    q = g.num_dst
+    feat = torch.empty(q, 9, dtype=torch.float32, device=query_pos.device)
+    ws = _ws(lib.gaot_geoembed_stats_workspace_bytes(), query_pos.device)
+    check(lib.gaot_geoembed_stats(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), q,
+                                  _ptr(feat), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_stats")
+    return feat
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def scale_mix_fwd(xs, logits: Tensor):
+    lib = _lib.load()
+    n, c = xs[0].shape
+    out = torch.empty_like(xs[0])
+    w = torch.empty(n, len(xs), dtype=torch.float32, device=out.device)
+    check(lib.gaot_scale_mix_fwd(_ptr_array(xs), len(xs), _ptr(logits), _ptr(out), _ptr(w), n, c, _stream()),
+          "gaot_scale_mix_fwd")
+    return out, w
+
+
+def scale_mix_bwd(xs, w: Tensor, dout: Tensor):
+    lib = _lib.load()
+    n, c = xs[0].shape
+    dxs = [torch.empty_like(x) for x in xs]
+    dlog = torch.empty_like(w)
+    check(lib.gaot_scale_mix_bwd(_ptr_array(xs), len(xs), _ptr(w), _ptr(dout), _ptr_array(dxs), _ptr(dlog), n, c,
+                                 _stream()), "gaot_scale_mix_bwd")
+    return dxs, dlog

@@ -86,6 +86,89 @@ int gaot_gno_bwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const flo
                  float* grad_f_y /* [num_sources, channels] */, const gaot_mlp_grad_t* grads /* host */,
                  void* workspace, size_t workspace_bytes, gaot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Statistical geometric-embedding features (reference GeometricEmbedding.
+ * _compute_statistical_features_pyg, src/model/layers/geoembed.py:99-182): z-scored
+ * [N_i, D_avg, D_var, centroid-query (3), covariance eigenvalues desc (3)] per query row, from the
+ * by-query neighbour list.  features: [num_queries, 9].
+ * ------------------------------------------------------------------------------------------- */
+size_t gaot_geoembed_stats_workspace_bytes(void);
+int gaot_geoembed_stats(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
+                        const int32_t* src_sorted, int64_t num_queries, float* features, void* workspace,
+                        size_t workspace_bytes, gaot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense GEMM  C[m][n] = act(sum_k A(m,k) B(k,n) + bias[n]) + residual[m][n]   (row-major, fp32 I/O)
+ * stands in for ATen addmm/mm behind nn.Linear and its autograd (reference mlp.py:327-335,
+ * attn.py:104-106,129,156; gaot_3d.py:205).  a_trans: A(m,k) = A[k*lda+m]; b_trans: B(k,n) =
+ * B[n*ldb+k] (nn.Linear weight layout).  act: 0 none, 1 GELU(erf), 2 ReLU, 3 SiLU.  preact
+ * (optional, ldc) receives the value before the activation.  precision 0 = fp32 MFMA (exact fp32
+ * products), 1 = bf16 operands / fp32 accumulate.  Long reductions with few output tiles (weight
+ * gradients) are split over K with a fixed-order second pass (workspace).
+ * ------------------------------------------------------------------------------------------- */
+size_t gaot_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+              int64_t ldc, int a_trans, int b_trans, const float* bias, int act, const float* residual, int64_t ldr,
+              float* preact, int precision, void* workspace, size_t workspace_bytes, gaot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention: softmax(Q K^T * scale) V per head, no mask, no dropout (reference
+ * GroupQueryFlashAttention.forward, src/model/layers/attn.py:110-127 -> F.scaled_dot_product_
+ * attention) and its autograd.  q/k/v/o are [B*S, heads*32] views with row strides ld* (floats),
+ * so the fused QKV projection output can be addressed in place.  lse/delta: [B, H, S] scratch
+ * kept from forward / filled by backward.  head_dim must be 32.  HKV < H = grouped-query heads
+ * (k = k.repeat_interleave(H/HKV)).
+ * ------------------------------------------------------------------------------------------- */
+int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq, int64_t ldk,
+                  int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim, float scale, int precision,
+                  gaot_stream_t stream);
+int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                  float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
+                  float scale, int precision, gaot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row / element kernels (HBM-bound).
+ *   rmsnorm : y = x * rsqrt(mean(x^2) + eps) * w         (attn.py:174-178); rstd[rows] kept for bwd
+ *   rope    : in-place 1-D rotary embedding over the flattened token index (attn.py:118-120;
+ *             rotary_embedding_torch: interleaved pairs, angle = (row % seq_len) * freqs[i]);
+ *             inverse=1 applies the transpose rotation (backward)
+ *   swiglu  : u = silu(a) * g on a fused [rows][2F] buffer (attn.py:156) and its backward
+ *   act_bwd : dz = dh * act'(z)      axpy : out = a + alpha * b[i % period]
+ *   patchify: [B,D,H,W,C] <-> [B,S,P^3 C] token layout (gaot_3d.py:199-202, 218-220)
+ *   mse     : nn.MSELoss mean reduction (src/trainer/base.py:56) and d(loss)/d(pred) * (*grad_loss)
+ *   colsum  : out[n] = sum_m x[m][n]  (bias gradients)
+ * ------------------------------------------------------------------------------------------- */
+int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, int64_t rows, int dim, float eps,
+                     gaot_stream_t stream);
+size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim);
+int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, float* dx, float* dweight,
+                     int64_t rows, int dim, void* workspace, size_t workspace_bytes, gaot_stream_t stream);
+size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N);
+int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, float* out, void* workspace, size_t workspace_bytes,
+                gaot_stream_t stream);
+int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head_dim, int seq_len, const float* freqs,
+              int inverse, gaot_stream_t stream);
+int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, gaot_stream_t stream);
+int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int64_t rows, int F, gaot_stream_t stream);
+int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream);
+int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period, gaot_stream_t stream);
+int gaot_patchify(const float* src, float* dst, int B, int D, int H, int W, int P, int C, int to_tokens,
+                  gaot_stream_t stream);
+size_t gaot_mse_workspace_bytes(void);
+int gaot_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, void* workspace, size_t workspace_bytes,
+                 gaot_stream_t stream);
+int gaot_mse_bwd(const float* pred, const float* target, int64_t n, const float* grad_loss, float* dpred,
+                 gaot_stream_t stream);
+
+/* Multi-scale mix (reference magno.py:590-594 / 784-788): out = sum_s softmax(logits)_s * x_s with per-node
+ * logits [n, num_scales]; xs / dxs are HOST arrays of device pointers ([n, 32] each); weights [n, num_scales]
+ * keeps the softmax for the backward. */
+int gaot_scale_mix_fwd(const float* const* xs, int num_scales, const float* logits, float* out, float* weights,
+                       int64_t n, int channels, gaot_stream_t stream);
+int gaot_scale_mix_bwd(const float* const* xs, int num_scales, const float* weights, const float* dout,
+                       float* const* dxs, float* dlogits, int64_t n, int channels, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,133 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/*.h declares (no compute),
+the drop-in model has the reference's state_dict layout, the host-side data helpers follow the reference's
+conventions, and the product refuses to run without the GPU path."""
+import glob
+import os
+import re
+import types
+
+import pytest
+import torch
+
+import golden_io as gio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gaot_3d_amd import _lib
+    lib = _lib.load()
+    declared = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        declared |= set(re.findall(r"\b(gaot_\w+)\s*\(", src))
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported by libgaot3d_hip.so"
+    assert declared == set(_lib.SIGNATURES.keys()), declared ^ set(_lib.SIGNATURES.keys())
+    assert lib.gaot_abi_version() == 1
+
+
+@pytest.mark.parametrize("case", ["model_knn_abs", "model_radius_rope", "model_channel_multiscale"])
+def test_state_dict_layout_matches_reference(case):
+    from test_model_gpu import product_config
+    from gaot_3d_amd.model import init_model
+    meta, g = gio.load(case)
+    model = init_model(meta["in_size"], meta["out_size"], "gaot_3d", product_config(meta))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g["sd"].keys())           # same names in the same registration order
+    for k, v in g["sd"].items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    model.load_state_dict(g["sd"], strict=True)
+    assert sum(p.numel() for p in model.parameters()) == meta["nparams"]
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    assert not any(k.endswith("rotary_emb.freqs") for k in trainable)
+
+
+def test_yaml_config_parameter_count():
+    """model section of the reference's pressure.yaml: 11 244 737 parameters"""
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from gaot_3d_amd.model.layers.magno import MAGNOConfig
+    cfg = types.SimpleNamespace(
+        magno=MAGNOConfig(gno_coord_dim=3, lifting_channels=32, mlp_type="linear", use_geoembed=[True, False],
+                          encoder_feature_attr=["pos", "c"], neighbor_strategy="bidirectional"),
+        transformer=TransformerConfig(patch_size=2, positional_embedding="rope", num_layers=10,
+                                      attn_config=AttentionConfig(), ffn_config=FFNConfig()),
+        latent_tokens=(64, 64, 32))
+    with torch.device("meta"):
+        m = init_model(6, 1, "gaot_3d", cfg)
+    assert sum(p.numel() for p in m.parameters()) == 11244737
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 11244577
+
+
+def test_init_model_rejects_unknown():
+    from gaot_3d_amd.model import init_model
+    with pytest.raises(ValueError):
+        init_model(3, 1, "gino", types.SimpleNamespace())
+
+
+def test_unsupported_variants_raise():
+    from gaot_3d_amd.model.layers.geoembed import GeometricEmbedding
+    from gaot_3d_amd.model.layers.integral_transform import IntegralTransform
+    it = IntegralTransform(channel_mlp_layers=[38, 64, 32], transform_type="nonlinear")
+    with pytest.raises(NotImplementedError):
+        it(torch.zeros(4, 3), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long), torch.zeros(4, 32))
+    with pytest.raises(NotImplementedError):
+        GeometricEmbedding(3, 32, method="pointnet")(torch.zeros(4, 3), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long))
+    with pytest.raises(ValueError):
+        GeometricEmbedding(3, 32, method="nope")
+
+
+def test_no_cpu_fallback():
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd._lib import GaotError
+    with pytest.raises((GaotError, RuntimeError)):
+        GF.linear(torch.zeros(4, 8), torch.zeros(3, 8), None, precision=0)
+
+
+def test_batching_increments_and_graph_helpers():
+    from gaot_3d_amd.data import (MeshBatch, coalesce_edges, knn_edges_bruteforce, knn_edges_grid, latent_grid,
+                                  radius_edges_bruteforce)
+    g = torch.Generator().manual_seed(0)
+    lat = latent_grid((6, 5, 4))
+    assert torch.allclose(lat[1], torch.tensor([-1.0, -1.0, -1.0 + 2 / 3]))   # w fastest, "ij" indexing
+    pos = torch.rand(500, 3, generator=g) * 2 - 1
+    bf = knn_edges_bruteforce(pos, lat, 8)
+    gr = knn_edges_grid(pos, (6, 5, 4), (-1.0,) * 3, (1.0,) * 3, 8)
+    assert torch.equal(bf[0], gr[0])
+    assert torch.equal(bf[1].view(-1, 8).sort(1).values, gr[1].view(-1, 8).sort(1).values)
+    # radius: centres = latent, cap 32, rows [phys, latent] sorted by latent
+    rad = radius_edges_bruteforce(pos, lat, 0.6, 32, "latent")
+    assert (rad[1][1:] >= rad[1][:-1]).all() and torch.bincount(rad[1]).max() <= 32
+    assert ((pos[rad[0]] - lat[rad[1]]).norm(dim=1) <= 0.6 + 1e-6).all()
+    co = coalesce_edges(torch.cat([bf, bf], 1), lat.shape[0])
+    assert co.shape[1] == bf.shape[1]
+    # batching offsets follow EnrichedData.__inc__ (reference pyg_datasets.py:18-26)
+    s1 = MeshBatch(pos=pos[:10], x=pos[:10, :1], encoder_edge_index_s0=torch.tensor([[0, 9], [1, 2]]),
+                   decoder_edge_index_s0=torch.tensor([[1, 2], [0, 9]]))
+    s2 = MeshBatch(pos=pos[:7], x=pos[:7, :1], encoder_edge_index_s0=torch.tensor([[3], [5]]),
+                   decoder_edge_index_s0=torch.tensor([[5], [3]]))
+    b = MeshBatch.from_data_list([s1, s2], num_latent_nodes=120)
+    assert b.num_graphs == 2 and b.pos.shape[0] == 17
+    assert torch.equal(b.encoder_edge_index_s0, torch.tensor([[0, 9, 13], [1, 2, 125]]))
+    assert torch.equal(b.decoder_edge_index_s0, torch.tensor([[1, 2, 125], [0, 9, 13]]))
+    assert torch.equal(b.batch, torch.tensor([0] * 10 + [1] * 7))
+
+
+def test_get_neighbor_strategy_conventions():
+    from gaot_3d_amd.data import latent_grid
+    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy
+    g = torch.Generator().manual_seed(1)
+    lat = latent_grid((3, 3, 3))
+    pos = torch.rand(40, 3, generator=g) * 2 - 1
+    bp, bl = torch.zeros(40, dtype=torch.long), torch.zeros(27, dtype=torch.long)
+    enc = get_neighbor_strategy("knn", pos, bp, lat, bl, 0.5, 2, False)
+    dec = get_neighbor_strategy("knn", pos, bp, lat, bl, 0.5, 2, True)
+    assert enc.shape == (2, 80) and enc[0].max() < 40 and enc[1].max() < 27     # [phys, latent]
+    assert torch.equal(dec, enc.flip(0))                                          # [latent, phys]
+    bi = get_neighbor_strategy("bidirectional", pos, bp, lat, bl, 0.9, 2, False)
+    rev = get_neighbor_strategy("reverse", pos, bp, lat, bl, 0.9, 2, True)
+    assert torch.equal(rev, bi.flip(0))        # 'reverse' = flip of the *bidirectional* encoder graph
+    with pytest.raises(ValueError):
+        get_neighbor_strategy("nope", pos, bp, lat, bl, 0.5, 1, False)

@@ -1,0 +1,236 @@
+"""GPU parity of the dense / row kernels through the C ABI, each against a plain fp32 (or fp64) torch
+CPU restatement of the same reference op.  Tolerances per SURVEY §8d (fp32: rtol 1e-4 / atol 1e-5 on
+outputs, 1e-3 on gradients; bf16 operands: rtol 2e-2)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import gaot_oracle as orc  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(name, a, b, rtol, atol):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ref = b.abs().max().item() if b.numel() else 0.0
+    print(f"[parity] {name}: max_abs={err:.3e} ref_peak={ref:.3e}")
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{name}: max abs err {err:.3e}"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (37, 5, 9), (300, 32, 6), (257, 64, 64), (1000, 256, 32), (513, 130, 70),
+                                   (128, 768, 256)])
+@pytest.mark.parametrize("a_trans,b_trans", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_fp32(m, n, k, a_trans, b_trans):
+    from gaot_3d_amd import ops
+    a = gen(k, m, seed=1) if a_trans else gen(m, k, seed=1)
+    b = gen(n, k, seed=2) if b_trans else gen(k, n, seed=2)
+    ref = (a.t() if a_trans else a).double() @ (b.t() if b_trans else b).double()
+    out = ops.gemm(a.to(DEV), b.to(DEV), m, n, k, a.shape[1], b.shape[1], bool(a_trans), bool(b_trans), precision=0)
+    close(f"gemm{m}x{n}x{k}_{a_trans}{b_trans}", out, ref, 1e-4, 1e-4 * max(1.0, math.sqrt(k)))
+
+
+def test_gemm_epilogues_and_splitk():
+    from gaot_3d_amd import ops
+    m, n, k = 700, 48, 33
+    x, w, b, r = gen(m, k, seed=3), gen(n, k, seed=4), gen(n, seed=5), gen(m, n, seed=6)
+    for act, fn in (("gelu", F.gelu), ("relu", F.relu), ("silu", F.silu), (None, lambda t: t)):
+        z = F.linear(x, w, b)
+        ref = fn(z) + r
+        out, pre = ops.gemm(x.to(DEV), w.to(DEV), m, n, k, k, k, False, True, b.to(DEV), ops.ACT[act], r.to(DEV), n,
+                            want_preact=True, precision=0)
+        close(f"epi_{act}", out, ref, 1e-4, 1e-5)
+        close(f"epi_{act}_pre", pre, z, 1e-4, 1e-5)
+    # weight-gradient shape: long reduction, few output tiles -> split-K path, written into a column block
+    rows = 50000
+    dy, xx = gen(rows, 40, seed=7), gen(rows, 24, seed=8)
+    ref = dy.double().t() @ xx.double()
+    big = torch.zeros(40, 64, device=DEV)
+    ops.gemm(dy.to(DEV), xx.to(DEV), 40, 24, rows, 40, 24, True, False, out=big[:, 16:], ldc=64, precision=0)
+    close("splitk_block", big[:, 16:40], ref, 1e-4, 2e-3)
+    assert big[:, :16].abs().max().item() == 0 and big[:, 40:].abs().max().item() == 0
+
+
+def test_gemm_bf16_operands():
+    from gaot_3d_amd import ops
+    m, n, k = 512, 256, 256
+    a, b = gen(m, k, seed=1), gen(n, k, seed=2)
+    ref = a.bfloat16().double() @ b.bfloat16().double().t()
+    out = ops.gemm(a.to(DEV), b.to(DEV), m, n, k, k, k, False, True, precision=1)
+    close("gemm_bf16_vs_bf16_rounded_operands", out, ref, 1e-4, 1e-3)   # exact products of rounded operands
+    close("gemm_bf16_vs_fp32", out, a.double() @ b.double().t(), 2e-2, 0.5)
+
+
+def _attn_ref(qkv, b, s, h, hkv, freqs):
+    q, k, v = qkv.split([h * 32, hkv * 32, hkv * 32], dim=1)
+    q = q.view(b, s, h, 32).transpose(1, 2)
+    k = k.view(b, s, hkv, 32).transpose(1, 2)
+    v = v.view(b, s, hkv, 32).transpose(1, 2)
+    if hkv != h:
+        k = k.repeat_interleave(h // hkv, dim=1)
+        v = v.repeat_interleave(h // hkv, dim=1)
+    if freqs is not None:
+        q, k = orc.rope_rotate(q, freqs), orc.rope_rotate(k, freqs)
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32), dim=-1)
+    return (att @ v).transpose(1, 2).reshape(b * s, h * 32)
+
+
+@pytest.mark.parametrize("b,s,h,hkv,rope", [(1, 64, 2, 2, False), (2, 100, 2, 1, True), (1, 333, 8, 8, True),
+                                            (1, 1, 1, 1, False), (1, 130, 4, 2, False)])
+def test_attention_fwd_bwd(b, s, h, hkv, rope):
+    from gaot_3d_amd import functional as GF
+    qkv = gen(b * s, (h + 2 * hkv) * 32, seed=s)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)) if rope else None
+    w = gen(b * s, h * 32, seed=s + 1)
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = _attn_ref(qr, b, s, h, hkv, freqs.double() if rope else None)
+    (ref * w.double()).sum().backward()
+    qd = qkv.to(DEV).requires_grad_(True)
+    out = GF.AttentionFn.apply(qd, freqs.to(DEV) if rope else None, b, s, h, hkv)
+    (out * w.to(DEV)).sum().backward()
+    close(f"attn_out_{s}", out, ref, 1e-4, 1e-5)
+    close(f"attn_dqkv_{s}", qd.grad, qr.grad, 1e-3, 2e-5)
+
+
+def test_attention_spike_rows():
+    """online-softmax rescale path: one key dominates late in the sequence"""
+    from gaot_3d_amd import functional as GF
+    b, s, h = 1, 200, 1
+    qkv = gen(b * s, 96, seed=11)
+    qkv[150, 32:64] = qkv[7, 0:32] * 6.0   # key 150 aligned with query 7 -> its max jumps in a late tile
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = _attn_ref(qr, b, s, h, h, None)
+    ref.sum().backward()
+    qd = qkv.to(DEV).requires_grad_(True)
+    out = GF.AttentionFn.apply(qd, None, b, s, h, h)
+    out.sum().backward()
+    close("attn_spike_out", out, ref, 1e-4, 1e-5)
+    close("attn_spike_grad", qd.grad, qr.grad, 1e-3, 2e-5)
+
+
+def test_rmsnorm_swiglu_rope_patchify_mse():
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd import ops
+    # rmsnorm
+    x, w, g = gen(300, 256, seed=1), gen(256, seed=2) * 0.1 + 1, gen(300, 256, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (orc.rmsnorm(xr, wr, 1e-6) * g).sum().backward()
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = GF.RMSNormFn.apply(xd, wd, 1e-6)
+    (y * g.to(DEV)).sum().backward()
+    close("rmsnorm_y", y, orc.rmsnorm(x, w, 1e-6), 1e-5, 1e-6)
+    close("rmsnorm_dx", xd.grad, xr.grad, 1e-4, 1e-5)
+    close("rmsnorm_dw", wd.grad, wr.grad, 1e-4, 1e-4)
+    # swiglu
+    ag, du = gen(77, 2 * 128, seed=4), gen(77, 128, seed=5)
+    ar = ag.clone().requires_grad_(True)
+    ur = F.silu(ar[:, :128]) * ar[:, 128:]
+    (ur * du).sum().backward()
+    ad = ag.to(DEV).requires_grad_(True)
+    u = GF.SwiGLUFn.apply(ad, 128)
+    (u * du.to(DEV)).sum().backward()
+    close("swiglu_u", u, ur, 1e-5, 1e-6)
+    close("swiglu_dag", ad.grad, ar.grad, 1e-4, 1e-6)
+    # rope (restatement of rotary_embedding_torch; third-party, unpinned) + inverse
+    s, nh = 50, 3
+    t = gen(2 * s, nh * 32 + 32, seed=6)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ref = t.clone()
+    ref[:, :nh * 32] = orc.rope_rotate(t[:, :nh * 32].view(2, s, nh, 32).transpose(1, 2), freqs).transpose(1, 2).reshape(2 * s, nh * 32)
+    td = t.to(DEV).clone()
+    ops.rope_(td, 2 * s, t.shape[1], 0, nh, s, freqs.to(DEV), False)
+    close("rope_fwd", td, ref, 1e-5, 1e-5)
+    ops.rope_(td, 2 * s, t.shape[1], 0, nh, s, freqs.to(DEV), True)
+    close("rope_roundtrip", td, t, 1e-5, 1e-5)
+    # patchify: reference view/permute (gaot_3d.py:199-202) and its inverse
+    b, d, h, wd_, p, c = 2, 4, 6, 2, 2, 32
+    grid = gen(b, d * h * wd_, c, seed=7)
+    ref = grid.view(b, d // p, p, h // p, p, wd_ // p, p, c).permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous().view(b, -1, p ** 3 * c)
+    tok = ops.patchify(grid.to(DEV), b, d, h, wd_, p, c, True)
+    assert torch.equal(tok.cpu().view(ref.shape), ref)
+    assert torch.equal(ops.patchify(tok, b, d, h, wd_, p, c, False).cpu(), grid)
+    # mse
+    pr, tg = gen(1234, 3, seed=8), gen(1234, 3, seed=9)
+    prr = pr.clone().requires_grad_(True)
+    lr = F.mse_loss(prr, tg)
+    (lr * 1.7).backward()
+    pdv = pr.to(DEV).requires_grad_(True)
+    l = GF.mse_loss(pdv, tg.to(DEV))
+    (l * 1.7).backward()
+    close("mse", l, lr, 1e-6, 1e-7)
+    close("mse_grad", pdv.grad, prr.grad, 1e-5, 1e-8)
+    # colsum
+    xx = gen(7001, 70, seed=10)
+    close("colsum", ops.colsum(xx.to(DEV), 7001, 70, 70), xx.double().sum(0), 1e-5, 1e-3)
+
+
+def test_linear_family_autograd():
+    from gaot_3d_amd import functional as GF
+    x, w, b = gen(500, 9, seed=1), gen(64, 9, seed=2), gen(64, seed=3)
+    w2, b2 = gen(32, 64, seed=4), gen(32, seed=5)
+    g = gen(500, 32, seed=6)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b, w2, b2)]
+    (F.linear(F.relu(F.linear(leaves[0], leaves[1], leaves[2])), leaves[3], leaves[4]) * g).sum().backward()
+    dl = [t.to(DEV).requires_grad_(True) for t in (x, w, b, w2, b2)]
+    y = GF.linear(GF.linear(dl[0], dl[1], dl[2], act="relu", precision=0), dl[3], dl[4], precision=0)
+    (y * g.to(DEV)).sum().backward()
+    for name, a, r in zip(("dx", "dw", "db", "dw2", "db2"), dl, leaves):
+        close(f"linear_{name}", a.grad, r.grad, 1e-3, 1e-4)
+    # cat_linear == linear(cat) ; multi_linear == cat of linears ; Conv1d storage
+    a1, a2, wc, bc = gen(300, 32, seed=7), gen(300, 32, seed=8), gen(32, 64, 1, seed=9), gen(32, seed=10)
+    gg = gen(300, 32, seed=11)
+    ls = [t.clone().requires_grad_(True) for t in (a1, a2, wc, bc)]
+    (F.linear(torch.cat([ls[0], ls[1]], 1), ls[2][:, :, 0], ls[3]) * gg).sum().backward()
+    ds = [t.to(DEV).requires_grad_(True) for t in (a1, a2, wc, bc)]
+    yy = GF.cat_linear([ds[0], ds[1]], ds[2], ds[3], precision=0)
+    (yy * gg.to(DEV)).sum().backward()
+    for name, a, r in zip(("da1", "da2", "dW", "db"), ds, ls):
+        close(f"catlinear_{name}", a.grad, r.grad, 1e-3, 1e-4)
+    xq, wq, wk = gen(200, 64, seed=12), gen(64, 64, seed=13), gen(32, 64, seed=14)
+    g2 = gen(200, 96, seed=15)
+    lq = [t.clone().requires_grad_(True) for t in (xq, wq, wk)]
+    (torch.cat([F.linear(lq[0], lq[1]), F.linear(lq[0], lq[2])], 1) * g2).sum().backward()
+    dq = [t.to(DEV).requires_grad_(True) for t in (xq, wq, wk)]
+    (GF.multi_linear(dq[0], [dq[1], dq[2]], precision=0) * g2.to(DEV)).sum().backward()
+    for name, a, r in zip(("dx", "dwq", "dwk"), dq, lq):
+        close(f"multilinear_{name}", a.grad, r.grad, 1e-3, 1e-4)
+
+
+def test_geoembed_stats_and_scale_mix():
+    import golden_io as gio
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd import ops
+    meta, g = gio.load("ops")
+    pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
+    gr = ops.build_graph(ei.to(DEV), pos.shape[0], lat.shape[0])
+    feats = ops.geoembed_stats(pos.to(DEV), lat.to(DEV), gr)
+    close("geo_stat_features_golden", feats, g["out"]["geo_stat_features"], 1e-3, 2e-4)
+    # scale mix
+    n = 500
+    xs = [gen(n, 32, seed=i) for i in range(3)]
+    lg, go = gen(n, 3, seed=7), gen(n, 32, seed=8)
+    lx = [t.clone().requires_grad_(True) for t in xs]
+    ll = lg.clone().requires_grad_(True)
+    wts = torch.softmax(ll, -1)
+    ref = sum(wts[:, i:i + 1] * lx[i] for i in range(3))
+    (ref * go).sum().backward()
+    dx = [t.to(DEV).requires_grad_(True) for t in xs]
+    dlg = lg.to(DEV).requires_grad_(True)
+    out = GF.ScaleMixFn.apply(dlg, *dx)
+    (out * go.to(DEV)).sum().backward()
+    close("scalemix_out", out, ref, 1e-5, 1e-6)
+    close("scalemix_dlogits", dlg.grad, ll.grad, 1e-4, 1e-6)
+    for i in range(3):
+        close(f"scalemix_dx{i}", dx[i].grad, lx[i].grad, 1e-5, 1e-6)
