@@ -352,7 +352,8 @@ extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, flo
 extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                              const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk,
                              int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B,
-                             int S, int H, int HKV, int head_dim, float scale, int precision, gaot_stream_t stream) {
+                             int S, int H, int HKV, int head_dim, float scale, int precision, int phase_mask,
+                             gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_bwd: head_dim %d unsupported (only 32)", head_dim);
@@ -366,9 +367,11 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
     AttnBwdArgs a{q, k, v, o, d_o, lse, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, S, H, HKV, scale};
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)B * S * H;
-    hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_attn_bwd_dkv_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_attn_bwd_dq_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 1) hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a);
+    if (phase_mask & 2)
+        hipLaunchKernelGGL(k_attn_bwd_dkv_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 4)
+        hipLaunchKernelGGL(k_attn_bwd_dq_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

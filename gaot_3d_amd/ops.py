@@ -34,6 +34,38 @@ def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# Optional per-call device timing (bench.py): HIP events recorded on the stream the kernels are launched on.
+TIMING = {"enabled": False, "events": {}}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING["enabled"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING["enabled"]:
+            self.e1.record(torch.cuda.current_stream())
+            TIMING["events"].setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
+def timing_reset(enabled: bool):
+    TIMING["enabled"] = enabled
+    TIMING["events"] = {}
+
+
+def timing_summary():
+    """-> {name: (calls, total_ms)} ; call after torch.cuda.synchronize()"""
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in TIMING["events"].items()}
+
+
 # ------------------------------------------------------------------------------------------------
 # CSR
 # ------------------------------------------------------------------------------------------------
@@ -124,8 +156,9 @@ def gno_forward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, g: B
     e = g.by_dst.num_edges
     out = torch.empty(q, m.channels, dtype=torch.float32, device=x_pos.device)
     ws = _ws(lib.gaot_gno_fwd_workspace_bytes(e, m.channels), x_pos.device)
-    check(lib.gaot_gno_fwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(g.by_dst.other), _ptr(g.by_dst.key),
-                           _ptr(g.by_dst.rowptr), e, q, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_gno_fwd")
+    with _timed(f"gno_fwd_nh{m.n_hidden}"):
+        check(lib.gaot_gno_fwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(g.by_dst.other), _ptr(g.by_dst.key),
+                               _ptr(g.by_dst.rowptr), e, q, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_gno_fwd")
     return out
 
 
@@ -147,9 +180,10 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
         gs.weight[l] = gw[l].data_ptr()
         gs.bias[l] = gb[l].data_ptr()
     ws = _ws(lib.gaot_gno_bwd_workspace_bytes(C.byref(m), e), dev)
-    check(lib.gaot_gno_bwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(grad_out), _ptr(g.by_dst.rowptr),
-                           _ptr(g.by_src.key), _ptr(g.by_src.other), _ptr(g.by_src.rowptr), e, g.num_src, g.num_dst,
-                           _ptr(grad_f), C.byref(gs), _ptr(ws), ws.numel(), _stream()), "gaot_gno_bwd")
+    with _timed(f"gno_bwd_nh{m.n_hidden}"):
+        check(lib.gaot_gno_bwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(grad_out), _ptr(g.by_dst.rowptr),
+                               _ptr(g.by_src.key), _ptr(g.by_src.other), _ptr(g.by_src.rowptr), e, g.num_src, g.num_dst,
+                               _ptr(grad_f), C.byref(gs), _ptr(ws), ws.numel(), _stream()), "gaot_gno_bwd")
     return grad_f, gw, gb
 
 
@@ -256,8 +290,9 @@ def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float):
     lse = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     base = qkv.data_ptr()
     q, k, v = C.c_void_p(base), C.c_void_p(base + 4 * h * 32), C.c_void_p(base + 4 * (h + hkv) * 32)
-    check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale),
-                            _PRECISION["mode"], _stream()), "gaot_attn_fwd")
+    with _timed("attn_fwd"):
+        check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale),
+                                _PRECISION["mode"], _stream()), "gaot_attn_fwd")
     return o, lse
 
 
@@ -269,10 +304,12 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     base, gbase = qkv.data_ptr(), dqkv.data_ptr()
     offk, offv = 4 * h * 32, 4 * (h + hkv) * 32
-    check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o), _ptr(d_o),
-                            _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
-                            C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
-                            float(scale), _PRECISION["mode"], _stream()), "gaot_attn_bwd")
+    for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
+        with _timed(name):
+            check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
+                                    _ptr(d_o), _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
+                                    C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
+                                    float(scale), _PRECISION["mode"], mask, _stream()), "gaot_attn_bwd")
     return dqkv
 
 

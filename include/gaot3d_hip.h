@@ -116,7 +116,7 @@ int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, in
  * GroupQueryFlashAttention.forward, src/model/layers/attn.py:110-127 -> F.scaled_dot_product_
  * attention) and its autograd.  q/k/v/o are [B*S, heads*32] views with row strides ld* (floats),
  * so the fused QKV projection output can be addressed in place.  lse/delta: [B, H, S] scratch
- * kept from forward / filled by backward.  head_dim must be 32.  HKV < H = grouped-query heads
+ * kept from forward / filled by backward (phase 1 of gaot_attn_bwd; phases may be issued one by one).  head_dim must be 32.  HKV < H = grouped-query heads
  * (k = k.repeat_interleave(H/HKV)).
  * ------------------------------------------------------------------------------------------- */
 int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq, int64_t ldk,
@@ -125,7 +125,8 @@ int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, floa
 int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                   float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                   int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
-                  float scale, int precision, gaot_stream_t stream);
+                  float scale, int precision, int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */,
+                  gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row / element kernels (HBM-bound).

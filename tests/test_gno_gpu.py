@@ -122,7 +122,25 @@ def test_gno_golden_variable_degree():
         close(f"golden/grad_b{i}", gb[i], gg[f"channel_mlp.fcs.{i}.bias"], 1e-3, 1e-5)
 
 
-@pytest.mark.parametrize("nh", [1, 2, 3, 4])
+def test_gno_four_hidden_layers_forward_only():
+    """NH=4: forward is supported; backward would need 172 KB of LDS per workgroup and must refuse loudly"""
+    from gaot_3d_amd import ops
+    from gaot_3d_amd._lib import GaotError
+    gen = torch.Generator().manual_seed(4)
+    ei = rand_graph(500, 90, 3000, seed=14, dtype=torch.int32)
+    y, x = torch.rand(500, 3, generator=gen), torch.rand(90, 3, generator=gen)
+    f, w = torch.randn(500, 32, generator=gen), torch.randn(90, 32, generator=gen)
+    sd = _mlp_sd([6, 64, 64, 64, 64, 32], seed=4)
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(5)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(5)]
+    g = ops.build_graph(ei.to(DEV), 500, 90)
+    out = ops.gno_forward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), g)
+    close("nh4/out", out, orc.integral_transform(sd, "", y, x, ei, f), 1e-4, 1e-5)
+    with pytest.raises(GaotError):
+        ops.gno_backward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), w.to(DEV), g)
+
+
+@pytest.mark.parametrize("nh", [1, 2, 3])
 def test_gno_random_graph(nh):
     gen = torch.Generator().manual_seed(nh)
     n_src, n_dst, e = 3000, 700, 20011
