@@ -49,6 +49,9 @@ SIGNATURES = {
     "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
     "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
     "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
+    "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),

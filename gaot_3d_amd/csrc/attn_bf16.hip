@@ -1,0 +1,479 @@
+// bf16 matrix-core attention (v_mfma_f32_32x32x16_bf16, fp32 softmax / accumulators) for the latent
+// Transformer -- same operator as attn.hip (reference src/model/layers/attn.py:110-127), precision 1.
+//
+// With head_dim 32 the kernel is bound by the softmax VALU work, not by the MFMAs, so the design
+// minimises everything that is not exp/max/sum:
+//   * a prep pass turns the fused fp32 q|k|v projection into ONE bf16 image [rows][(h+2hkv)*32]
+//     with RoPE applied and q pre-multiplied by (1/sqrt(d))*log2(e): the kernels use exp2 directly;
+//   * K/V (fwd, dQ) or Q/dO (dK/dV) stream through LDS as row-major 32x32 bf16 tiles (64-B rows,
+//     16-B chunks XOR-swizzled by (row>>2)&3): ds_read_b128 serves the operands that contract over
+//     head_dim, ds_read_b64_tr_b16 (hardware transpose) the operands that contract over rows --
+//     one image, both uses, conflict-free;
+//   * score tiles are computed transposed where needed so that the fp32 accumulator of one MFMA
+//     chain, rounded to bf16 in registers, IS the B operand of the next chain (no LDS round trip
+//     for P / dS).
+// dQ has its own pass: no float atomics, bit-reproducible gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 32;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// ---- LDS tile: [32 rows][32 bf16] = 2 KB, 16-B chunk c of row r lives at chunk c ^ ((r>>2)&3) ----------
+constexpr int TILE_BYTES = 32 * 64;
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// operand that contracts over head_dim: lane (row = l31, half hf), k-step s -> 8 bf16 = cols 16s+8hf..+7
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int l31, int hf, int s) {
+    return *reinterpret_cast<const bf16x8*>(tile + tile_off(l31, 2 * s + hf));
+}
+// operand that contracts over tile ROWS (transposed use): lane (col = l31, half hf), k-step s ->
+// element j = tile[row 16s + 8(j>>2) + 4hf + (j&3)][col]  (the k order of an accumulator-as-operand)
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int lane, int s) {
+    const int i = lane & 15, grp = (lane >> 4) & 1, hf = lane >> 5;
+    const int col = 16 * grp + 4 * (i & 3);          // this lane ADDRESSES row (i>>2), cols col..col+3 of the block
+    const int r0 = 16 * s + 4 * hf + (i >> 2);
+    const int r1 = r0 + 8;
+    const char* p0 = tile + tile_off(r0, col >> 3) + ((col & 7) << 1);
+    const char* p1 = tile + tile_off(r1, col >> 3) + ((col & 7) << 1);
+    const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p0));
+    const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p1));
+    bf16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    return o;
+}
+// fp32 accumulator tile (16 regs) -> two bf16 B-operand fragments (k-steps 0,1)
+__device__ __forceinline__ void acc_to_frags(const f32x16& p, bf16x8& f0, bf16x8& f1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f0[j] = (short)f2bf(p[j]);
+        f1[j] = (short)f2bf(p[8 + j]);
+    }
+}
+
+// cooperative stage of NT tiles (each [32][32] bf16) of a row-major bf16 matrix with row pitch ld (elements)
+// tiles 0,1 come from matrix A (rows row0.., row0+32..), tiles 2,3 from matrix B (same rows)
+__device__ __forceinline__ void stage_load4(uint4 (&regs)[2], const bf16_t* pa, int64_t lda, const bf16_t* pb, int64_t ldb,
+                                            int64_t row0, int64_t nrows) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int t = idx >> 7, r = (idx & 127) >> 2, c = idx & 3;
+        const int64_t row = row0 + 32 * (t & 1) + r;
+        const bf16_t* base = (t < 2) ? pa : pb;
+        const int64_t ld = (t < 2) ? lda : ldb;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row < nrows) val = *reinterpret_cast<const uint4*>(base + row * ld + 8 * c);
+        regs[it] = val;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stage_store(const uint4 (&regs)[(NT * 128 + 255) / 256], char* lds) {
+#pragma unroll
+    for (int it = 0; it < (NT * 128 + 255) / 256; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int t = idx >> 7, r = (idx & 127) >> 2, c = idx & 3;
+        if (t < NT) *reinterpret_cast<uint4*>(lds + t * TILE_BYTES + tile_off(r, c)) = regs[it];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: fp32 fused projection [rows][ld] -> bf16 image, RoPE on q,k heads (optional), q *= qscale
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prep_qkv(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int ld, int nq_heads,
+                           int nk_heads, int S, const float* __restrict__ freqs, float qscale) {
+    const int pairs = ld / 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * pairs) return;
+    const int p = (int)(i % pairs);
+    const int64_t row = i / pairs;
+    const int col = 2 * p;
+    const int head = col / D;
+    float2 v = *reinterpret_cast<const float2*>(x + row * ld + col);
+    if (freqs && head < nq_heads + nk_heads) {
+        const float ang = (float)(row % S) * freqs[(col % D) >> 1];
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        v = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
+    }
+    if (head < nq_heads) { v.x *= qscale; v.y *= qscale; }
+    const unsigned packed = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    *reinterpret_cast<unsigned*>(y + row * ld + col) = packed;
+}
+
+// prep for backward: dO fp32 -> bf16, delta[b][h][s] = sum_d dO*O (fp32)
+__global__ void k_prep_do(const float* __restrict__ d_o, const float* __restrict__ o, bf16_t* __restrict__ dob,
+                          float* __restrict__ delta, int B, int S, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, head)
+    const int64_t n = (int64_t)B * S * H;
+    if (i >= n) return;
+    const int head = (int)(i % H);
+    const int64_t row = i / H;
+    const float* dp = d_o + row * H * D + head * D;
+    const float* op = o + row * H * D + head * D;
+    bf16_t* yp = dob + row * H * D + head * D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(dp + 4 * c);
+        const float4 b = *reinterpret_cast<const float4*>(op + 4 * c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        const uint2 pk = make_uint2((unsigned)f2bf(a.x) | ((unsigned)f2bf(a.y) << 16),
+                                    (unsigned)f2bf(a.z) | ((unsigned)f2bf(a.w) << 16));
+        *reinterpret_cast<uint2*>(yp + 4 * c) = pk;
+    }
+    delta[((row / S) * H + head) * S + (row % S)] = s;
+}
+
+struct FwdArgs {
+    const bf16_t* qkv;   // bf16 image [B*S][ld]
+    float* o;            // [B*S][H*32] fp32
+    float* lse;          // [B][H][S]
+    int64_t ld;
+    int B, S, H, HKV;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_attn_fwd_bf16(FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int hkv = head / (a.H / a.HKV);
+    const int64_t q0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t rowbase = (int64_t)b * a.S;
+    const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
+    const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
+    const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
+
+    bf16x8 qf[2];
+    {
+        const int64_t qi = q0 + l31;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (qi < a.S) qf[s] = *reinterpret_cast<const bf16x8*>(qp + qi * a.ld + 16 * s + 8 * hf);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[s][j] = 0;
+            }
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    uint4 regs[2];
+    stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
+    for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
+        __syncthreads();
+        stage_store<4>(regs, lds);
+        __syncthreads();
+        if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t kb = k0 + 32 * t;
+            if (kb >= a.S) break;
+            const char* kt = lds + t * TILE_BYTES;
+            const char* vt = lds + (2 + t) * TILE_BYTES;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, ks), qf[ks], s, 0, 0, 0);
+            if (kb + 32 > a.S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + mfma32_row(r, hf) >= a.S) s[r] = -INFINITY;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, xhalf(mx));
+            const float mn = fmaxf(m, mx);
+            const float alpha = exp2f(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - mn);
+                ps += s[r];
+            }
+            ps += xhalf(ps);
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= alpha;
+            bf16x8 p0, p1;
+            acc_to_frags(s, p0, p1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
+        }
+    }
+    const int64_t qi = q0 + l31;
+    if (qi < a.S) {
+        const float inv = 1.f / l;
+        float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hf) = t;
+        }
+        if (hf == 0) a.lse[((int64_t)b * a.H + head) * a.S + qi] = m * LN2 + logf(l);
+    }
+}
+
+struct BwdArgs {
+    const bf16_t* qkv;   // bf16 image (q pre-scaled by scale*log2e)
+    const bf16_t* dob;   // bf16 dO [B*S][H*32]
+    const float* lse;    // [B][H][S]
+    const float* delta;  // [B][H][S]
+    float* dqkv;         // fp32 [B*S][ld]
+    int64_t ld;
+    int B, S, H, HKV;
+    float scale;
+};
+
+// ------------------------------------------------------------------------------------------------
+// dK / dV: 4 waves x 32 keys; Q / dO tiles stream through LDS; grid (ceil(S/128), HKV, B)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_bf16(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // Q0 Q1 dO0 dO1
+    __shared__ float lse_s[64];
+    __shared__ float del_s[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int hkv = blockIdx.y, b = blockIdx.z;
+    const int rep = a.H / a.HKV;
+    const int64_t key0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t rowbase = (int64_t)b * a.S;
+    const int64_t ki = key0 + l31;
+    bf16x8 kf[2], vf[2];
+    {
+        const bf16_t* kp = a.qkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+        const bf16_t* vp = a.qkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (ki < a.S) {
+                kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s + 8 * hf);
+                vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * hf);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kf[s][j] = 0; vf[s][j] = 0; }
+            }
+        }
+    }
+    f32x16 dkt, dvt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
+
+    for (int hr = 0; hr < rep; ++hr) {
+        const int head = hkv * rep + hr;
+        const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
+        const bf16_t* dop = a.dob + rowbase * (a.H * D) + head * D;
+        const float* lsep = a.lse + ((int64_t)b * a.H + head) * a.S;
+        const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
+        uint4 regs[2];
+        stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, 0, a.S);
+        float lt = 0.f, et = 0.f;
+        if (threadIdx.x < 64) {
+            lt = (threadIdx.x < a.S) ? lsep[threadIdx.x] * LOG2E : INFINITY;
+            et = (threadIdx.x < a.S) ? delp[threadIdx.x] : 0.f;
+        }
+        for (int64_t q0 = 0; q0 < a.S; q0 += 64) {
+            __syncthreads();
+            stage_store<4>(regs, lds);
+            if (threadIdx.x < 64) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            __syncthreads();
+            if (q0 + 64 < a.S) {
+                stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + 64, a.S);
+                if (threadIdx.x < 64) {
+                    const int64_t qq = q0 + 64 + threadIdx.x;
+                    lt = (qq < a.S) ? lsep[qq] * LOG2E : INFINITY;
+                    et = (qq < a.S) ? delp[qq] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (q0 + 32 * t >= a.S) break;
+                const char* qt = lds + t * TILE_BYTES;
+                const char* dt = lds + (2 + t) * TILE_BYTES;
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, l31, hf, ks), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dt, l31, hf, ks), vf[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = 32 * t + mfma32_row(r, hf);
+                    const float p = exp2f(s[r] - lse_s[qr]);
+                    s[r] = p;
+                    dp[r] = p * (dp[r] - del_s[qr]);
+                }
+                bf16x8 p0, p1, d0, d1;
+                acc_to_frags(s, p0, p1);
+                acc_to_frags(dp, d0, d1);
+                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dt, lane, 0), p0, dvt, 0, 0, 0);
+                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dt, lane, 1), p1, dvt, 0, 0, 0);
+                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(qt, lane, 0), d0, dkt, 0, 0, 0);
+                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(qt, lane, 1), d1, dkt, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (ki < a.S) {
+        float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+        float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+        const float ksc = 1.0f / LOG2E;  // Q image carries scale*log2e: dK = dS^T (Q*scale) = dS^T Qimg / log2e
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = make_float4(dkt[4 * g] * ksc, dkt[4 * g + 1] * ksc, dkt[4 * g + 2] * ksc, dkt[4 * g + 3] * ksc);
+            *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
+            float4 u = make_float4(dvt[4 * g], dvt[4 * g + 1], dvt[4 * g + 2], dvt[4 * g + 3]);
+            *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: 4 waves x 32 queries; K / V tiles stream through LDS; grid (ceil(S/128), H, B)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_bf16(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int hkv = head / (a.H / a.HKV);
+    const int64_t q0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t rowbase = (int64_t)b * a.S;
+    const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
+    const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
+    const int64_t qi = q0 + l31;
+    bf16x8 qf[2], dof[2];
+    {
+        const bf16_t* qp = a.qkv + (rowbase + qi) * a.ld + head * D;
+        const bf16_t* dop = a.dob + (rowbase + qi) * (a.H * D) + head * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (qi < a.S) {
+                qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hf);
+                dof[s] = *reinterpret_cast<const bf16x8*>(dop + 16 * s + 8 * hf);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { qf[s][j] = 0; dof[s][j] = 0; }
+            }
+        }
+    }
+    const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
+    const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
+    f32x16 dqt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+
+    uint4 regs[2];
+    stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
+    for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
+        __syncthreads();
+        stage_store<4>(regs, lds);
+        __syncthreads();
+        if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t kb = k0 + 32 * t;
+            if (kb >= a.S) break;
+            const char* kt = lds + t * TILE_BYTES;
+            const char* vt = lds + (2 + t) * TILE_BYTES;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, ks), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, ks), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = exp2f(s[r] - lse2);
+                if (kb + mfma32_row(r, hf) >= a.S) p = 0.f;
+                dp[r] = p * (dp[r] - del);
+            }
+            bf16x8 d0, d1;
+            acc_to_frags(dp, d0, d1);
+            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 0), d0, dqt, 0, 0, 0);
+            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 1), d1, dqt, 0, 0, 0);
+        }
+    }
+    if (qi < a.S) {
+        float* dqp = a.dqkv + (rowbase + qi) * a.ld + head * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = make_float4(dqt[4 * g] * a.scale, dqt[4 * g + 1] * a.scale, dqt[4 * g + 2] * a.scale,
+                                   dqt[4 * g + 3] * a.scale);
+            *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
+        }
+    }
+}
+
+}  // namespace
+
+// fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
+extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
+    return sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64;
+}
+
+extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse,
+                                  int B, int S, int H, int HKV, int head_dim, float scale, gaot_stream_t stream) {
+    GAOT_ENTER();
+    if (head_dim != D) {
+        gaot_set_error("gaot_attn_fwd_bf16: head_dim %d unsupported (only 32)", head_dim);
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
+    GAOT_CHECK_ARG(qkv && qkv_image && o && lse, "null pointer");
+    GAOT_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_image | (uintptr_t)o) & 15) == 0, "buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld = (H + 2 * HKV) * D;
+    const int64_t rows = (int64_t)B * S;
+    const int64_t n = rows * (ld / 2);
+    hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
+                       HKV, S, rope_freqs, scale * LOG2E);
+    FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
+    hipLaunchKernelGGL(k_attn_fwd_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse,
+                                  void* do_image, float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim,
+                                  float scale, int phase_mask, gaot_stream_t stream) {
+    GAOT_ENTER();
+    if (head_dim != D) {
+        gaot_set_error("gaot_attn_bwd_bf16: head_dim %d unsupported (only 32)", head_dim);
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
+    GAOT_CHECK_ARG(qkv_image && o && d_o && lse && do_image && delta && dqkv, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int ld = (H + 2 * HKV) * D;
+    BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, dqkv, ld, B, S, H, HKV, scale};
+    const int64_t n = (int64_t)B * S * H;
+    if (phase_mask & 1)
+        hipLaunchKernelGGL(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
+                           S, H);
+    if (phase_mask & 2)
+        hipLaunchKernelGGL(k_attn_bwd_dkv_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 4)
+        hipLaunchKernelGGL(k_attn_bwd_dq_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

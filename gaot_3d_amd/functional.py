@@ -113,26 +113,36 @@ class RMSNormFn(Function):
 
 
 class AttentionFn(Function):
-    """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k."""
+    """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k.
+    precision fp32: exact-fp32 MFMA kernels (csrc/attn.hip); bf16: csrc/attn_bf16.hip."""
 
     @staticmethod
     def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int):
-        if freqs is not None:
-            qkv = qkv.clone()
-            ld = qkv.shape[1]
-            ops.rope_(qkv, b * s, ld, 0, h + hkv, s, freqs, False)  # q heads then k heads are adjacent columns
         scale = 1.0 / (32 ** 0.5)
-        o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale)
-        ctx.save_for_backward(qkv, o, lse, freqs if freqs is not None else torch.empty(0, device=qkv.device))
-        ctx.dims = (b, s, h, hkv, scale, freqs is not None)
+        bf16 = ops.get_precision() == "bf16"
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        if bf16:
+            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale)
+            keep = img
+        else:
+            if freqs is not None:
+                qkv = qkv.clone()
+                ops.rope_(qkv, b * s, qkv.shape[1], 0, h + hkv, s, freqs, False)  # q then k heads: adjacent columns
+            o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale)
+            keep = qkv
+        ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else torch.empty(0, device=qkv.device))
+        ctx.dims = (b, s, h, hkv, scale, freqs is not None, bf16)
         return o
 
     @staticmethod
     def backward(ctx, d_o: Tensor):
-        qkv, o, lse, freqs = ctx.saved_tensors
-        b, s, h, hkv, scale, rope = ctx.dims
+        keep, o, lse, freqs = ctx.saved_tensors
+        b, s, h, hkv, scale, rope, bf16 = ctx.dims
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
-        dqkv = ops.attn_bwd(qkv, o, d, lse, b, s, h, hkv, scale)
+        if bf16:
+            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale)
+        else:
+            dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale)
         if rope:
             ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
         return dqkv, None, None, None, None, None

@@ -110,5 +110,9 @@ class GAOT3D(nn.Module):
         rndata = self.encoder(batch=batch, latent_tokens_pos=lat, latent_tokens_batch_idx=lat_bidx)
         rndata = self.process(rndata=rndata, condition=condition)
         flat = rndata.view(-1, self.node_latent_size)
+        shard_group = getattr(self, "_shard_group", None)
+        if shard_group is not None:  # decoder runs on this rank's points only: its latent gradient is a partial sum
+            from ..sharding import AllReduceGradFn
+            flat = AllReduceGradFn.apply(flat, shard_group)
         return self.decoder(rndata_flat=flat, phys_pos_query=q_pos, batch_idx_phys_query=q_bidx, latent_tokens_pos=lat,
                             latent_tokens_batch_idx=lat_bidx, batch=batch)

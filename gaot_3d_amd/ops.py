@@ -313,6 +313,32 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     return dqkv
 
 
+def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float):
+    """bf16 matrix-core attention on the fused fp32 projection; returns (o, lse, bf16 image kept for backward)"""
+    lib = _lib.load()
+    dev = qkv.device
+    o = torch.empty(b * s, h * 32, dtype=torch.float32, device=dev)
+    lse = torch.empty(b, h, s, dtype=torch.float32, device=dev)
+    img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), dev)
+    with _timed("attn_fwd"):
+        check(lib.gaot_attn_fwd_bf16(_ptr(qkv), _ptr(freqs), _ptr(img), _ptr(o), _ptr(lse), b, s, h, hkv, 32, float(scale),
+                                     _stream()), "gaot_attn_fwd_bf16")
+    return o, lse, img
+
+
+def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float) -> Tensor:
+    lib = _lib.load()
+    dev = o.device
+    dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
+    delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
+    doimg = _ws(2 * b * s * h * 32 + 64, dev)
+    for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
+        with _timed(name):
+            check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
+                                         b, s, h, hkv, 32, float(scale), mask, _stream()), "gaot_attn_bwd_bf16")
+    return dqkv
+
+
 def swiglu_fwd(ag: Tensor, f: int) -> Tensor:
     lib = _lib.load()
     rows = ag.shape[0]

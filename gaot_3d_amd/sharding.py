@@ -1,0 +1,152 @@
+"""Point-sharding of ONE sample across the GPUs of a node (new w.r.t. the reference, whose only
+parallelism is sample-level DDP, src/trainer/stat.py:431-436).
+
+Partition: physical points are split into `world` contiguous ranges; every edge lives with its PHYSICAL
+endpoint (encoder: source, decoder: query), so edges, features, targets and predictions are disjoint across
+ranks.  Latent coordinates, the latent Transformer and all parameters are replicated.
+
+Exchange steps (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
+  forward : encoder GNO   per-token SUM [M,C] and COUNT [M]  -> all_reduce(SUM) -> mean = sum / max(count,1)
+  backward: decoder       partial d(loss)/d(latent) [M,C]    -> all_reduce(SUM) before the (replicated, hence
+            identical) Transformer backward
+  after backward: gradients of the per-point / per-edge parameters (encoder.lifting, encoder.gno, decoder.*)
+            are partial sums -> one flat all_reduce (~125 KB).  Per-token parameters (encoder.geoembed,
+            encoder.recovery, patch_linear, processor.*) see identical full gradients on every rank.
+The geometry-only GeoEmbed statistics of the encoder need every point of the sample: the shard keeps the full
+coordinate array and the full encoder edge list for that one sweep (no gradients flow through it).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .data import MeshBatch
+
+Tensor = torch.Tensor
+
+
+def shard_range(n: int, rank: int, world: int):
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+def shard_batch(batch: MeshBatch, rank: int, world: int, num_latent: int) -> MeshBatch:
+    """Rank-local view of a single-graph batch: points [lo,hi), their features/targets, and the edges whose
+    physical endpoint is in the range, re-indexed to local point ids.  Adds ``geo_pos`` /
+    ``geo_encoder_edge_index_s*`` (full geometry) for the encoder's GeoEmbed statistics."""
+    if getattr(batch, "num_graphs", 1) != 1:
+        raise ValueError("point-sharding splits ONE sample; batch several samples with DDP instead")
+    n = batch.pos.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    out = MeshBatch()
+    for k, v in batch.__dict__.items():
+        if k.startswith("_"):
+            continue
+        if not torch.is_tensor(v):
+            setattr(out, k, v)
+            continue
+        if k.startswith("encoder_edge_index"):
+            m = (v[0] >= lo) & (v[0] < hi)
+            e = v[:, m].clone()
+            e[0] -= lo
+            setattr(out, k, e)
+            setattr(out, "geo_" + k, v)
+        elif k.startswith("decoder_edge_index"):
+            m = (v[1] >= lo) & (v[1] < hi)
+            e = v[:, m].clone()
+            e[1] -= lo
+            setattr(out, k, e)
+        elif k == "ptr":
+            continue
+        elif v.dim() >= 1 and v.shape[0] == n:
+            setattr(out, k, v[lo:hi].contiguous())
+        else:
+            setattr(out, k, v)
+    out.geo_pos = batch.pos
+    out.num_graphs = 1
+    out.shard = (rank, world, lo, hi, n)
+    out.ptr = torch.tensor([0, hi - lo], dtype=torch.long, device=batch.pos.device)
+    return out
+
+
+class GlobalSegmentMeanFn(torch.autograd.Function):
+    """local per-row mean + local degree  ->  mean over the edges of ALL ranks.
+    Backward receives the full gradient (the consumer is replicated) and returns its local share."""
+
+    @staticmethod
+    def forward(ctx, local_mean: Tensor, local_deg: Tensor, group):
+        s = local_mean * local_deg[:, None]
+        d = local_deg.clone()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+        dg = d.clamp(min=1.0)
+        ctx.save_for_backward(local_deg / dg)
+        return s / dg[:, None]
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (ratio,) = ctx.saved_tensors
+        return g * ratio[:, None], None, None
+
+
+class AllReduceGradFn(torch.autograd.Function):
+    """identity in forward; SUM all-reduce of the gradient in backward (partial -> full)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+PARTIAL_GRAD_PREFIXES = ("encoder.lifting.", "encoder.gno.", "decoder.")
+
+
+def partial_grad_parameters(model) -> List[torch.nn.Parameter]:
+    return [p for k, p in model.named_parameters() if p.requires_grad and k.startswith(PARTIAL_GRAD_PREFIXES)]
+
+
+def allreduce_partial_grads(params: List[torch.nn.Parameter], group):
+    """one flat SUM all-reduce over the gradients of the per-point / per-edge parameters"""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class ShardedStep:
+    """forward + MSE + backward of the drop-in model on a rank-local shard (see module docstring)."""
+
+    def __init__(self, model, group, n_total: int):
+        self.model = model
+        self.group = group
+        self.n_total = n_total
+        self.partial = partial_grad_parameters(model)
+        model.encoder._shard_group = group
+        model._shard_group = group
+
+    def forward_backward(self, batch: MeshBatch, tokens_pos: Optional[Tensor]):
+        from . import functional as GF
+        pred = self.model(batch=batch, tokens_pos=tokens_pos)
+        n_local = pred.shape[0]
+        # global MSE = sum over ranks of (local sum of squares) / (N_total * out)
+        loss = GF.mse_loss(pred, batch.x) * (float(n_local) / float(self.n_total))
+        loss.backward()
+        allreduce_partial_grads(self.partial, self.group)
+        total = loss.detach().clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return total

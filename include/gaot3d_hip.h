@@ -128,6 +128,18 @@ int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o
                   float scale, int precision, int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */,
                   gaot_stream_t stream);
 
+/* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
+ * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
+ * rope_freqs != NULL, q pre-scaled) into qkv_image (gaot_attn_bf16_image_bytes), which the backward re-uses;
+ * backward writes the fp32 gradient w.r.t. the ROTATED q|k|v into dqkv (apply gaot_rope(inverse=1) after it).
+ * do_image: scratch of B*S*H*32 bf16. */
+size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
+int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
+                       int H, int HKV, int head_dim, float scale, gaot_stream_t stream);
+int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse, void* do_image,
+                       float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim, float scale,
+                       int phase_mask, gaot_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row / element kernels (HBM-bound).
  *   rmsnorm : y = x * rsqrt(mean(x^2) + eps) * w         (attn.py:174-178); rstd[rows] kept for bwd

@@ -104,6 +104,36 @@ def test_attention_fwd_bwd(b, s, h, hkv, rope):
     close(f"attn_dqkv_{s}", qd.grad, qr.grad, 1e-3, 2e-5)
 
 
+@pytest.mark.parametrize("b,s,h,hkv,rope", [(1, 64, 2, 2, False), (2, 100, 2, 1, True), (1, 333, 8, 8, True),
+                                            (1, 1, 1, 1, False), (1, 1000, 4, 2, False)])
+def test_attention_bf16(b, s, h, hkv, rope):
+    """bf16 matrix-core path against the fp64 reference on the same inputs: tolerance of bf16 operands
+    (outputs rtol 2e-2; gradients: cosine similarity >= 0.999 and rtol 5e-2 on the peak scale)"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    qkv = gen(b * s, (h + 2 * hkv) * 32, seed=s)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)) if rope else None
+    w = gen(b * s, h * 32, seed=s + 1)
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = _attn_ref(qr, b, s, h, hkv, freqs.double() if rope else None)
+    (ref * w.double()).sum().backward()
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        qd = qkv.to(DEV).requires_grad_(True)
+        out = GF.AttentionFn.apply(qd, freqs.to(DEV) if rope else None, b, s, h, hkv)
+        (out * w.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    close(f"attn_bf16_out_{s}", out, ref, 2e-2, 2e-2)
+    g, gr = qd.grad.cpu().double(), qr.grad
+    cos = (g * gr).sum() / (g.norm() * gr.norm() + 1e-30)
+    print(f"[parity] attn_bf16_dqkv_{s}: cosine={cos.item():.6f} max_abs={(g - gr).abs().max().item():.3e} "
+          f"ref_peak={gr.abs().max().item():.3e}")
+    assert cos.item() >= 0.999 or gr.abs().max().item() < 1e-12
+    assert (g - gr).abs().max().item() <= 5e-2 * gr.abs().max().item() + 1e-6
+
+
 def test_attention_spike_rows():
     """online-softmax rescale path: one key dominates late in the sequence"""
     from gaot_3d_amd import functional as GF
