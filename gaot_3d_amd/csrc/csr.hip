@@ -118,25 +118,90 @@ __global__ void k_fill(const IDX* __restrict__ keys, int64_t E, int* __restrict_
     }
 }
 
-// G lanes cooperate on one row: rank sort of the (unique) edge ids of the row, then emit the
-// sorted id, the key and the other endpoint.  G in {8, 64}.
+constexpr int HEAVY_DEG = 128;     // rows longer than this go to the block-wide LDS sort
+constexpr int BITONIC_MAX = 8192;  // ints in LDS (32 KB)
+
+template <typename IDX>
+__device__ __forceinline__ void emit_sorted(int p, int id, int64_t row, const IDX* __restrict__ other, int* perm,
+                                            int* key_sorted, int* other_sorted) {
+    perm[p] = id;
+    key_sorted[p] = (int)row;
+    other_sorted[p] = (int)other[id];
+}
+
+// Light rows: G lanes cooperate on one row with a rank sort of the (unique) edge ids -- O(n^2/G) L1 hits,
+// fine for short rows.  Rows longer than HEAVY_DEG are queued for k_row_sort_heavy instead.  G in {8, 64}.
 template <typename IDX, int G>
 __global__ void k_row_sort(const IDX* __restrict__ keys, const IDX* __restrict__ other, int64_t Q,
                            const int* __restrict__ rowptr, const int* __restrict__ tmp, int* __restrict__ perm,
-                           int* __restrict__ key_sorted, int* __restrict__ other_sorted) {
+                           int* __restrict__ key_sorted, int* __restrict__ other_sorted, int* __restrict__ heavy_count,
+                           int* __restrict__ heavy_list) {
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int gl = threadIdx.x % G;
     if (gid >= Q) return;
     const int b = rowptr[gid], e = rowptr[gid + 1];
     const int n = e - b;
+    if (n > HEAVY_DEG) {
+        if (gl == 0) heavy_list[atomicAdd(heavy_count, 1)] = (int)gid;
+        return;
+    }
     for (int i = gl; i < n; i += G) {
         const int id = tmp[b + i];
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += (tmp[b + j] < id) ? 1 : 0;
-        const int p = b + rank;
-        perm[p] = id;
-        key_sorted[p] = (int)gid;
-        other_sorted[p] = (int)other[id];
+        emit_sorted<IDX>(b + rank, id, gid, other, perm, key_sorted, other_sorted);
+    }
+}
+
+// Heavy rows: one workgroup per row (persistent over the queue).  n <= BITONIC_MAX: bitonic sort of the ids
+// in LDS (n log^2 n); longer rows: chunked rank sort against LDS-resident chunks.  Which block sorts which
+// row does not matter: the result (ascending edge id inside the row) is unique.
+template <typename IDX>
+__global__ __launch_bounds__(256) void k_row_sort_heavy(const IDX* __restrict__ other, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ tmp, int* __restrict__ perm,
+                                                        int* __restrict__ key_sorted, int* __restrict__ other_sorted,
+                                                        const int* __restrict__ heavy_count,
+                                                        const int* __restrict__ heavy_list) {
+    __shared__ int sh[BITONIC_MAX];
+    const int nheavy = *heavy_count;
+    for (int w = blockIdx.x; w < nheavy; w += gridDim.x) {
+        const int row = heavy_list[w];
+        const int b = rowptr[row], n = rowptr[row + 1] - b;
+        __syncthreads();
+        if (n <= BITONIC_MAX) {
+            int np = 1;
+            while (np < n) np <<= 1;
+            for (int i = threadIdx.x; i < np; i += 256) sh[i] = (i < n) ? tmp[b + i] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= np; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = threadIdx.x; i < np; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const int a = sh[i], c = sh[ixj];
+                            const bool up = (i & k) == 0;
+                            if ((a > c) == up) { sh[i] = c; sh[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < n; i += 256) emit_sorted<IDX>(b + i, sh[i], row, other, perm, key_sorted, other_sorted);
+        } else {
+            for (int t0 = 0; t0 < n; t0 += 256) {       // 256 targets per pass, one per thread
+                const int ti = t0 + threadIdx.x;
+                const int id = (ti < n) ? tmp[b + ti] : 0;
+                int rank = 0;
+                for (int c0 = 0; c0 < n; c0 += BITONIC_MAX) {
+                    const int cn = min(BITONIC_MAX, n - c0);
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < cn; i += 256) sh[i] = tmp[b + c0 + i];
+                    __syncthreads();
+                    if (ti < n)
+                        for (int i = 0; i < cn; ++i) rank += (sh[i] < id) ? 1 : 0;
+                }
+                if (ti < n) emit_sorted<IDX>(b + rank, id, row, other, perm, key_sorted, other_sorted);
+            }
+        }
     }
 }
 
@@ -151,7 +216,10 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     int* cursor = counts + (Q + 1);         // [Q+1]
     int* bsum = cursor + (Q + 1);           // [nb+1]
     int* tmp = bsum + (nb + 1);             // [E]
+    int* heavy_count = tmp + E;             // [1] (+3 pad)
+    int* heavy_list = heavy_count + 4;      // [<= E / HEAVY_DEG + 1]
     hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(Q + 1), st);
+    hipMemsetAsync(heavy_count, 0, sizeof(int) * 4, st);
     if (E == 0) {
         hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
         return GAOT_OK;
@@ -166,12 +234,14 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     if (E / (Q > 0 ? Q : 1) >= 16) {
         const int64_t threads = Q * 64;
         hipLaunchKernelGGL((k_row_sort<IDX, 64>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted);
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list);
     } else {
         const int64_t threads = Q * 8;
         hipLaunchKernelGGL((k_row_sort<IDX, 8>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted);
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list);
     }
+    hipLaunchKernelGGL((k_row_sort_heavy<IDX>), dim3(1024), dim3(256), 0, st, other, rowptr, tmp, perm, key_sorted,
+                       other_sorted, heavy_count, heavy_list);
     return GAOT_OK;
 }
 
@@ -179,7 +249,7 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
 
 extern "C" size_t gaot_csr_workspace_bytes(int64_t num_edges, int64_t num_rows) {
     const int64_t nb = ceil_div(num_rows, SCAN_TILE);
-    return sizeof(int) * (size_t)(2 * (num_rows + 1) + (nb + 1) + num_edges) + 64;
+    return sizeof(int) * (size_t)(2 * (num_rows + 1) + (nb + 1) + num_edges + 4 + num_edges / HEAVY_DEG + 1) + 64;
 }
 
 extern "C" int gaot_csr_build(const void* edge_index, int index_is_i64, int64_t num_edges, int sort_row,

@@ -285,7 +285,12 @@ struct GemmPlan {
     int splits;
     int64_t kps;
 };
-static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
+int gaot_gemm_bf16_dispatch(const float* A, const float* B, float* C, float* preact, const float* bias,
+                            const float* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                            int64_t ldc, int64_t ldr, int a_trans, int b_trans, int act, int splits, int64_t kps,
+                            int a_vec, int b_vec, hipStream_t st);
+
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
     GemmPlan p;
     p.cfg = N <= 32 ? 0 : (N <= 64 ? 1 : 2);
     const int bm = 128, bn = p.cfg == 0 ? 32 : (p.cfg == 1 ? 64 : 128);
@@ -295,14 +300,14 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
         s = std::min<int64_t>(64, std::max<int64_t>(1, 512 / tiles));
         s = std::min<int64_t>(s, ceil_div(K, 1024));
     }
-    p.kps = ceil_div(ceil_div(K, s), BK) * BK;
+    p.kps = ceil_div(ceil_div(K, s), bk) * bk;
     p.splits = (int)std::max<int64_t>(1, ceil_div(K, std::max<int64_t>(p.kps, 1)));
     if (p.splits <= 1) { p.splits = 1; p.kps = K; }
     return p;
 }
 
 extern "C" size_t gaot_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    const GemmPlan p = plan_gemm(M, N, K);
+    const GemmPlan p = plan_gemm(M, N, K);   // the 64-deep bf16 tiling never needs more splits than this
     return p.splits > 1 ? sizeof(float) * (size_t)(p.splits * M * N) + 64 : 0;
 }
 
@@ -324,7 +329,8 @@ extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, in
     const int a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
     const int b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
 
-    const GemmPlan p = plan_gemm(M, N, K);
+    const bool wide_bf16 = precision == 1 && N > 64;
+    const GemmPlan p = plan_gemm(M, N, K, wide_bf16 ? 64 : BK);
     GemmArgs gk = g;
     float* part = (float*)workspace;
     if (p.splits > 1) {
@@ -333,7 +339,11 @@ extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, in
         gk.k_per_split = p.kps;
         gk.C = part;
     }
-    if (p.cfg == 0) launch_cfg<4, 1, 1, 1>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
+    if (wide_bf16) {
+        int rc = gaot_gemm_bf16_dispatch(A, B, gk.C, preact, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_trans, b_trans,
+                                         act, gk.splits, gk.k_per_split, a_vec, b_vec, st);
+        if (rc != GAOT_OK) return rc;
+    } else if (p.cfg == 0) launch_cfg<4, 1, 1, 1>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else if (p.cfg == 1) launch_cfg<4, 1, 1, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else launch_cfg<2, 2, 2, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     if (gk.splits > 1) {

@@ -1,0 +1,250 @@
+// bf16 matrix-core GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 I/O) for the Transformer
+// projections and their autograd -- precision 1 of gaot_gemm (see gemm.hip for the operator contract).
+//
+//   C[m][n] = act( sum_k A(m,k) B(k,n) + bias[n] ) + residual[m][n]
+//
+// fp32 operands are rounded to bf16 once, while they are staged into LDS.  An operand whose reduction
+// index is contiguous in memory (x in x W^T, W in x W^T, dy in dy W) is staged as [row][64 k] and read
+// with ds_read_b128; an operand whose reduction index is the SLOW index (W in dy W, both operands of
+// the weight gradient dy^T x) is staged in its memory orientation [64 k][row] and read through the
+// hardware-transposing ds_read_b64_tr_b16 -- no scattered 2-byte LDS writes, no transposed copies in
+// HBM.  Row pitches are padded (144 B / 320 B) so that both kinds of read are bank-conflict free.
+// 128x128 tile, 4 waves (2x2), 64x64 per wave, BK = 64, register-staged prefetch of the next tile.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+struct GArgs {
+    const float* A; const float* B; float* C; float* preact; const float* bias; const float* residual;
+    int64_t M, N, K, lda, ldb, ldc, ldr;
+    int act, splits;
+    int64_t k_per_split;
+};
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(bf16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case 1: return gelu_f(v);
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return v / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+// KS == false: operand element (row, k) at X[row*ld + k]  -> LDS [128 rows][64 k], pitch 144 B
+// KS == true : operand element (row, k) at X[k*ld + row]  -> LDS [64 k][128 rows], pitch 320 B
+template <bool KS>
+struct Tile {
+    static constexpr int PITCH = KS ? (128 * 2 + 64) : (BK * 2 + 16);
+    static constexpr int BYTES = KS ? BK * PITCH : 128 * PITCH;
+    float4 regs[8];
+
+    __device__ __forceinline__ void load(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                         int64_t kend, bool vec_ok) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int idx = threadIdx.x + v * 256;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!KS) {
+                const int r = idx >> 4, kq = idx & 15;   // 16 float4 per row of 64 k
+                const int64_t row = row0 + r, k = k0 + 4 * kq;
+                if (row < nrows && k < kend) {
+                    const float* p = X + row * ld + k;
+                    if (vec_ok && k + 3 < kend) t = *reinterpret_cast<const float4*>(p);
+                    else {
+                        t.x = p[0];
+                        if (k + 1 < kend) t.y = p[1];
+                        if (k + 2 < kend) t.z = p[2];
+                        if (k + 3 < kend) t.w = p[3];
+                    }
+                }
+            } else {
+                const int kk = idx >> 5, rq = idx & 31;  // 32 float4 per k-row of 128
+                const int64_t k = k0 + kk, row = row0 + 4 * rq;
+                if (k < kend && row < nrows) {
+                    const float* p = X + k * ld + row;
+                    if (vec_ok && row + 3 < nrows) t = *reinterpret_cast<const float4*>(p);
+                    else {
+                        t.x = p[0];
+                        if (row + 1 < nrows) t.y = p[1];
+                        if (row + 2 < nrows) t.z = p[2];
+                        if (row + 3 < nrows) t.w = p[3];
+                    }
+                }
+            }
+            regs[v] = t;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int idx = threadIdx.x + v * 256;
+            const uint2 pk = make_uint2(pack2(regs[v].x, regs[v].y), pack2(regs[v].z, regs[v].w));
+            if (!KS) {
+                const int r = idx >> 4, kq = idx & 15;
+                *reinterpret_cast<uint2*>(lds + r * PITCH + kq * 8) = pk;
+            } else {
+                const int kk = idx >> 5, rq = idx & 31;
+                *reinterpret_cast<uint2*>(lds + kk * PITCH + rq * 8) = pk;
+            }
+        }
+    }
+    // MFMA operand fragment for tile-row block `rb` (32 rows), k-step s (16 k): element j <-> k index
+    //   KS == false: k = 16s + 8hf + j                          (ds_read_b128 along k)
+    //   KS == true : k = 16s + 8(j>>2) + 4hf + (j&3)            (two transposed 4x16 block reads)
+    // Both operands of one GEMM may use different k orders only if ... they may not: see k_gemm_bf16.
+    static __device__ __forceinline__ bf16x8 frag(const char* lds, int rb, int s, int lane) {
+        const int l31 = lane & 31, hf = lane >> 5;
+        if (!KS) {
+            return *reinterpret_cast<const bf16x8*>(lds + (rb * 32 + l31) * PITCH + (16 * s + 8 * hf) * 2);
+        } else {
+            const int i = lane & 15, grp = (lane >> 4) & 1;
+            const int col = rb * 32 + 16 * grp + 4 * (i & 3);
+            const int r0 = 16 * s + 4 * hf + (i >> 2);
+            const char* p0 = lds + r0 * PITCH + col * 2;
+            const char* p1 = p0 + 8 * PITCH;
+            const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p0));
+            const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p1));
+            bf16x8 o;
+            o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+            o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+            return o;
+        }
+    }
+    // same k order as the KS fragment, but from a k-contiguous tile: gather k = 16s+4hf+{0..3} and +8
+    static __device__ __forceinline__ bf16x8 frag_as_ks(const char* lds, int rb, int s, int lane) {
+        const int l31 = lane & 31, hf = lane >> 5;
+        const char* p = lds + (rb * 32 + l31) * PITCH + (16 * s + 4 * hf) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(p);
+        const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+        bf16x8 o;
+        o[0] = (short)(lo.x & 0xffff); o[1] = (short)(lo.x >> 16); o[2] = (short)(lo.y & 0xffff); o[3] = (short)(lo.y >> 16);
+        o[4] = (short)(hi.x & 0xffff); o[5] = (short)(hi.x >> 16); o[6] = (short)(hi.y & 0xffff); o[7] = (short)(hi.y >> 16);
+        return o;
+    }
+};
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_vec) {
+    using TA = Tile<A_KS>;
+    using TB = Tile<B_KS>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* la = lds;
+    char* lb = lds + TA::BYTES;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t bm = (int64_t)blockIdx.y * BM, bn = (int64_t)blockIdx.x * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t kend = (g.splits > 1) ? ((kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K) : g.K;
+    // the two operands must walk k in the same order inside a 16-step: if exactly one of them is k-strided
+    // (transposed reads), the k-contiguous one gathers its 8 elements in that order as well
+    constexpr bool MIXED = A_KS != B_KS;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TA ta;
+    TB tb;
+    if (kbeg < kend) {
+        ta.load(g.A, g.lda, bm, g.M, kbeg, kend, a_vec);
+        tb.load(g.B, g.ldb, bn, g.N, kbeg, kend, b_vec);
+    }
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        ta.store(la);
+        tb.store(lb);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            ta.load(g.A, g.lda, bm, g.M, k0 + BK, kend, a_vec);
+            tb.load(g.B, g.ldb, bn, g.N, k0 + BK, kend, b_vec);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (MIXED && !A_KS) af[i] = TA::frag_as_ks(la, wr * 2 + i, s, lane);
+                else af[i] = TA::frag(la, wr * 2 + i, s, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (MIXED && !B_KS) bf[j] = TB::frag_as_ks(lb, wc * 2 + j, s, lane);
+                else bf[j] = TB::frag(lb, wc * 2 + j, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = bn + (wc * 2 + j) * 32 + l31;
+            if (n >= g.N) continue;
+            const float bv = (g.splits <= 1 && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = bm + (wr * 2 + i) * 32 + mfma32_row(r, hf);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (g.splits > 1) {
+                    g.C[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                } else {
+                    v += bv;
+                    if (g.preact) g.preact[m * g.ldc + n] = v;
+                    v = act_apply(v, g.act);
+                    if (g.residual) v += g.residual[m * g.ldr + n];
+                    g.C[m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
+template <bool A_KS, bool B_KS>
+int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
+    const size_t lds = Tile<A_KS>::BYTES + Tile<B_KS>::BYTES;
+    auto kern = k_gemm_bf16<A_KS, B_KS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            gaot_set_error("gemm_bf16: cannot set dynamic LDS %zu: %s", lds, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
+    return GAOT_OK;
+}
+
+}  // namespace
+
+// called by gaot_gemm (gemm.hip) for precision == 1 when the output is wide enough for the 128x128 tile
+int gaot_gemm_bf16_dispatch(const float* A, const float* B, float* C, float* preact, const float* bias,
+                            const float* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                            int64_t ldc, int64_t ldr, int a_trans, int b_trans, int act, int splits, int64_t kps,
+                            int a_vec, int b_vec, hipStream_t st) {
+    GArgs g{A, B, C, preact, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, splits, kps};
+    const bool a_ks = a_trans != 0;   // A(m,k) = A[k*lda + m]
+    const bool b_ks = b_trans == 0;   // B(k,n) = B[k*ldb + n]
+    if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, st);
+    if (!a_ks && b_ks) return launch<false, true>(g, a_vec, b_vec, splits, st);
+    if (a_ks && !b_ks) return launch<true, false>(g, a_vec, b_vec, splits, st);
+    return launch<true, true>(g, a_vec, b_vec, splits, st);
+}

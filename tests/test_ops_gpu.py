@@ -73,6 +73,22 @@ def test_gemm_bf16_operands():
     close("gemm_bf16_vs_fp32", out, a.double() @ b.double().t(), 2e-2, 0.5)
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 200, 130), (1024, 256, 256), (256, 1024, 5000), (129, 65, 64)])
+@pytest.mark.parametrize("a_trans,b_trans", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_bf16_wide_tile(m, n, k, a_trans, b_trans):
+    """128x128x64 bf16 kernel (gemm_bf16.hip): k-contiguous operands via ds_read_b128, k-strided operands via
+    transposed LDS reads, mixed orders, split-K, edges.  Exact w.r.t. bf16-rounded operands up to fp32 summation."""
+    from gaot_3d_amd import ops
+    a = gen(k, m, seed=1) if a_trans else gen(m, k, seed=1)
+    b = gen(n, k, seed=2) if b_trans else gen(k, n, seed=2)
+    bias, res = gen(n, seed=3), gen(m, n, seed=4)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = (ar.t() if a_trans else ar) @ (br.t() if b_trans else br) + bias.double() + res.double()
+    out = ops.gemm(a.to(DEV), b.to(DEV), m, n, k, a.shape[1], b.shape[1], bool(a_trans), bool(b_trans), bias.to(DEV), 0,
+                   res.to(DEV), n, precision=1)
+    close(f"gemm_bf16_{m}x{n}x{k}_{a_trans}{b_trans}", out, ref, 1e-4, 2e-3 * max(1.0, math.sqrt(k / 256)))
+
+
 def _attn_ref(qkv, b, s, h, hkv, freqs):
     q, k, v = qkv.split([h * 32, hkv * 32, hkv * 32], dim=1)
     q = q.view(b, s, h, 32).transpose(1, 2)
