@@ -13,6 +13,10 @@
 //     chain, rounded to bf16 in registers, IS the B operand of the next chain (no LDS round trip
 //     for P / dS).
 // dQ has its own pass: no float atomics, bit-reproducible gradients.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -144,7 +148,8 @@ struct FwdArgs {
 // ------------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_attn_fwd_bf16(FwdArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -167,10 +172,58 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_bf16(FwdArgs a) {
             }
         }
     }
-    f32x16 acc;
+    f32x16 acc, negm;   // negm = -m broadcast: C operand of the score MFMA, so the tile arrives as S - m
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; negm[r] = 0.f; }
+    float m = 0.f, l = 0.f;
+
+    // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
+    // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
+    // scale (acc, l) is rescaled exactly once.
+    auto tile = [&](const char* kt, const char* vt, int64_t kb, bool first, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+        if constexpr (TAIL) {
+            const int nv = (int)(a.S - kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, sc[15]);
+        mx = fmaxf(mx, xhalf(mx));
+        if (first || __any(mx > 0.f)) {
+            const float up = first ? mx : fmaxf(mx, 0.f);     // how far this lane's max moves (log2 units)
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
+            m += up;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r] - up);
+                ps += sc[r];
+                acc[r] *= alpha;
+                negm[r] = -m;
+            }
+            ps += xhalf(ps);
+            l = l * alpha + ps;
+        } else {
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                ps += sc[r];
+            }
+            ps += xhalf(ps);
+            l += ps;
+        }
+        bf16x8 p0, p1;
+        acc_to_frags(sc, p0, p1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
+    };
 
     uint4 regs[2];
     stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
@@ -179,44 +232,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_bf16(FwdArgs a) {
         stage_store<4>(regs, lds);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t kb = k0 + 32 * t;
-            if (kb >= a.S) break;
-            const char* kt = lds + t * TILE_BYTES;
-            const char* vt = lds + (2 + t) * TILE_BYTES;
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, ks), qf[ks], s, 0, 0, 0);
-            if (kb + 32 > a.S) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb + mfma32_row(r, hf) >= a.S) s[r] = -INFINITY;
-            }
-            float mx = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, xhalf(mx));
-            const float mn = fmaxf(m, mx);
-            const float alpha = exp2f(m - mn);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - mn);
-                ps += s[r];
-            }
-            ps += xhalf(ps);
-            l = l * alpha + ps;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= alpha;
-            bf16x8 p0, p1;
-            acc_to_frags(s, p0, p1);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
+        if (k0 + 64 <= a.S) {
+            tile(lds, lds + 2 * TILE_BYTES, k0, k0 == 0, std::false_type{});
+            tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, false, std::false_type{});
+        } else {
+            tile(lds, lds + 2 * TILE_BYTES, k0, k0 == 0, std::true_type{});
+            if (k0 + 32 < a.S) tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, false, std::true_type{});
         }
     }
     const int64_t qi = q0 + l31;
@@ -246,10 +267,10 @@ struct BwdArgs {
 // ------------------------------------------------------------------------------------------------
 // dK / dV: 4 waves x 32 keys; Q / dO tiles stream through LDS; grid (ceil(S/128), HKV, B)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_bf16(BwdArgs a) {
+__global__ __launch_bounds__(256, 3) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // Q0 Q1 dO0 dO1
-    __shared__ float lse_s[64];
-    __shared__ float del_s[64];
+    __shared__ __attribute__((aligned(16))) float lse_s[64];
+    __shared__ __attribute__((aligned(16))) float del_s[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.y, b = blockIdx.z;
     const int rep = a.H / a.HKV;
@@ -306,23 +327,28 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                 if (q0 + 32 * t >= a.S) break;
                 const char* qt = lds + t * TILE_BYTES;
                 const char* dt = lds + (2 + t) * TILE_BYTES;
-                f32x16 s, dp;
+                // accumulators start at -lse[q] / -delta[q] (rows of this lane: 4 runs of 4 consecutive q)
+                f32x16 sc, dp;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 lv = *reinterpret_cast<const float4*>(&lse_s[32 * t + 8 * g4 + 4 * hf]);
+                    const float4 dv = *reinterpret_cast<const float4*>(&del_s[32 * t + 8 * g4 + 4 * hf]);
+                    sc[4 * g4] = -lv.x; sc[4 * g4 + 1] = -lv.y; sc[4 * g4 + 2] = -lv.z; sc[4 * g4 + 3] = -lv.w;
+                    dp[4 * g4] = -dv.x; dp[4 * g4 + 1] = -dv.y; dp[4 * g4 + 2] = -dv.z; dp[4 * g4 + 3] = -dv.w;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, l31, hf, ks), kf[ks], s, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, l31, hf, ks), kf[ks], sc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dt, l31, hf, ks), vf[ks], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int qr = 32 * t + mfma32_row(r, hf);
-                    const float p = exp2f(s[r] - lse_s[qr]);
-                    s[r] = p;
-                    dp[r] = p * (dp[r] - del_s[qr]);
+                    const float p = __builtin_amdgcn_exp2f(sc[r]);   // rows beyond S carry lse = +inf -> p = 0
+                    sc[r] = p;
+                    dp[r] = p * dp[r];
                 }
                 bf16x8 p0, p1, d0, d1;
-                acc_to_frags(s, p0, p1);
+                acc_to_frags(sc, p0, p1);
                 acc_to_frags(dp, d0, d1);
                 dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dt, lane, 0), p0, dvt, 0, 0, 0);
                 dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dt, lane, 1), p1, dvt, 0, 0, 0);
@@ -349,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_bf16(BwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dQ: 4 waves x 32 queries; K / V tiles stream through LDS; grid (ceil(S/128), H, B)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_bf16(BwdArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -376,9 +403,30 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_bf16(BwdArgs a) {
     }
     const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
     const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
-    f32x16 dqt;
+    // -lse[q] and -delta[q] live in two accumulator-shaped register sets and enter the MFMA chains as the C
+    // operand: the score tile arrives as S - lse and the dP tile as dP - delta, at no VALU cost per tile
+    f32x16 dqt, negl, negd;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { dqt[r] = 0.f; negl[r] = -lse2; negd[r] = -del; }
+
+    auto tile = [&](const char* kt, const char* vt, int64_t kb, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negl, 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 0), dof[0], negd, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 1), dof[1], dp, 0, 0, 0);
+        const int nv = TAIL ? (int)(a.S - kb) : 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(sc[r]);
+            if (TAIL && mfma32_row(r, hf) >= nv) p = 0.f;
+            dp[r] = p * dp[r];
+        }
+        bf16x8 d0, d1;
+        acc_to_frags(dp, d0, d1);
+        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 0), d0, dqt, 0, 0, 0);
+        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 1), d1, dqt, 0, 0, 0);
+    };
 
     uint4 regs[2];
     stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
@@ -387,30 +435,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_bf16(BwdArgs a) {
         stage_store<4>(regs, lds);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t kb = k0 + 32 * t;
-            if (kb >= a.S) break;
-            const char* kt = lds + t * TILE_BYTES;
-            const char* vt = lds + (2 + t) * TILE_BYTES;
-            f32x16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, ks), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, ks), dof[ks], dp, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = exp2f(s[r] - lse2);
-                if (kb + mfma32_row(r, hf) >= a.S) p = 0.f;
-                dp[r] = p * (dp[r] - del);
-            }
-            bf16x8 d0, d1;
-            acc_to_frags(dp, d0, d1);
-            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 0), d0, dqt, 0, 0, 0);
-            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 1), d1, dqt, 0, 0, 0);
+        if (k0 + 64 <= a.S) {
+            tile(lds, lds + 2 * TILE_BYTES, k0, std::false_type{});
+            tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, std::false_type{});
+        } else {
+            tile(lds, lds + 2 * TILE_BYTES, k0, std::true_type{});
+            if (k0 + 32 < a.S) tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, std::true_type{});
         }
     }
     if (qi < a.S) {
@@ -425,6 +455,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_bf16(BwdArgs a) {
 }
 
 }  // namespace
+
+// register budget of the fwd / dQ kernels: 2 waves/SIMD (200 VGPRs, no spill) or 3 (168 VGPRs); tuning knob
+static int attn_occ() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GAOT_ATTN_OCC");
+        v = (e && e[0] == '3') ? 3 : 2;
+    }
+    return v;
+}
 
 // fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
 extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
@@ -448,7 +488,10 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
     FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
-    hipLaunchKernelGGL(k_attn_fwd_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    if (attn_occ() == 3)
+        hipLaunchKernelGGL(k_attn_fwd_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_attn_fwd_bf16<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -472,8 +515,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                            S, H);
     if (phase_mask & 2)
         hipLaunchKernelGGL(k_attn_bwd_dkv_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
-    if (phase_mask & 4)
-        hipLaunchKernelGGL(k_attn_bwd_dq_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 4) {
+        if (attn_occ() == 3)
+            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

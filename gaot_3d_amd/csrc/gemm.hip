@@ -297,7 +297,8 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
     const int64_t tiles = ceil_div(M, bm) * ceil_div(N, bn);
     int64_t s = 1;
     if (tiles < 128 && K >= 4096) {
-        s = std::min<int64_t>(64, std::max<int64_t>(1, 512 / tiles));
+        const int64_t cap = K >= 131072 ? 256 : 64;
+        s = std::min<int64_t>(cap, std::max<int64_t>(1, 1024 / tiles));
         s = std::min<int64_t>(s, ceil_div(K, 1024));
     }
     p.kps = ceil_div(ceil_div(K, s), bk) * bk;

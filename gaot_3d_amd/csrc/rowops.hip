@@ -92,13 +92,22 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
         dw_part[(int64_t)blockIdx.x * d + i] = sm[i] + sm[d + i] + sm[2 * d + i] + sm[3 * d + i];
 }
 
-// out[n] = sum_{p<parts} part[p][n]   (fixed order)
+// out[n] = sum_{p<parts} part[p][n]; 32 columns x 8 part-lanes per block, fixed summation order
 __global__ void k_reduce_parts(const float* __restrict__ part, int64_t parts, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float sm[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + cx;
     float s = 0.f;
-    for (int64_t p = 0; p < parts; ++p) s += part[p * n + i];
-    out[i] = s;
+    if (i < n)
+        for (int64_t p = ry; p < parts; p += 8) s += part[p * n + i];
+    sm[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += sm[j][cx];
+        out[i] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,7 +362,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
                        dx, part, rows, dim);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim, 32)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -380,7 +389,7 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
                        rpc, part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N)), dim3(256), 0, st, part, chunks, N, out);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N, 32)), dim3(256), 0, st, part, chunks, N, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

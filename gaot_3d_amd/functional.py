@@ -56,7 +56,10 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dz, w, m, k, n, n, k, False, False, precision=ctx.precision).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(dz, x2, n, k, m, n, k, True, False, precision=ctx.precision).view(ctx.wshape)
+            if n == 1:   # dW[0][:] = sum_m dz[m] x[m][:] -- put the wide dimension on the tile rows instead
+                dw = ops.gemm(x2, dz, k, 1, m, k, 1, True, False, precision=ctx.precision).view(ctx.wshape)
+            else:
+                dw = ops.gemm(dz, x2, n, k, m, n, k, True, False, precision=ctx.precision).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dz, m, n, n)
         return dx, dw, db, None, None
