@@ -25,10 +25,17 @@ constexpr int D = 32;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short bf16_t;
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// max over the two lanes (l, l+32) that share an MFMA column, without going through LDS
+__device__ __forceinline__ float max_halves(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
 
 // ---- LDS tile: [32 rows][32 bf16] = 2 KB, 16-B chunk c of row r lives at chunk c ^ ((r>>2)&3) ----------
 constexpr int TILE_BYTES = 32 * 64;
@@ -180,51 +187,6 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
     // scale (acc, l) is rescaled exactly once.
-    auto tile = [&](const char* kt, const char* vt, int64_t kb, bool first, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
-        if constexpr (TAIL) {
-            const int nv = (int)(a.S - kb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
-        }
-        float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
-        mx = fmaxf(mx, sc[15]);
-        mx = fmaxf(mx, xhalf(mx));
-        if (first || __any(mx > 0.f)) {
-            const float up = first ? mx : fmaxf(mx, 0.f);     // how far this lane's max moves (log2 units)
-            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
-            m += up;
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sc[r] = __builtin_amdgcn_exp2f(sc[r] - up);
-                ps += sc[r];
-                acc[r] *= alpha;
-                negm[r] = -m;
-            }
-            ps += xhalf(ps);
-            l = l * alpha + ps;
-        } else {
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sc[r] = __builtin_amdgcn_exp2f(sc[r]);
-                ps += sc[r];
-            }
-            ps += xhalf(ps);
-            l += ps;
-        }
-        bf16x8 p0, p1;
-        acc_to_frags(sc, p0, p1);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
-    };
-
     uint4 regs[2];
     stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
@@ -232,15 +194,58 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
         stage_store<4>(regs, lds);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
-        if (k0 + 64 <= a.S) {
-            tile(lds, lds + 2 * TILE_BYTES, k0, k0 == 0, std::false_type{});
-            tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, false, std::false_type{});
-        } else {
-            tile(lds, lds + 2 * TILE_BYTES, k0, k0 == 0, std::true_type{});
-            if (k0 + 32 < a.S) tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, false, std::true_type{});
+        // one 32-key tile at a time.  Fast path (no running max grows): p = exp2(S - m) needs no subtraction and
+        // the O accumulator is not rescaled; otherwise everything at the old scale (acc, l, this tile) is rescaled
+        // exactly once, in place.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t kb = k0 + 32 * t;
+            if (kb >= a.S) break;
+            const char* kt = lds + t * TILE_BYTES;
+            const char* vt = lds + (2 + t) * TILE_BYTES;
+            const bool first = (kb == 0);
+            f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+            if (kb + 32 > a.S) {   // wave-uniform: only the last tile of the sequence
+                const int nv = (int)(a.S - kb);
+    #pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+    #pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+            mx = fmaxf(mx, sc[15]);
+            mx = max_halves(mx);
+            if (first || __any(mx > 0.f)) {
+                // some row's running max moves: rescale everything that is at the old scale, in place
+                const float up = first ? mx : fmaxf(mx, 0.f);     // how far this lane's max moves (log2 units)
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
+                m += up;
+                l *= alpha;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[r] -= up;
+                    acc[r] *= alpha;
+                    negm[r] = -m;
+                }
+            }
+            f32x2 ps2 = {0.f, 0.f};
+    #pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                sc[r + 1] = __builtin_amdgcn_exp2f(sc[r + 1]);
+                ps2 += (f32x2){sc[r], sc[r + 1]};
+            }
+            l += ps2[0] + ps2[1];   // per-half partial; the halves are added once, after the key loop
+            bf16x8 p0, p1;
+            acc_to_frags(sc, p0, p1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
         }
     }
     const int64_t qi = q0 + l31;
+    l += xhalf(l);
     if (qi < a.S) {
         const float inv = 1.f / l;
         float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, 0, a.S);
         float lt = 0.f, et = 0.f;
         if (threadIdx.x < 64) {
-            lt = (threadIdx.x < a.S) ? lsep[threadIdx.x] * LOG2E : INFINITY;
-            et = (threadIdx.x < a.S) ? delp[threadIdx.x] : 0.f;
+            lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;   // staged NEGATED: they are the
+            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] : 0.f;                  // initial accumulator values
         }
         for (int64_t q0 = 0; q0 < a.S; q0 += 64) {
             __syncthreads();
@@ -318,8 +323,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                 stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + 64, a.S);
                 if (threadIdx.x < 64) {
                     const int64_t qq = q0 + 64 + threadIdx.x;
-                    lt = (qq < a.S) ? lsep[qq] * LOG2E : INFINITY;
-                    et = (qq < a.S) ? delp[qq] : 0.f;
+                    lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
+                    et = (qq < a.S) ? -delp[qq] : 0.f;
                 }
             }
 #pragma unroll
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const float4 lv = *reinterpret_cast<const float4*>(&lse_s[32 * t + 8 * g4 + 4 * hf]);
                     const float4 dv = *reinterpret_cast<const float4*>(&del_s[32 * t + 8 * g4 + 4 * hf]);
-                    sc[4 * g4] = -lv.x; sc[4 * g4 + 1] = -lv.y; sc[4 * g4 + 2] = -lv.z; sc[4 * g4 + 3] = -lv.w;
-                    dp[4 * g4] = -dv.x; dp[4 * g4 + 1] = -dv.y; dp[4 * g4 + 2] = -dv.z; dp[4 * g4 + 3] = -dv.w;
+                    sc[4 * g4] = lv.x; sc[4 * g4 + 1] = lv.y; sc[4 * g4 + 2] = lv.z; sc[4 * g4 + 3] = lv.w;
+                    dp[4 * g4] = dv.x; dp[4 * g4 + 1] = dv.y; dp[4 * g4 + 2] = dv.z; dp[4 * g4 + 3] = dv.w;
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -409,25 +414,6 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dqt[r] = 0.f; negl[r] = -lse2; negd[r] = -del; }
 
-    auto tile = [&](const char* kt, const char* vt, int64_t kb, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negl, 0, 0, 0);
-        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 0), dof[0], negd, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 1), dof[1], dp, 0, 0, 0);
-        const int nv = TAIL ? (int)(a.S - kb) : 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = __builtin_amdgcn_exp2f(sc[r]);
-            if (TAIL && mfma32_row(r, hf) >= nv) p = 0.f;
-            dp[r] = p * dp[r];
-        }
-        bf16x8 d0, d1;
-        acc_to_frags(dp, d0, d1);
-        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 0), d0, dqt, 0, 0, 0);
-        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 1), d1, dqt, 0, 0, 0);
-    };
-
     uint4 regs[2];
     stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
@@ -435,12 +421,28 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
         stage_store<4>(regs, lds);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
-        if (k0 + 64 <= a.S) {
-            tile(lds, lds + 2 * TILE_BYTES, k0, std::false_type{});
-            tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, std::false_type{});
-        } else {
-            tile(lds, lds + 2 * TILE_BYTES, k0, std::true_type{});
-            if (k0 + 32 < a.S) tile(lds + TILE_BYTES, lds + 3 * TILE_BYTES, k0 + 32, std::true_type{});
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t kb = k0 + 32 * t;
+            if (kb >= a.S) break;
+            const char* kt = lds + t * TILE_BYTES;
+            const char* vt = lds + (2 + t) * TILE_BYTES;
+            f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negl, 0, 0, 0);
+            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 0), dof[0], negd, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vt, l31, hf, 1), dof[1], dp, 0, 0, 0);
+            if (kb + 32 > a.S) {   // wave-uniform: last tile only
+                const int nv = (int)(a.S - kb);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(sc[r]) * dp[r];
+            bf16x8 d0, d1;
+            acc_to_frags(dp, d0, d1);
+            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 0), d0, dqt, 0, 0, 0);
+            dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kt, lane, 1), d1, dqt, 0, 0, 0);
         }
     }
     if (qi < a.S) {

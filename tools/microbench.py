@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmarks at the configs[1] shapes (for rocprofv3 / quick A-B): attention fwd+bwd, GEMM shapes, GNO."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gaot_3d_amd
+from gaot_3d_amd import ops, functional as GF
+
+what = sys.argv[1] if len(sys.argv) > 1 else "attn"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = "cuda:0"
+gaot_3d_amd.set_precision(os.environ.get("GAOT_PRECISION", "bf16"))
+torch.manual_seed(0)
+
+
+def timeit(fn, name, flops=None):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"{name}: {dt*1e3:.3f} ms" + (f"  {flops/dt/1e12:.1f} TF/s" if flops else ""))
+
+
+if what == "attn":
+    b, s, h = 1, 16384, 8
+    qkv = torch.randn(b * s, 3 * h * 32, device=dev)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+    d_o = torch.randn(b * s, h * 32, device=dev)
+    att = 2 * s * s * 32 * h
+    if ops.get_precision() == "bf16":
+        o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5)
+        timeit(lambda: ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5), "attn_fwd_bf16(+prep)", 2 * att)
+        timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5), "attn_bwd_bf16(all)", 4 * att)
+    else:
+        o, lse = ops.attn_fwd(qkv, b, s, h, h, 32 ** -0.5)
+        timeit(lambda: ops.attn_fwd(qkv, b, s, h, h, 32 ** -0.5), "attn_fwd_f32", 2 * att)
+        timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, b, s, h, h, 32 ** -0.5), "attn_bwd_f32", 4 * att)
+elif what == "gemm":
+    m = 16384
+    for (n, k) in ((256, 256), (1024, 256), (256, 1024), (256, 512)):
+        x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); dy = torch.randn(m, n, device=dev)
+        fl = 2 * m * n * k
+        timeit(lambda: ops.gemm(x, w, m, n, k, k, k, False, True), f"fwd  x[{m},{k}] W[{n},{k}]^T", fl)
+        timeit(lambda: ops.gemm(dy, w, m, k, n, n, k, False, False), f"dx   dy[{m},{n}] W[{n},{k}]", fl)
+        timeit(lambda: ops.gemm(dy, x, n, k, m, n, k, True, False), f"dW   dy^T[{n},{m}] x[{m},{k}]", fl)
+elif what == "gno":
+    from gaot_3d_amd.data import make_synthetic_sample
+    batch, tokens = make_synthetic_sample(500000, (64, 64, 32), k=8, seed=0, device=dev)
+    n, m = 500000, tokens.shape[0]
+    tokens = tokens.to(dev)
+    for nh, ei, ns, nd, yp, xp in ((3, batch.encoder_edge_index_s0, n, m, batch.pos, tokens),
+                                   (2, batch.decoder_edge_index_s0, m, n, tokens, batch.pos)):
+        ws = [torch.randn(64, 6, device=dev) * 0.3] + [torch.randn(64, 64, device=dev) * 0.1 for _ in range(nh - 1)] + [torch.randn(32, 64, device=dev) * 0.1]
+        bs = [torch.zeros(w.shape[0], device=dev) for w in ws]
+        timeit(lambda: ops.build_graph(ei, ns, nd), f"csr x2 (E={ei.shape[1]})")
+        g = ops.build_graph(ei, ns, nd)
+        f = torch.randn(ns, 32, device=dev); go = torch.randn(nd, 32, device=dev)
+        e = ei.shape[1]
+        fl = e * (21280 if nh == 3 else 13088)
+        timeit(lambda: ops.gno_forward(ws, bs, yp, xp, f, g), f"gno_fwd nh={nh}", fl)
+        timeit(lambda: ops.gno_backward(ws, bs, yp, xp, f, go, g), f"gno_bwd nh={nh}", 3 * fl)
