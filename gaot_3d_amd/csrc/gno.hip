@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd(MlpPtrs mlp, const float* __
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h[t][ob][r] = gelu_f(h[t][ob][r]);
+                for (int r = 0; r < 16; ++r) h[t][ob][r] = gelu_fast(h[t][ob][r]);
         }
         // ---- hidden layers H -> H ----------------------------------------------------------------
 #pragma unroll
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd(MlpPtrs mlp, const float* __
 #pragma unroll
                 for (int ob = 0; ob < KB; ++ob)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) h[t][ob][r] = gelu_f(hn[t][ob][r]);
+                    for (int r = 0; r < 16; ++r) h[t][ob][r] = gelu_fast(hn[t][ob][r]);
         }
         // ---- last layer, transposed: K'[e][c] = sum_k Hlast[k][e] * WL[c][k] + bL[c] ---------------
         wave_lds_fence();  // ids visible to the whole wave
@@ -431,8 +431,10 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd(
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                gp[0][ob][r] = gelu_grad_f(z[r]);
-                h[ob][r] = gelu_f(z[r]);
+                float gv, dv;
+                gelu_fast_pair(z[r], gv, dv);
+                h[ob][r] = gv;
+                gp[0][ob][r] = dv;
                 hst[(0 * 32 + l31) * LDH + 32 * ob + mfma32_row(r, hf)] = h[ob][r];
             }
         }
@@ -459,8 +461,10 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd(
             for (int ob = 0; ob < KB; ++ob)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    gp[l][ob][r] = gelu_grad_f(z[ob][r]);
-                    h[ob][r] = gelu_f(z[ob][r]);
+                    float gv, dv;
+                    gelu_fast_pair(z[ob][r], gv, dv);
+                    h[ob][r] = gv;
+                    gp[l][ob][r] = dv;
                     hst[(l * 32 + l31) * LDH + 32 * ob + mfma32_row(r, hf)] = h[ob][r];
                 }
         });
