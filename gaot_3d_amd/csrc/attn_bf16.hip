@@ -272,7 +272,8 @@ struct BwdArgs {
 // ------------------------------------------------------------------------------------------------
 // dK / dV: 4 waves x 32 keys; Q / dO tiles stream through LDS; grid (ceil(S/128), HKV, B)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void k_attn_bwd_dkv_bf16(BwdArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // Q0 Q1 dO0 dO1
     __shared__ __attribute__((aligned(16))) float lse_s[64];
     __shared__ __attribute__((aligned(16))) float del_s[64];
@@ -468,6 +469,15 @@ static int attn_occ() {
     return v;
 }
 
+static int dkv_occ() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GAOT_DKV_OCC");
+        v = (e && e[0] == '4') ? 4 : 3;
+    }
+    return v;
+}
+
 // fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
 extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
     return sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64;
@@ -515,8 +525,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 1)
         hipLaunchKernelGGL(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
                            S, H);
-    if (phase_mask & 2)
-        hipLaunchKernelGGL(k_attn_bwd_dkv_bf16, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 2) {
+        if (dkv_occ() == 4)
+            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+    }
     if (phase_mask & 4) {
         if (attn_occ() == 3)
             hipLaunchKernelGGL(k_attn_bwd_dq_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
