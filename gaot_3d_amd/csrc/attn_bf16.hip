@@ -473,7 +473,7 @@ static int dkv_occ() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GAOT_DKV_OCC");
-        v = (e && e[0] == '4') ? 4 : 3;
+        v = (e && e[0] == '3') ? 3 : 4;
     }
     return v;
 }

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;   // BM is a template parameter: 128, or 64 when the grid would under-fill the chip
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
@@ -39,16 +39,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 // KS == false: operand element (row, k) at X[row*ld + k]  -> LDS [128 rows][64 k], pitch 144 B
 // KS == true : operand element (row, k) at X[k*ld + row]  -> LDS [64 k][128 rows], pitch 320 B
-template <bool KS>
+template <bool KS, int ROWS>
 struct Tile {
-    static constexpr int PITCH = KS ? (128 * 2 + 64) : (BK * 2 + 16);
-    static constexpr int BYTES = KS ? BK * PITCH : 128 * PITCH;
-    float4 regs[8];
+    static constexpr int PITCH = KS ? (ROWS * 2 + 64) : (BK * 2 + 16);
+    static constexpr int BYTES = KS ? BK * PITCH : ROWS * PITCH;
+    static constexpr int NV = ROWS / 16;   // float4 per thread per tile
+    float4 regs[NV];
 
     __device__ __forceinline__ void load(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                          int64_t kend, bool vec_ok) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int idx = threadIdx.x + v * 256;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!KS) {
@@ -65,7 +66,7 @@ struct Tile {
                     }
                 }
             } else {
-                const int kk = idx >> 5, rq = idx & 31;  // 32 float4 per k-row of 128
+                const int kk = idx / (ROWS / 4), rq = idx % (ROWS / 4);  // ROWS/4 float4 per k-row
                 const int64_t k = k0 + kk, row = row0 + 4 * rq;
                 if (k < kend && row < nrows) {
                     const float* p = X + k * ld + row;
@@ -83,14 +84,14 @@ struct Tile {
     }
     __device__ __forceinline__ void store(char* lds) const {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int idx = threadIdx.x + v * 256;
             const uint2 pk = make_uint2(pack2(regs[v].x, regs[v].y), pack2(regs[v].z, regs[v].w));
             if (!KS) {
                 const int r = idx >> 4, kq = idx & 15;
                 *reinterpret_cast<uint2*>(lds + r * PITCH + kq * 8) = pk;
             } else {
-                const int kk = idx >> 5, rq = idx & 31;
+                const int kk = idx / (ROWS / 4), rq = idx % (ROWS / 4);
                 *reinterpret_cast<uint2*>(lds + kk * PITCH + rq * 8) = pk;
             }
         }
@@ -130,10 +131,11 @@ struct Tile {
     }
 };
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, int BM>
 __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_vec) {
-    using TA = Tile<A_KS>;
-    using TB = Tile<B_KS>;
+    using TA = Tile<A_KS, BM>;
+    using TB = Tile<B_KS, BN>;
+    constexpr int MT = BM / 64;   // 32-row MFMA tiles per wave along M (waves are 2 x 2)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* la = lds;
     char* lb = lds + TA::BYTES;
@@ -146,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
     // (transposed reads), the k-contiguous one gathers its 8 elements in that order as well
     constexpr bool MIXED = A_KS != B_KS;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -170,11 +172,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
         }
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 af[2], bf[2];
+            bf16x8 af[MT], bf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if constexpr (MIXED && !A_KS) af[i] = TA::frag_as_ks(la, wr * 2 + i, s, lane);
-                else af[i] = TA::frag(la, wr * 2 + i, s, lane);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (MIXED && !A_KS) af[i] = TA::frag_as_ks(la, wr * MT + i, s, lane);
+                else af[i] = TA::frag(la, wr * MT + i, s, lane);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
                 else bf[j] = TB::frag(lb, wc * 2 + j, s, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int64_t n = bn + (wc * 2 + j) * 32 + l31;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
             const float bv = (g.splits <= 1 && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = bm + (wr * 2 + i) * 32 + mfma32_row(r, hf);
+                const int64_t m = bm + (wr * MT + i) * 32 + mfma32_row(r, hf);
                 if (m >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.splits > 1) {
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
         }
 }
 
-template <bool A_KS, bool B_KS>
-int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
-    const size_t lds = Tile<A_KS>::BYTES + Tile<B_KS>::BYTES;
-    auto kern = k_gemm_bf16<A_KS, B_KS>;
+template <bool A_KS, bool B_KS, int BM>
+int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
+    const size_t lds = Tile<A_KS, BM>::BYTES + Tile<B_KS, BN>::BYTES;
+    auto kern = k_gemm_bf16<A_KS, B_KS, BM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -231,6 +233,14 @@ int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
     return GAOT_OK;
+}
+
+template <bool A_KS, bool B_KS>
+int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
+    // fewer than two 128x128 workgroups per CU: halve the tile height so that twice as many workgroups hide latency
+    const int64_t blocks128 = ceil_div(g.N, BN) * ceil_div(g.M, 128) * splits;
+    if (blocks128 < 512 && g.M > 64) return launch_bm<A_KS, B_KS, 64>(g, a_vec, b_vec, splits, st);
+    return launch_bm<A_KS, B_KS, 128>(g, a_vec, b_vec, splits, st);
 }
 
 }  // namespace

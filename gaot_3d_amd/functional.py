@@ -22,10 +22,12 @@ def _w2d(w: Tensor) -> Tensor:
 
 
 class LinearFn(Function):
-    """y = act(x W^T + b).  Stands in for nn.Linear (+ F.gelu / ReLU) and its autograd."""
+    """y = act(x W^T + b) [+ residual].  Stands in for nn.Linear (+ F.gelu / ReLU, + the residual add that follows
+    it in the Transformer block) and its autograd."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int, precision: Optional[int]):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int, precision: Optional[int],
+                residual: Optional[Tensor]):
         w = _w2d(weight)
         n, k = w.shape
         if x.shape[-1] != k:
@@ -34,13 +36,20 @@ class LinearFn(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         m = x2.shape[0]
+        res = None
+        if residual is not None:
+            res = residual.reshape(m, n)
+            if not res.is_contiguous():
+                res = res.contiguous()
         if act:
-            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, act, want_preact=True, precision=precision)
+            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, act, residual=res, ldr=n, want_preact=True,
+                            precision=precision)
         else:
-            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, 0, precision=precision), None
+            y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, 0, residual=res, ldr=n, precision=precision), None
         ctx.save_for_backward(x2, w, z)
         ctx.act, ctx.has_bias, ctx.precision = act, bias is not None, precision
         ctx.wshape, ctx.xshape = weight.shape, x.shape
+        ctx.res_shape = residual.shape if residual is not None else None
         return y.view(*x.shape[:-1], n)
 
     @staticmethod
@@ -52,7 +61,7 @@ class LinearFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dz = ops.act_bwd(z, dy2, ctx.act) if ctx.act else dy2
-        dx = dw = db = None
+        dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dz, w, m, k, n, n, k, False, False, precision=ctx.precision).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
@@ -62,11 +71,13 @@ class LinearFn(Function):
                 dw = ops.gemm(dz, x2, n, k, m, n, k, True, False, precision=ctx.precision).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dz, m, n, n)
-        return dx, dw, db, None, None
+        if ctx.res_shape is not None and ctx.needs_input_grad[5]:
+            dres = dy2.view(ctx.res_shape)
+        return dx, dw, db, None, None, dres
 
 
-def linear(x, weight, bias=None, act: Optional[str] = None, precision: Optional[int] = None):
-    return LinearFn.apply(x, weight, bias, ops.ACT[act], precision)
+def linear(x, weight, bias=None, act: Optional[str] = None, precision: Optional[int] = None, residual=None):
+    return LinearFn.apply(x, weight, bias, ops.ACT[act], precision, residual)
 
 
 class GnoFn(Function):

@@ -84,7 +84,9 @@ class GroupQueryFlashAttention(nn.Module):
         if positional_embedding == "rope":
             self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
 
-    def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
+    def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None):
+        """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`)."""
         if self.training and self.atten_dropout > 0.0:
             raise NotImplementedError("attention dropout > 0 in training mode is not implemented on the HIP path; "
                                       "set atten_dropout=0.0 (reference default 0.1, attn.py:22) or call .eval()")
@@ -92,7 +94,7 @@ class GroupQueryFlashAttention(nn.Module):
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
         o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads)
-        y = GF.linear(o, self.o_proj.weight, None)
+        y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
 
     @classmethod
@@ -112,11 +114,13 @@ class FFN(nn.Module):
         self.correction = None
         self.hidden = hidden_size
 
-    def forward(self, x, condition: Optional[float] = None):
+    def forward(self, x, condition: Optional[float] = None, residual: Optional[torch.Tensor] = None):
+        """``residual`` (extension): added inside the w2 GEMM epilogue (the block's `h + ffn(h)`)."""
         shp = x.shape
         ag = GF.multi_linear(x, [self.w1.weight, self.w3.weight])   # [rows, 2F] = [w1 x | w3 x]
         u = GF.SwiGLUFn.apply(ag, self.hidden)
-        return GF.linear(u, self.w2.weight, None).view(*shp[:-1], -1)
+        res = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        return GF.linear(u, self.w2.weight, None, residual=res).view(*shp[:-1], -1)
 
     @classmethod
     def from_config(cls, input_size: int, output_size: int, config: FFNConfig):
@@ -155,10 +159,10 @@ class TransformerBlock(nn.Module):
             x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
                               self.skip_proj.bias).view(b, s, -1)
         h = x if self.attn_norm is None else self.attn_norm(x)
-        h = GF.add(x, self.attn(h, condition=condition, relative_positions=relative_positions))
+        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(norm(x))
         h = h if self.ffn_norm is None else self.ffn_norm(h)
         # NB: the second residual adds the *normalised* h (reference attn.py:226-229)
-        return GF.add(h, self.ffn(h, condition=condition))
+        return self.ffn(h, condition=condition, residual=h)                                          # h + ffn(h)
 
     @classmethod
     def from_config(cls, input_size: int, output_size: int, skip_connection: bool = False,
