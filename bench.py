@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--precision", type=str, default=os.environ.get("GAOT_PRECISION", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="also use the hipGraph replay for N>1 (default: N=1 only)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -121,7 +122,7 @@ def main():
     cfg = model_config(latent, args.layers, args.knn)
     torch.manual_seed(args.seed)
     model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
-    use_graph = not args.no_graph
+    use_graph = (not args.no_graph) and (world == 1 or args.graph)
     opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5, capturable=use_graph)
 
     batch, tokens = make_synthetic_sample(args.points, latent, k=args.knn, seed=args.seed, device=str(dev))

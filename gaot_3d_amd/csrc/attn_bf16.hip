@@ -86,6 +86,31 @@ __device__ __forceinline__ void stage_load4(uint4 (&regs)[2], const bf16_t* pa, 
         regs[it] = val;
     }
 }
+// TPM tiles per matrix (A tiles first, then B tiles); 128 16-B chunks per tile
+template <int TPM>
+__device__ __forceinline__ void stage_loadN(uint4 (&regs)[TPM], const bf16_t* pa, int64_t lda, const bf16_t* pb, int64_t ldb,
+                                            int64_t row0, int64_t nrows) {
+#pragma unroll
+    for (int it = 0; it < TPM; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int t = idx >> 7, r = (idx & 127) >> 2, c = idx & 3;
+        const int64_t row = row0 + 32 * (t % TPM) + r;
+        const bf16_t* base = (t < TPM) ? pa : pb;
+        const int64_t ld = (t < TPM) ? lda : ldb;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row < nrows) val = *reinterpret_cast<const uint4*>(base + row * ld + 8 * c);
+        regs[it] = val;
+    }
+}
+template <int TPM>
+__device__ __forceinline__ void stage_storeN(const uint4 (&regs)[TPM], char* lds) {
+#pragma unroll
+    for (int it = 0; it < TPM; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int t = idx >> 7, r = (idx & 127) >> 2, c = idx & 3;
+        *reinterpret_cast<uint4*>(lds + t * TILE_BYTES + tile_off(r, c)) = regs[it];
+    }
+}
 template <int NT>
 __device__ __forceinline__ void stage_store(const uint4 (&regs)[(NT * 128 + 255) / 256], char* lds) {
 #pragma unroll
@@ -155,9 +180,9 @@ struct FwdArgs {
 // ------------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
 // ------------------------------------------------------------------------------------------------
-template <int OCC>
+template <int OCC, int TPM>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int hkv = head / (a.H / a.HKV);
@@ -187,22 +212,19 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
     // scale (acc, l) is rescaled exactly once.
-    uint4 regs[2];
-    stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
-    for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
+    uint4 regs[TPM];
+    stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, 0, a.S);
+    for (int64_t k0 = 0; k0 < a.S; k0 += 32 * TPM) {
         __syncthreads();
-        stage_store<4>(regs, lds);
+        stage_storeN<TPM>(regs, lds);
         __syncthreads();
-        if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
+        if (k0 + 32 * TPM < a.S) stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, k0 + 32 * TPM, a.S);
         // one 32-key tile at a time.  Fast path (no running max grows): p = exp2(S - m) needs no subtraction and
         // the O accumulator is not rescaled; otherwise everything at the old scale (acc, l, this tile) is rescaled
         // exactly once, in place.
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int64_t kb = k0 + 32 * t;
-            if (kb >= a.S) break;
+        auto do_tile = [&](int t, int64_t kb) {
             const char* kt = lds + t * TILE_BYTES;
-            const char* vt = lds + (2 + t) * TILE_BYTES;
+            const char* vt = lds + (TPM + t) * TILE_BYTES;
             const bool first = (kb == 0);
             f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
@@ -242,6 +264,21 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
             acc_to_frags(sc, p0, p1);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
+        };
+        if constexpr (OCC >= 5) {   // rolled: fewer live registers, one more wave per SIMD
+#pragma unroll 1
+            for (int t = 0; t < TPM; ++t) {
+                const int64_t kb = k0 + 32 * t;
+                if (kb >= a.S) break;
+                do_tile(t, kb);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPM; ++t) {
+                const int64_t kb = k0 + 32 * t;
+                if (kb >= a.S) break;
+                do_tile(t, kb);
+            }
         }
     }
     const int64_t qi = q0 + l31;
@@ -328,7 +365,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                     et = (qq < a.S) ? -delp[qq] : 0.f;
                 }
             }
-#pragma unroll
+#pragma unroll 1
             for (int t = 0; t < 2; ++t) {
                 if (q0 + 32 * t >= a.S) break;
                 const char* qt = lds + t * TILE_BYTES;
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
         stage_store<4>(regs, lds);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
-#pragma unroll
+#pragma unroll 1
         for (int t = 0; t < 2; ++t) {
             const int64_t kb = k0 + 32 * t;
             if (kb >= a.S) break;
@@ -459,12 +496,12 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
 
 }  // namespace
 
-// register budget of the fwd / dQ kernels: 2 waves/SIMD (200 VGPRs, no spill) or 3 (168 VGPRs); tuning knob
+// forward kernel variant: 5 waves/SIMD (rolled tile loop, 96 VGPRs) or 4 (unrolled); tuning knob GAOT_ATTN_OCC
 static int attn_occ() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GAOT_ATTN_OCC");
-        v = (e && e[0] == '3') ? 3 : 2;
+        v = e ? atoi(e) : 4;
     }
     return v;
 }
@@ -500,10 +537,12 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
     FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
-    if (attn_occ() == 3)
-        hipLaunchKernelGGL(k_attn_fwd_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_attn_fwd_bf16<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    const dim3 fgrid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
+    switch (attn_occ()) {
+        case 5: hipLaunchKernelGGL((k_attn_fwd_bf16<5, 2>), fgrid, dim3(256), 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_fwd_bf16<4, 4>), fgrid, dim3(256), 0, st, a); break;   // 128-key stages
+        default: hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2>), fgrid, dim3(256), 0, st, a); break;
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -532,10 +571,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
     }
     if (phase_mask & 4) {
-        if (attn_occ() == 3)
-            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<2>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
