@@ -261,6 +261,19 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd(MlpPtrs mlp, const float* __
 // =================================================================================================
 // Backward
 // =================================================================================================
+// gs[q][:] = grad_out[q][:] / deg(q): folds the mean's 1/deg into ONE streaming pass instead of two rowptr loads
+// and a divide per edge inside the backward kernel
+__global__ void k_scale_by_inv_deg(const float* __restrict__ gout, const int* __restrict__ rowptr, int64_t Q,
+                                   float* __restrict__ gs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index, 8 per row
+    if (i >= Q * 8) return;
+    const int64_t q = i >> 3;
+    const int deg = rowptr[q + 1] - rowptr[q];
+    const float inv = deg > 0 ? 1.0f / (float)deg : 0.f;
+    float4 v = reinterpret_cast<const float4*>(gout)[i];
+    reinterpret_cast<float4*>(gs)[i] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
 // transpose the MLP weights into [in][out] (global workspace) for the recompute chain
 __global__ void k_transpose_w(const float* __restrict__ w, int out_dim, int in_dim, float* __restrict__ wt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,8 +346,8 @@ __device__ __forceinline__ void load_wgroup(float (&w)[16], const WRsrc& rs, int
 template <int NH, int H>
 __global__ __launch_bounds__(256, 1) void k_gno_bwd(
     MlpPtrs mlp, MlpPtrs mlp_t /* w = transposed copies [in][out] */, const float* __restrict__ y_pos,
-    const float* __restrict__ x_pos, const float* __restrict__ f_y, const float* __restrict__ gout,
-    const int* __restrict__ rowptr_dst, const int* __restrict__ src_s, const int* __restrict__ dst_s,
+    const float* __restrict__ x_pos, const float* __restrict__ f_y, const float* __restrict__ gs /* grad_out / deg */,
+    const int* __restrict__ src_s, const int* __restrict__ dst_s,
     const int* __restrict__ rowptr_src, int64_t E, float* __restrict__ grad_f, float* __restrict__ part,
     float* __restrict__ wpart /* [n_blocks][ParamLayout::total] */) {
     // One workgroup = 4 waves = 4 tiles of 32 source-sorted edges per iteration.  Each wave runs the
@@ -468,6 +481,17 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd(
                     hst[(l * 32 + l31) * LDH + 32 * ob + mfma32_row(r, hf)] = h[ob][r];
                 }
         });
+        // ---- gather f[src] and g[dst] rows now: their latency hides under the last layer's MFMA chain ---------
+        wave_lds_fence();
+        float fv[16], gv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int el = mfma32_row(r, hf);
+            const int s_ = ids[el], q_ = ids[32 + el];
+            const bool ok = q_ >= 0;
+            gv[r] = ok ? gs[(int64_t)q_ * C + l31] : 0.f;
+            fv[r] = ok ? f_y[(int64_t)s_ * C + l31] : 0.f;
+        }
         // ---- last layer transposed: K'[e][c] -------------------------------------------------------
         f32x16 kp;
         {
@@ -486,21 +510,13 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd(
             for (int r = 0; r < 16; ++r)
                 kp = __builtin_amdgcn_mfma_f32_32x32x2f32(h[kb][r], (G % 2 == 0) ? wA[r] : wB[r], kp, 0, 0, 0);
         });
-        wave_lds_fence();
-        // ---- per edge: g = grad_out[dst]/deg ; m' = g*k' (-> grad_f) ; dk' = g*f --------------------
+        // ---- per edge: g = grad_out[dst]/deg (pre-scaled) ; m' = g*k' (-> grad_f) ; dk' = g*f --------------
         f32x16 dkp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int el = mfma32_row(r, hf);
-            const int s = ids[el], q = ids[32 + el];
-            float g = 0.f, fv = 0.f;
-            if (q >= 0) {
-                const int deg = rowptr_dst[q + 1] - rowptr_dst[q];
-                g = gout[(int64_t)q * C + l31] / (float)deg;
-                fv = f_y[(int64_t)s * C + l31];
-            }
-            buf[el * LDH + l31] = g * kp[r];
-            dkp[r] = g * fv;
+            buf[el * LDH + l31] = gv[r] * kp[r];
+            dkp[r] = gv[r] * fv[r];
         }
         wave_lds_fence();
         if (hf == 0) segment_walk<C>(buf, LDH, ids, l31, base, rowptr_src, grad_f, part, false);
@@ -709,7 +725,7 @@ int launch_fwd(const MlpPtrs& p, const float* y_pos, const float* x_pos, const f
 
 template <int NH, int H>
 int launch_bwd(const MlpPtrs& p, const MlpPtrs& pt, const float* y_pos, const float* x_pos, const float* f_y,
-               const float* gout, const int* rowptr_dst, const int* src_s, const int* dst_s, const int* rowptr_src,
+               const float* gs, const int* src_s, const int* dst_s, const int* rowptr_src,
                int64_t E, float* grad_f, float* part, float* wpart, int grid, hipStream_t st) {
     const size_t lds = bwd_lds_bytes(NH, H);
     auto kern = k_gno_bwd<NH, H>;
@@ -718,7 +734,7 @@ int launch_bwd(const MlpPtrs& p, const MlpPtrs& pt, const float* y_pos, const fl
         gaot_set_error("gno_bwd: cannot set dynamic LDS %zu: %s", lds, hipGetErrorString(e));
         return GAOT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, pt, y_pos, x_pos, f_y, gout, rowptr_dst, src_s, dst_s,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, pt, y_pos, x_pos, f_y, gs, src_s, dst_s,
                        rowptr_src, E, grad_f, part, wpart);
     return GAOT_OK;
 }
@@ -780,14 +796,15 @@ extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     return GAOT_OK;
 }
 
-extern "C" size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp, int64_t num_edges) {
+extern "C" size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp, int64_t num_edges, int64_t num_queries) {
     if (!mlp) return 0;
     const int total = param_total(mlp->n_hidden, mlp->hidden);
     const int grid = bwd_grid(num_edges);
     size_t fl = (size_t)(ceil_div(num_edges, 32) * 2 * 32)  // segment partials
                 + (size_t)total                             // transposed weights (<= total)
                 + (size_t)total                             // reduced flat gradient
-                + (size_t)grid * total;                     // per-block partials
+                + (size_t)grid * total                      // per-block partials
+                + (size_t)num_queries * 32;                 // grad_out / deg
     return sizeof(float) * fl + 256;
 }
 
@@ -804,7 +821,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         return GAOT_ERR_UNSUPPORTED;
     }
     GAOT_CHECK_ARG(num_edges >= 0 && num_sources >= 0 && num_queries >= 0, "negative size");
-    GAOT_CHECK_ARG(workspace_bytes >= gaot_gno_bwd_workspace_bytes(mlp, num_edges), "workspace too small");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_gno_bwd_workspace_bytes(mlp, num_edges, num_queries), "workspace too small");
     GAOT_CHECK_ARG(rowptr_src && rowptr_dst, "null rowptr");
     hipStream_t st = (hipStream_t)stream;
     const int nh = mlp->n_hidden, h = mlp->hidden;
@@ -815,6 +832,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     float* wt = part + ceil_div(num_edges, 32) * 2 * 32;
     float* flat = wt + total;
     float* wpart = flat + total;
+    float* gs = wpart + (size_t)grid * total;
 
     MlpPtrs p, pt;
     int off = 0;
@@ -851,11 +869,13 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         hipMemsetAsync(flat, 0, sizeof(float) * total, st);
     } else {
         GAOT_CHECK_ARG(y_pos && x_pos && f_y && grad_out && src_sorted && dst_sorted && grad_f_y, "null pointer");
+        hipLaunchKernelGGL(k_scale_by_inv_deg, dim3((unsigned)ceil_div(num_queries * 8, 256)), dim3(256), 0, st, grad_out,
+                           rowptr_dst, num_queries, gs);
         int rc = GAOT_OK;
         switch (nh) {
-            case 1: rc = launch_bwd<1, 64>(p, pt, y_pos, x_pos, f_y, grad_out, rowptr_dst, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
-            case 2: rc = launch_bwd<2, 64>(p, pt, y_pos, x_pos, f_y, grad_out, rowptr_dst, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
-            case 3: rc = launch_bwd<3, 64>(p, pt, y_pos, x_pos, f_y, grad_out, rowptr_dst, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
+            case 1: rc = launch_bwd<1, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
+            case 2: rc = launch_bwd<2, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
+            case 3: rc = launch_bwd<3, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
         }
         if (rc != GAOT_OK) return rc;
         hipLaunchKernelGGL(k_reduce_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, wpart, n_waves,

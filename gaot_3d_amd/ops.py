@@ -179,7 +179,7 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
     for l in range(len(weights)):
         gs.weight[l] = gw[l].data_ptr()
         gs.bias[l] = gb[l].data_ptr()
-    ws = _ws(lib.gaot_gno_bwd_workspace_bytes(C.byref(m), e), dev)
+    ws = _ws(lib.gaot_gno_bwd_workspace_bytes(C.byref(m), e, g.num_dst), dev)
     with _timed(f"gno_bwd_nh{m.n_hidden}"):
         check(lib.gaot_gno_bwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(grad_out), _ptr(g.by_dst.rowptr),
                                _ptr(g.by_src.key), _ptr(g.by_src.other), _ptr(g.by_src.rowptr), e, g.num_src, g.num_dst,

@@ -78,7 +78,7 @@ int gaot_gno_fwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const flo
  * parameter; none wrt coordinates.  Edges are given sorted by SOURCE (gaot_csr_build with
  * sort_row=0) so that grad_f_y is again an atomics-free segmented sum; rowptr_dst (from the
  * by-query list) supplies the mean's 1/deg.  grad outputs are overwritten, not accumulated. */
-size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp /* host */, int64_t num_edges);
+size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp /* host */, int64_t num_edges, int64_t num_queries);
 int gaot_gno_bwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const float* x_pos, const float* f_y,
                  const float* grad_out /* [num_queries, channels] */, const int32_t* rowptr_dst,
                  const int32_t* src_sorted /* by source */, const int32_t* dst_sorted /* by source */,
