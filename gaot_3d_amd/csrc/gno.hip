@@ -21,82 +21,11 @@
 //     (deterministic; no float atomics anywhere).
 #include <type_traits>
 
-#include "common.h"
+#include "gno_common.h"
 
 namespace {
 
-constexpr int IN0 = 6;      // [y_pos(3), x_pos(3)]
-constexpr int IN0P = 8;     // padded
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS ops of one wave execute in order; this only stops the compiler from reordering.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-struct MlpPtrs {
-    const float* w[GAOT_MAX_MLP_LAYERS];
-    const float* b[GAOT_MAX_MLP_LAYERS];
-};
-struct MlpGradPtrs {
-    float* w[GAOT_MAX_MLP_LAYERS];
-    float* b[GAOT_MAX_MLP_LAYERS];
-};
-
-// Per-lane walk over one 32-edge tile staged in LDS as stage[e*ld + c]: lane = channel c.
-// Complete rows are stored (mean or sum); rows open to the left go to part slot 0, rows open only
-// to the right to slot 1 (combined later by k_segment_fixup in tile order).
-template <int C>
-__device__ __forceinline__ void segment_walk(const float* stage, int ld, const int* ids, int c, int64_t tbase,
-                                             const int* __restrict__ rowptr, float* __restrict__ out,
-                                             float* __restrict__ part, bool mean) {
-    const int64_t tile = tbase >> 5;
-    int cur = ids[0];
-    float sum = 0.f;
-    auto flush = [&](int q, float s) {
-        if (q < 0) return;
-        const int rb = rowptr[q], re = rowptr[q + 1];
-        const bool ol = rb < tbase, orr = re > tbase + 32;
-        if (!ol && !orr) {
-            out[(int64_t)q * C + c] = mean ? s / (float)(re - rb) : s;
-        } else if (ol) {
-            part[(tile * 2 + 0) * C + c] = s;
-        } else {
-            part[(tile * 2 + 1) * C + c] = s;
-        }
-    };
-#pragma unroll 4
-    for (int e = 0; e < 32; ++e) {
-        const int d = ids[e];
-        if (d != cur) {
-            flush(cur, sum);
-            cur = d;
-            sum = 0.f;
-        }
-        if (d >= 0) sum += stage[e * ld + c];
-    }
-    flush(cur, sum);
-}
-
-// rows with no edges -> 0; rows spanning several tiles -> ordered sum of the tile partials
-template <int C>
-__global__ void k_segment_fixup(const int* __restrict__ rowptr, int64_t Q, const float* __restrict__ part,
-                                float* __restrict__ out, int mean) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q * C) return;
-    const int64_t q = i / C;
-    const int c = (int)(i % C);
-    const int rb = rowptr[q], re = rowptr[q + 1];
-    if (re == rb) {
-        out[i] = 0.f;
-        return;
-    }
-    const int t0 = rb >> 5, t1 = (re - 1) >> 5;
-    if (t0 == t1) return;
-    float s = part[((int64_t)t0 * 2 + 1) * C + c];
-    for (int t = t0 + 1; t <= t1; ++t) s += part[((int64_t)t * 2 + 0) * C + c];
-    out[i] = mean ? s / (float)(re - rb) : s;
-}
+using namespace gno;
 
 // =================================================================================================
 // Forward
@@ -751,13 +680,17 @@ bool mlp_supported(const gaot_mlp_t* m, bool backward) {
 
 }  // namespace
 
+int gaot_gno_fwd_bf16_dispatch(int n_hidden, const float* const* w, const float* const* b, const float* y_pos,
+                               const float* x_pos, const float* f_y, const int32_t* src_sorted, const int32_t* dst_sorted,
+                               const int32_t* rowptr_dst, int64_t num_edges, float* out, float* part, hipStream_t st);
+
 extern "C" size_t gaot_gno_fwd_workspace_bytes(int64_t num_edges, int channels) {
     return sizeof(float) * (size_t)(ceil_div(num_edges, 32) * 2 * channels) + 64;
 }
 
 extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const float* x_pos, const float* f_y,
                             const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_dst,
-                            int64_t num_edges, int64_t num_queries, float* out, void* workspace,
+                            int64_t num_edges, int64_t num_queries, float* out, int precision, void* workspace,
                             size_t workspace_bytes, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(mlp, "null mlp");
@@ -781,6 +714,11 @@ extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     int rc = GAOT_OK;
     if (num_edges > 0) {
         GAOT_CHECK_ARG(y_pos && x_pos && f_y && src_sorted && dst_sorted, "null pointer");
+        GAOT_CHECK_ARG(precision == 0 || precision == 1, "precision must be 0 (fp32) or 1 (bf16 matrix cores)");
+        if (precision == 1) {
+            rc = gaot_gno_fwd_bf16_dispatch(mlp->n_hidden, p.w, p.b, y_pos, x_pos, f_y, src_sorted, dst_sorted, rowptr_dst,
+                                            num_edges, out, part, st);
+        } else
         switch (mlp->n_hidden) {
             case 1: rc = launch_fwd<1, 64>(p, y_pos, x_pos, f_y, src_sorted, dst_sorted, rowptr_dst, num_edges, out, part, st); break;
             case 2: rc = launch_fwd<2, 64>(p, y_pos, x_pos, f_y, src_sorted, dst_sorted, rowptr_dst, num_edges, out, part, st); break;

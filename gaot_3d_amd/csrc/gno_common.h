@@ -1,0 +1,82 @@
+// Pieces shared by the fp32 (gno.hip) and bf16 (gno_bf16.hip) GNO kernels: the per-lane segmented walk over a
+// 32-edge LDS tile, the tile-ordered fix-up of rows that straddle tiles, small structs.
+#pragma once
+#include "common.h"
+
+namespace gno {
+
+constexpr int IN0 = 6;      // [y_pos(3), x_pos(3)]
+constexpr int IN0P = 8;     // padded
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS ops of one wave execute in order; this only stops the compiler from reordering.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct MlpPtrs {
+    const float* w[GAOT_MAX_MLP_LAYERS];
+    const float* b[GAOT_MAX_MLP_LAYERS];
+};
+struct MlpGradPtrs {
+    float* w[GAOT_MAX_MLP_LAYERS];
+    float* b[GAOT_MAX_MLP_LAYERS];
+};
+
+// Per-lane walk over one 32-edge tile staged in LDS as stage[e*ld + c]: lane = channel c.
+// Complete rows are stored (mean or sum); rows open to the left go to part slot 0, rows open only
+// to the right to slot 1 (combined later by k_segment_fixup in tile order).
+template <int C>
+__device__ __forceinline__ void segment_walk(const float* stage, int ld, const int* ids, int c, int64_t tbase,
+                                             const int* __restrict__ rowptr, float* __restrict__ out,
+                                             float* __restrict__ part, bool mean) {
+    const int64_t tile = tbase >> 5;
+    int cur = ids[0];
+    float sum = 0.f;
+    auto flush = [&](int q, float s) {
+        if (q < 0) return;
+        const int rb = rowptr[q], re = rowptr[q + 1];
+        const bool ol = rb < tbase, orr = re > tbase + 32;
+        if (!ol && !orr) {
+            out[(int64_t)q * C + c] = mean ? s / (float)(re - rb) : s;
+        } else if (ol) {
+            part[(tile * 2 + 0) * C + c] = s;
+        } else {
+            part[(tile * 2 + 1) * C + c] = s;
+        }
+    };
+#pragma unroll 4
+    for (int e = 0; e < 32; ++e) {
+        const int d = ids[e];
+        if (d != cur) {
+            flush(cur, sum);
+            cur = d;
+            sum = 0.f;
+        }
+        if (d >= 0) sum += stage[e * ld + c];
+    }
+    flush(cur, sum);
+}
+
+// rows with no edges -> 0; rows spanning several tiles -> ordered sum of the tile partials
+template <int C>
+__global__ void k_segment_fixup(const int* __restrict__ rowptr, int64_t Q, const float* __restrict__ part,
+                                float* __restrict__ out, int mean) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * C) return;
+    const int64_t q = i / C;
+    const int c = (int)(i % C);
+    const int rb = rowptr[q], re = rowptr[q + 1];
+    if (re == rb) {
+        out[i] = 0.f;
+        return;
+    }
+    const int t0 = rb >> 5, t1 = (re - 1) >> 5;
+    if (t0 == t1) return;
+    float s = part[((int64_t)t0 * 2 + 1) * C + c];
+    for (int t = t0 + 1; t <= t1; ++t) s += part[((int64_t)t * 2 + 0) * C + c];
+    out[i] = mean ? s / (float)(re - rb) : s;
+}
+
+
+}  // namespace gno

@@ -144,8 +144,10 @@ def _mlp_struct(weights: Sequence[Tensor], biases: Sequence[Tensor]) -> Tuple[Ml
     return m, keep
 
 
-def gno_forward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, g: BipartiteGraph) -> Tensor:
+def gno_forward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, g: BipartiteGraph,
+                precision: Optional[int] = None) -> Tensor:
     lib = _lib.load()
+    prec = _PRECISION["mode"] if precision is None else precision
     m, keep = _mlp_struct(weights, biases)
     y_pos = _req(y_pos, torch.float32, "y_pos")
     x_pos = _req(x_pos, torch.float32, "x_pos")
@@ -158,7 +160,7 @@ def gno_forward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, g: B
     ws = _ws(lib.gaot_gno_fwd_workspace_bytes(e, m.channels), x_pos.device)
     with _timed(f"gno_fwd_nh{m.n_hidden}"):
         check(lib.gaot_gno_fwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(g.by_dst.other), _ptr(g.by_dst.key),
-                               _ptr(g.by_dst.rowptr), e, q, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_gno_fwd")
+                               _ptr(g.by_dst.rowptr), e, q, _ptr(out), prec, _ptr(ws), ws.numel(), _stream()), "gaot_gno_fwd")
     return out
 
 

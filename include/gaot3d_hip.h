@@ -71,8 +71,9 @@ typedef struct {
 size_t gaot_gno_fwd_workspace_bytes(int64_t num_edges, int channels);
 int gaot_gno_fwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const float* x_pos, const float* f_y,
                  const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_dst, int64_t num_edges,
-                 int64_t num_queries, float* out /* [num_queries, channels] */, void* workspace,
-                 size_t workspace_bytes, gaot_stream_t stream);
+                 int64_t num_queries, float* out /* [num_queries, channels] */,
+                 int precision /* 0: exact-fp32 MFMA; 1: bf16 MFMA for the hidden/last layers, fp32 accumulate */,
+                 void* workspace, size_t workspace_bytes, gaot_stream_t stream);
 
 /* Backward of the above (autograd of the reference ops): grad wrt f_y and wrt every MLP
  * parameter; none wrt coordinates.  Edges are given sorted by SOURCE (gaot_csr_build with

@@ -193,3 +193,29 @@ def test_gno_deterministic():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for u, v in zip(a[2] + a[3], b[2] + b[3]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("nh", [1, 2, 3, 4])
+def test_gno_bf16_forward(nh):
+    """bf16 matrix-core variant (hidden/last layers on v_mfma_f32_32x32x16_bf16, layer 0 exact fp32): tolerance of
+    bf16 operands -- rtol 2e-2 on the output scale (SURVEY §8d bf16 mode)"""
+    from gaot_3d_amd import ops
+    gen = torch.Generator().manual_seed(20 + nh)
+    n_src, n_dst, e = 3000, 700, 20011
+    ei = rand_graph(n_src, n_dst, e, seed=30 + nh, dtype=torch.int32)
+    y = torch.rand(n_src, 3, generator=gen) * 2 - 1
+    x = torch.rand(n_dst, 3, generator=gen) * 2 - 1
+    f = torch.randn(n_src, 32, generator=gen)
+    sd = _mlp_sd([6] + [64] * nh + [32], seed=nh)
+    n = nh + 1
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(n)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(n)]
+    g = ops.build_graph(ei.to(DEV), n_src, n_dst)
+    out = ops.gno_forward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), g, precision=1).cpu()
+    ref = orc.integral_transform(sd, "", y, x, ei, f)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    print(f"[parity] gno_bf16_fwd_nh{nh}: max_abs={err:.3e} ref_peak={scale:.3e}")
+    assert err <= 2e-2 * scale
+    out32 = ops.gno_forward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), g, precision=0).cpu()
+    assert torch.allclose(out32, ref, rtol=1e-4, atol=1e-5)
