@@ -42,7 +42,7 @@ SIGNATURES = {
     "gaot_gno_fwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _i, _p, _sz, _p]),
     "gaot_gno_bwd_workspace_bytes": (_sz, [C.POINTER(MlpT), _i64, _i64]),
     "gaot_gno_bwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p,
-                          C.POINTER(MlpGradT), _p, _sz, _p]),
+                          C.POINTER(MlpGradT), _i, _p, _sz, _p]),
     "gaot_geoembed_stats_workspace_bytes": (_sz, []),
     "gaot_geoembed_stats": (_i, [_p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "gaot_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -684,6 +684,12 @@ int gaot_gno_fwd_bf16_dispatch(int n_hidden, const float* const* w, const float*
                                const float* x_pos, const float* f_y, const int32_t* src_sorted, const int32_t* dst_sorted,
                                const int32_t* rowptr_dst, int64_t num_edges, float* out, float* part, hipStream_t st);
 
+size_t gaot_gno_bwd_bf16_image_bytes(int n_hidden);
+int gaot_gno_bwd_bf16_dispatch(int n_hidden, const float* const* w, const float* const* b, const float* w0t,
+                               void* images, const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
+                               const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
+                               int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st);
+
 extern "C" size_t gaot_gno_fwd_workspace_bytes(int64_t num_edges, int channels) {
     return sizeof(float) * (size_t)(ceil_div(num_edges, 32) * 2 * channels) + 64;
 }
@@ -743,14 +749,14 @@ extern "C" size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp, int64_t nu
                 + (size_t)total                             // reduced flat gradient
                 + (size_t)grid * total                      // per-block partials
                 + (size_t)num_queries * 32;                 // grad_out / deg
-    return sizeof(float) * fl + 256;
+    return sizeof(float) * fl + gaot_gno_bwd_bf16_image_bytes(mlp->n_hidden) + 512;
 }
 
 extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const float* x_pos, const float* f_y,
                             const float* grad_out, const int32_t* rowptr_dst, const int32_t* src_sorted,
                             const int32_t* dst_sorted, const int32_t* rowptr_src, int64_t num_edges,
                             int64_t num_sources, int64_t num_queries, float* grad_f_y, const gaot_mlp_grad_t* grads,
-                            void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
+                            int precision, void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(mlp && grads, "null mlp");
     if (!mlp_supported(mlp, true)) {
@@ -771,6 +777,8 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     float* flat = wt + total;
     float* wpart = flat + total;
     float* gs = wpart + (size_t)grid * total;
+    void* images = (void*)(((uintptr_t)(gs + (size_t)num_queries * 32) + 255) & ~(uintptr_t)255);
+    GAOT_CHECK_ARG(precision == 0 || precision == 1, "precision must be 0 (fp32) or 1 (bf16 matrix cores)");
 
     MlpPtrs p, pt;
     int off = 0;
@@ -810,6 +818,10 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         hipLaunchKernelGGL(k_scale_by_inv_deg, dim3((unsigned)ceil_div(num_queries * 8, 256)), dim3(256), 0, st, grad_out,
                            rowptr_dst, num_queries, gs);
         int rc = GAOT_OK;
+        if (precision == 1) {
+            rc = gaot_gno_bwd_bf16_dispatch(nh, p.w, p.b, pt.w[0], images, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted,
+                                            rowptr_src, num_edges, grad_f_y, part, wpart, grid, st);
+        } else
         switch (nh) {
             case 1: rc = launch_bwd<1, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
             case 2: rc = launch_bwd<2, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;

@@ -164,9 +164,11 @@ def gno_forward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, g: B
     return out
 
 
-def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, grad_out: Tensor, g: BipartiteGraph):
+def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, grad_out: Tensor, g: BipartiteGraph,
+                 precision: Optional[int] = None):
     """-> (grad_f_y, [grad_w...], [grad_b...])"""
     lib = _lib.load()
+    prec = _PRECISION["mode"] if precision is None else precision
     m, keep = _mlp_struct(weights, biases)
     y_pos = _req(y_pos, torch.float32, "y_pos")
     x_pos = _req(x_pos, torch.float32, "x_pos")
@@ -185,7 +187,7 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
     with _timed(f"gno_bwd_nh{m.n_hidden}"):
         check(lib.gaot_gno_bwd(C.byref(m), _ptr(y_pos), _ptr(x_pos), _ptr(f_y), _ptr(grad_out), _ptr(g.by_dst.rowptr),
                                _ptr(g.by_src.key), _ptr(g.by_src.other), _ptr(g.by_src.rowptr), e, g.num_src, g.num_dst,
-                               _ptr(grad_f), C.byref(gs), _ptr(ws), ws.numel(), _stream()), "gaot_gno_bwd")
+                               _ptr(grad_f), C.byref(gs), prec, _ptr(ws), ws.numel(), _stream()), "gaot_gno_bwd")
     return grad_f, gw, gb
 
 

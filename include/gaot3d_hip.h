@@ -85,7 +85,7 @@ int gaot_gno_bwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const flo
                  const int32_t* src_sorted /* by source */, const int32_t* dst_sorted /* by source */,
                  const int32_t* rowptr_src, int64_t num_edges, int64_t num_sources, int64_t num_queries,
                  float* grad_f_y /* [num_sources, channels] */, const gaot_mlp_grad_t* grads /* host */,
-                 void* workspace, size_t workspace_bytes, gaot_stream_t stream);
+                 int precision, void* workspace, size_t workspace_bytes, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Statistical geometric-embedding features (reference GeometricEmbedding.

@@ -219,3 +219,39 @@ def test_gno_bf16_forward(nh):
     assert err <= 2e-2 * scale
     out32 = ops.gno_forward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), g, precision=0).cpu()
     assert torch.allclose(out32, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("nh", [1, 2, 3])
+def test_gno_bf16_backward(nh):
+    """bf16 matrix-core backward: gradients against the fp32 oracle -- cosine >= 0.999 and max error <= 3e-2 of the
+    gradient's peak (bf16 operand tolerance); graph with empty rows and a >32-degree row on both sides"""
+    from gaot_3d_amd import ops
+    gen = torch.Generator().manual_seed(40 + nh)
+    n_src, n_dst, e = 3000, 700, 20011
+    ei = rand_graph(n_src, n_dst, e, seed=50 + nh, dtype=torch.int32)
+    ei[0, 100:400] = 17          # a heavy SOURCE row as well (segmented grad_f over > 32 edges)
+    y = torch.rand(n_src, 3, generator=gen) * 2 - 1
+    x = torch.rand(n_dst, 3, generator=gen) * 2 - 1
+    f = torch.randn(n_src, 32, generator=gen)
+    w = torch.randn(n_dst, 32, generator=gen)
+    sd = _mlp_sd([6] + [64] * nh + [32], seed=nh)
+    n = nh + 1
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(n)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(n)]
+    g = ops.build_graph(ei.to(DEV), n_src, n_dst)
+    gf, gw, gb = ops.gno_backward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), w.to(DEV), g, precision=1)
+    torch.cuda.synchronize()
+    _, rgf, sdr = _oracle_gno(sd, y, x, ei, f, w)
+
+    def check(name, a, b):
+        a, b = a.detach().cpu().double().flatten(), b.double().flatten()
+        cos = (a * b).sum() / (a.norm() * b.norm() + 1e-30)
+        err = (a - b).abs().max().item()
+        print(f"[parity] gno_bf16_bwd_nh{nh}/{name}: cosine={cos.item():.6f} max_abs={err:.3e} ref_peak={b.abs().max().item():.3e}")
+        assert cos.item() >= 0.999, name
+        assert err <= 3e-2 * b.abs().max().item() + 1e-7, name
+
+    check("grad_f", gf, rgf)
+    for i in range(n):
+        check(f"grad_w{i}", gw[i], sdr[f"channel_mlp.fcs.{i}.weight"].grad)
+        check(f"grad_b{i}", gb[i], sdr[f"channel_mlp.fcs.{i}.bias"].grad)
