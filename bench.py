@@ -227,10 +227,10 @@ def main():
         roof = None
         if dom:
             d = per_kernel[dom]
-            # GNO kernels run their edge MLP on exact-fp32 MFMA: in fp32 arithmetic they are bound by the fp32 matrix
-            # rate, not by HBM; report against the binding roof
-            if d["bound"] == "hbm" and d["tflops"] / 157.3 > d.get("gbps", 0) / 8000.0:
-                ach, (peak, unit), bound = d["tflops"], (157.3, "TFLOP/s"), "mfma"
+            # GNO kernels: layer 0 always runs on exact-fp32 MFMA, the other layers on the precision's matrix rate;
+            # report against whichever roof (matrix rate of the arithmetic used, or HBM) binds tighter
+            if d["bound"] == "hbm" and d["tflops"] / peaks["mfma"][0] > d.get("gbps", 0) / 8000.0:
+                ach, (peak, unit), bound = d["tflops"], peaks["mfma"], "mfma"
             elif d["bound"] == "hbm":
                 ach, (peak, unit), bound = d["gbps"], peaks["hbm"], "hbm"
             else:
@@ -240,7 +240,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get(dom)
+                    roof["traffic"] = json.load(open(pmc)).get(dom, {}).get("bytes_per_launch")
                 except Exception:
                     pass
         out = {
