@@ -252,14 +252,15 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                     negm[r] = -m;
                 }
             }
-            f32x2 ps2 = {0.f, 0.f};
+            float ps0 = 0.f, ps1 = 0.f;   // two scalar chains: packed-f32 adds cost more issue cycles beside MFMAs
     #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 sc[r] = __builtin_amdgcn_exp2f(sc[r]);
                 sc[r + 1] = __builtin_amdgcn_exp2f(sc[r + 1]);
-                ps2 += (f32x2){sc[r], sc[r + 1]};
+                ps0 += sc[r];
+                ps1 += sc[r + 1];
             }
-            l += ps2[0] + ps2[1];   // per-half partial; the halves are added once, after the key loop
+            l += ps0 + ps1;   // per-half partial; the halves are added once, after the key loop
             bf16x8 p0, p1;
             acc_to_frags(sc, p0, p1);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);

@@ -11,6 +11,8 @@
 // HBM.  Row pitches are padded (144 B / 320 B) so that both kinds of read are bank-conflict free.
 // 128x128 tile, 4 waves (2x2), 64x64 per wave, BK = 64, register-staged prefetch of the next tile.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -131,10 +133,52 @@ struct Tile {
     }
 };
 
-template <bool A_KS, bool B_KS, int BM>
-__global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_vec) {
-    using TA = Tile<A_KS, BM>;
-    using TB = Tile<B_KS, BN>;
+// Branch-free variant of Tile::load for 16-byte aligned operands with K % 4 == 0: the tile is addressed through
+// a buffer resource that starts at the tile's first row, so rows past the end of the matrix read as zero in
+// hardware and the k tail is masked by pushing the lane's offset out of range.  One VGPR of address per operand;
+// the per-load row / k displacement is a scalar offset.
+template <bool KS, int ROWS>
+struct VTile : Tile<KS, ROWS> {
+    using Base = Tile<KS, ROWS>;
+    static constexpr int NV = Base::NV;
+    static constexpr int KR = 1024 / ROWS;   // KS: k-rows covered by one pass of the 256 threads
+    __amdgpu_buffer_rsrc_t rs;
+    int voff, ld4, kk;
+
+    __device__ __forceinline__ void setup(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t K) {
+        const float* base = KS ? X + row0 : X + row0 * ld;
+        int64_t bytes = KS ? ((K - 1) * ld + (nrows - row0)) * 4 : ((nrows - row0 - 1) * ld + K) * 4;
+        bytes = bytes < 0 ? 0 : (bytes > 0x7fffffff ? 0x7fffffff : bytes);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+        ld4 = (int)ld * 4;
+        if (!KS) {
+            kk = 4 * (threadIdx.x & 15);
+            voff = (threadIdx.x >> 4) * ld4 + kk * 4;
+        } else {
+            kk = threadIdx.x / (ROWS / 4);
+            voff = kk * ld4 + (threadIdx.x % (ROWS / 4)) * 16;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kend) {
+        if (!KS) {
+            const int vo = (k0 + kk < kend) ? voff : (int)0x80000000;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                this->regs[v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, v * 16 * ld4 + k0 * 4, 0));
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int vo = (k0 + v * KR + kk < kend) ? voff : (int)0x80000000;
+                this->regs[v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (k0 + v * KR) * ld4, 0));
+            }
+        }
+    }
+};
+
+template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int b_vec) {
+    using TA = typename std::conditional<VEC, VTile<A_KS, BM>, Tile<A_KS, BM>>::type;
+    using TB = typename std::conditional<VEC, VTile<B_KS, BN>, Tile<B_KS, BN>>::type;
     constexpr int MT = BM / 64;   // 32-row MFMA tiles per wave along M (waves are 2 x 2)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* la = lds;
@@ -158,7 +202,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
 
     TA ta;
     TB tb;
-    if (kbeg < kend) {
+    if constexpr (VEC) {
+        ta.setup(g.A, g.lda, bm, g.M, g.K);
+        tb.setup(g.B, g.ldb, bn, g.N, g.K);
+        if (kbeg < kend) {
+            ta.load((int)kbeg, (int)kend);
+            tb.load((int)kbeg, (int)kend);
+        }
+    } else if (kbeg < kend) {
         ta.load(g.A, g.lda, bm, g.M, kbeg, kend, a_vec);
         tb.load(g.B, g.ldb, bn, g.N, kbeg, kend, b_vec);
     }
@@ -167,8 +218,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
         tb.store(lb);
         __syncthreads();
         if (k0 + BK < kend) {
-            ta.load(g.A, g.lda, bm, g.M, k0 + BK, kend, a_vec);
-            tb.load(g.B, g.ldb, bn, g.N, k0 + BK, kend, b_vec);
+            if constexpr (VEC) {
+                ta.load((int)k0 + BK, (int)kend);
+                tb.load((int)k0 + BK, (int)kend);
+            } else {
+                ta.load(g.A, g.lda, bm, g.M, k0 + BK, kend, a_vec);
+                tb.load(g.B, g.ldb, bn, g.N, k0 + BK, kend, b_vec);
+            }
         }
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -217,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(GArgs g, int a_vec, int b_
         }
 }
 
-template <bool A_KS, bool B_KS, int BM>
+template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC>
 int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
     const size_t lds = Tile<A_KS, BM>::BYTES + Tile<B_KS, BN>::BYTES;
-    auto kern = k_gemm_bf16<A_KS, B_KS, BM>;
+    auto kern = k_gemm_bf16<A_KS, B_KS, BM, VEC, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -239,8 +295,22 @@ template <bool A_KS, bool B_KS>
 int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
     // fewer than two 128x128 workgroups per CU: halve the tile height so that twice as many workgroups hide latency
     const int64_t blocks128 = ceil_div(g.N, BN) * ceil_div(g.M, 128) * splits;
-    if (blocks128 < 512 && g.M > 64) return launch_bm<A_KS, B_KS, 64>(g, a_vec, b_vec, splits, st);
-    return launch_bm<A_KS, B_KS, 128>(g, a_vec, b_vec, splits, st);
+    static const int thr = getenv("GAOT_GEMM_THR") ? atoi(getenv("GAOT_GEMM_THR")) : 2100;
+    const bool small = blocks128 < thr && g.M > 64;
+    // buffer-addressed tiles need 16-byte aligned rows, whole float4s along k and 31-bit byte offsets inside a tile
+    const int64_t span_a = (A_KS ? g.K : 128) * g.lda * 4, span_b = (B_KS ? g.K : 128) * g.ldb * 4;
+    const bool vec = a_vec && b_vec && g.K % 4 == 0 && span_a < 0x7fffffff && span_b < 0x7fffffff;
+    static const int occ = getenv("GAOT_GEMM_OCC") ? atoi(getenv("GAOT_GEMM_OCC")) : 2;
+    if (vec) {
+        if (small) {
+            if (occ == 4) return launch_bm<A_KS, B_KS, 64, true, 4>(g, a_vec, b_vec, splits, st);
+            if (occ == 3) return launch_bm<A_KS, B_KS, 64, true, 3>(g, a_vec, b_vec, splits, st);
+            return launch_bm<A_KS, B_KS, 64, true, 2>(g, a_vec, b_vec, splits, st);
+        }
+        return launch_bm<A_KS, B_KS, 128, true, 2>(g, a_vec, b_vec, splits, st);
+    }
+    if (small) return launch_bm<A_KS, B_KS, 64, false, 2>(g, a_vec, b_vec, splits, st);
+    return launch_bm<A_KS, B_KS, 128, false, 2>(g, a_vec, b_vec, splits, st);
 }
 
 }  // namespace
