@@ -23,7 +23,7 @@ def timeit(fn, name, flops=None):
 
 
 if what == "attn":
-    b, s, h = 1, 16384, 8
+    b, s, h = 1, int(os.environ.get('MB_S', 16384)), 8
     qkv = torch.randn(b * s, 3 * h * 32, device=dev)
     freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
     d_o = torch.randn(b * s, h * 32, device=dev)
@@ -32,6 +32,14 @@ if what == "attn":
         o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5)
         timeit(lambda: ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5), "attn_fwd_bf16(+prep)", 2 * att)
         timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5), "attn_bwd_bf16(all)", 4 * att)
+        ops.timing_reset(True)
+        for _ in range(reps):
+            ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5)
+            ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5)
+        torch.cuda.synchronize()
+        for name, (calls, tot) in ops.timing_summary().items():
+            print(f"  {name}: {tot / calls:.4f} ms")
+        ops.timing_reset(False)
     else:
         o, lse = ops.attn_fwd(qkv, b, s, h, h, 32 ** -0.5)
         timeit(lambda: ops.attn_fwd(qkv, b, s, h, h, 32 ** -0.5), "attn_fwd_f32", 2 * att)
