@@ -233,6 +233,39 @@ def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
     return MSELossFn.apply(pred, target)
 
 
+def _adjacent(ws) -> bool:
+    """True when the 2-D weights sit back to back in one storage (same K): they then form ONE [sum N_i, K] matrix."""
+    k = ws[0].shape[1]
+    for a, b in zip(ws[:-1], ws[1:]):
+        if b.shape[1] != k or not (a.is_contiguous() and b.is_contiguous()) or a.device != b.device:
+            return False
+        if b.data_ptr() != a.data_ptr() + a.numel() * a.element_size():
+            return False
+        if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+            return False   # neighbours in memory by allocator accident, not slices of one buffer
+    return True
+
+
+def colocate(params) -> None:
+    """Re-point the storage of separate parameters (the reference keeps q_proj/k_proj/v_proj and w1/w3 as separate
+    nn.Linear weights, attn.py:76-79,146-148) at consecutive slices of one buffer, values preserved, so that ONE GEMM
+    serves all of them in forward, input-gradient and weight-gradient.  Parameter objects, names, shapes and the
+    state_dict are unchanged; a later ``.to(device)`` simply undoes the co-location and the next forward redoes it."""
+    ps = list(params)
+    if _adjacent([_w2d(p.data) for p in ps]):
+        return
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise GaotError("colocate: parameters must be co-located before the step is captured into a graph")
+    with torch.no_grad():
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        off = 0
+        for p in ps:
+            v = flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            off += p.numel()
+
+
 class MultiLinearFn(Function):
     """[x W_0^T | x W_1^T | ...] written into the column blocks of ONE buffer (bias-free), so the
     separate q/k/v (and w1/w3) parameters of the reference feed one fused downstream kernel."""
@@ -247,12 +280,18 @@ class MultiLinearFn(Function):
         m = x2.shape[0]
         ntot = sum(w.shape[0] for w in ws)
         out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
-        col = 0
-        for w in ws:
-            n = w.shape[0]
-            ops.gemm(x2, w, m, n, k, k, k, False, True, out=out[:, col:], ldc=ntot, precision=precision)
-            col += n
-        ctx.save_for_backward(x2, *ws)
+        ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[2 + i] for i in range(len(ws)))
+        if ctx.fused:   # the weights are slices of one buffer (colocate): one [ntot, k] matrix, one GEMM
+            wcat = ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1))
+            ops.gemm(x2, wcat, m, ntot, k, k, k, False, True, out=out, ldc=ntot, precision=precision)
+            ctx.save_for_backward(x2, wcat)
+        else:
+            col = 0
+            for w in ws:
+                n = w.shape[0]
+                ops.gemm(x2, w, m, n, k, k, k, False, True, out=out[:, col:], ldc=ntot, precision=precision)
+                col += n
+            ctx.save_for_backward(x2, *ws)
         ctx.precision, ctx.xshape, ctx.wshapes = precision, x.shape, [w.shape for w in weights]
         return out
 
@@ -265,6 +304,16 @@ class MultiLinearFn(Function):
         dx = None
         dws = []
         col = 0
+        if ctx.fused:
+            (wcat,) = ws
+            if ctx.needs_input_grad[0]:
+                dx = ops.gemm(d, wcat, m, k, ntot, ntot, k, False, False, precision=ctx.precision)
+            dwcat = ops.gemm(d, x2, ntot, k, m, ntot, k, True, False, precision=ctx.precision)
+            for shp in ctx.wshapes:
+                n = shp[0]
+                dws.append(dwcat[col:col + n].view(shp))
+                col += n
+            return (dx.view(ctx.xshape) if dx is not None else None, None, *dws)
         for i, w in enumerate(ws):
             n = w.shape[0]
             blk = d[:, col:]

@@ -91,6 +91,7 @@ class GroupQueryFlashAttention(nn.Module):
             raise NotImplementedError("attention dropout > 0 in training mode is not implemented on the HIP path; "
                                       "set atten_dropout=0.0 (reference default 0.1, attn.py:22) or call .eval()")
         b, s, _ = x.shape
+        GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
         o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads)
@@ -117,6 +118,7 @@ class FFN(nn.Module):
     def forward(self, x, condition: Optional[float] = None, residual: Optional[torch.Tensor] = None):
         """``residual`` (extension): added inside the w2 GEMM epilogue (the block's `h + ffn(h)`)."""
         shp = x.shape
+        GF.colocate([self.w1.weight, self.w3.weight])
         ag = GF.multi_linear(x, [self.w1.weight, self.w3.weight])   # [rows, 2F] = [w1 x | w3 x]
         u = GF.SwiGLUFn.apply(ag, self.hidden)
         res = None if residual is None else residual.reshape(-1, residual.shape[-1])

@@ -131,3 +131,31 @@ def test_get_neighbor_strategy_conventions():
     assert torch.equal(rev, bi.flip(0))        # 'reverse' = flip of the *bidirectional* encoder graph
     with pytest.raises(ValueError):
         get_neighbor_strategy("nope", pos, bp, lat, bl, 0.5, 1, False)
+
+
+def test_colocate_keeps_parameters_and_values():
+    """co-locating q/k/v (or w1/w3) weights in one buffer must not change parameter identity, shapes, values or the
+    state_dict -- only where the storage lives (reference keeps them as separate nn.Linear weights, attn.py:76-79)"""
+    import torch
+    from gaot_3d_amd import functional as GF
+    lin = [torch.nn.Linear(16, n, bias=False) for n in (16, 8, 8)]
+    ps = [m.weight for m in lin]
+    before = [p.detach().clone() for p in ps]
+    ids = [id(p) for p in ps]
+    assert not GF._adjacent([p.data for p in ps])
+    GF.colocate(ps)
+    assert [id(p) for p in ps] == ids
+    assert GF._adjacent([p.data for p in ps])
+    for p, b in zip(ps, before):
+        assert p.shape == b.shape and torch.equal(p.detach(), b) and p.requires_grad and p.is_leaf
+    # in-place updates (optimizer, load_state_dict) keep the co-location; .to()-style replacement undoes it harmlessly
+    with torch.no_grad():
+        ps[1].add_(1.0)
+    lin[0].load_state_dict({"weight": torch.zeros(16, 16)})
+    assert GF._adjacent([p.data for p in ps]) and float(ps[0].abs().sum()) == 0.0
+    assert torch.equal(ps[1].detach(), before[1] + 1.0)
+    GF.colocate(ps)   # idempotent
+    assert GF._adjacent([p.data for p in ps])
+    # neighbours in memory that are NOT slices of one buffer must not be taken for one matrix
+    a, b = torch.zeros(4, 4), torch.zeros(4, 4)
+    assert not GF._adjacent([a, b])

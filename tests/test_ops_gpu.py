@@ -183,6 +183,39 @@ def test_attention_bf16_large_grid(b, s, h, hkv):
         assert c >= 0.999, (name, c)
 
 
+@pytest.mark.parametrize("m,k,ns", [(8, 64, (64, 64, 64)), (300, 256, (256, 128, 128)), (1000, 64, (128, 128))])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_multi_linear_colocated(m, k, ns, precision):
+    """q|k|v (w1|w3) through ONE GEMM after colocate(): same outputs and gradients as one GEMM per weight"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    x = gen(m, k, seed=m)
+    ws = [gen(n, k, seed=10 + i) * 0.1 for i, n in enumerate(ns)]
+    g = gen(m, sum(ns), seed=99)
+    xr = x.clone().double().requires_grad_(True)
+    wr = [w.clone().double().requires_grad_(True) for w in ws]
+    ref = torch.cat([xr @ w.t() for w in wr], 1)
+    (ref * g.double()).sum().backward()
+    gaot_3d_amd.set_precision(precision)
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        wd = [torch.nn.Parameter(w.to(DEV)) for w in ws]
+        GF.colocate(wd)
+        assert GF._adjacent([w.data for w in wd])
+        out = GF.multi_linear(xd, wd)
+        (out * g.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    rt, at = (1e-4, 1e-5) if precision == "fp32" else (2e-2, 2e-2)
+    close(f"mlc_out_{precision}_{m}", out, ref, rt, at)
+    gr, ga = (1e-3, 1e-4) if precision == "fp32" else (5e-2, 5e-2 * max(1.0, float(xr.grad.abs().max())))
+    close(f"mlc_dx_{precision}_{m}", xd.grad, xr.grad, gr, ga)
+    for i, (a, r) in enumerate(zip(wd, wr)):
+        ga_w = ga if precision == "fp32" else 5e-2 * float(r.grad.abs().max())
+        close(f"mlc_dw{i}_{precision}_{m}", a.grad, r.grad, gr, ga_w)
+
+
 def test_attention_spike_rows():
     """online-softmax rescale path: one key dominates late in the sequence"""
     from gaot_3d_amd import functional as GF
