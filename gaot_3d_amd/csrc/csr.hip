@@ -9,12 +9,48 @@
 //   3. scatter edge ids through per-row cursors     4. per-row rank sort of the edge ids
 // Step 4 makes the order inside a row = original edge order, so every later floating-point
 // segmented sum is bit-reproducible run to run.
+//
+// Fast path: neighbour searches emit their lists grouped by query, so one of the two orders a
+// bipartite graph needs is usually sorted already.  A first pass checks that on the device (no host
+// sync, graph-capturable); if the keys are non-decreasing the list IS its own stable sort: one
+// streaming pass writes rowptr / perm / the copies, and steps 1-4 return at their first instruction.
 #include "common.h"
 
 namespace {
 
+// *unsorted != 0 when some key is smaller than its predecessor
 template <typename IDX>
-__global__ void k_hist(const IDX* __restrict__ keys, int64_t E, int* __restrict__ counts) {
+__global__ void k_check_sorted(const IDX* __restrict__ keys, int64_t E, int* __restrict__ unsorted) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < E; i += stride) bad |= (i > 0) && (keys[i] < keys[i - 1]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) *unsorted = 1;   // benign race: every writer stores 1
+}
+
+// sorted keys: the input order is the stable sort.  rowptr[r] = first edge with key >= r.
+template <typename IDX>
+__global__ void k_sorted_build(const IDX* __restrict__ keys, const IDX* __restrict__ other, int64_t E, int64_t Q,
+                               const int* __restrict__ unsorted, int* __restrict__ rowptr, int* __restrict__ perm,
+                               int* __restrict__ key_sorted, int* __restrict__ other_sorted) {
+    if (*unsorted) return;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < E; i += stride) {
+        const int k = (int)keys[i];
+        perm[i] = (int)i;
+        key_sorted[i] = k;
+        other_sorted[i] = (int)other[i];
+        const int kprev = (i > 0) ? (int)keys[i - 1] : -1;
+        for (int r = kprev + 1; r <= k; ++r) rowptr[r] = (int)i;      // rows (kprev, k] start here (empty ones too)
+        if (i == E - 1)
+            for (int64_t r = (int64_t)k + 1; r <= Q; ++r) rowptr[r] = (int)E;
+    }
+}
+
+template <typename IDX>
+__global__ void k_hist(const IDX* __restrict__ keys, int64_t E, int* __restrict__ counts, const int* __restrict__ unsorted) {
+    if (!*unsorted) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < E; i += stride) atomicAdd(&counts[(int)keys[i]], 1);
@@ -75,8 +111,9 @@ __global__ void k_scan_blocksums(int* __restrict__ block_sums, int nb) {
 
 // out[i] = exclusive prefix; also copies to cursor[i]; writes out[n] = total when i==n-1
 __global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* __restrict__ block_offs,
-                             int* __restrict__ out, int* __restrict__ cursor) {
+                             int* __restrict__ out, int* __restrict__ cursor, const int* __restrict__ unsorted) {
     __shared__ int wsum[SCAN_BLOCK / 64];
+    if (!*unsorted) return;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
@@ -109,7 +146,9 @@ __global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* _
 }
 
 template <typename IDX>
-__global__ void k_fill(const IDX* __restrict__ keys, int64_t E, int* __restrict__ cursor, int* __restrict__ tmp) {
+__global__ void k_fill(const IDX* __restrict__ keys, int64_t E, int* __restrict__ cursor, int* __restrict__ tmp,
+                       const int* __restrict__ unsorted) {
+    if (!*unsorted) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < E; i += stride) {
@@ -135,7 +174,8 @@ template <typename IDX, int G>
 __global__ void k_row_sort(const IDX* __restrict__ keys, const IDX* __restrict__ other, int64_t Q,
                            const int* __restrict__ rowptr, const int* __restrict__ tmp, int* __restrict__ perm,
                            int* __restrict__ key_sorted, int* __restrict__ other_sorted, int* __restrict__ heavy_count,
-                           int* __restrict__ heavy_list) {
+                           int* __restrict__ heavy_list, const int* __restrict__ unsorted) {
+    if (!*unsorted) return;
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int gl = threadIdx.x % G;
     if (gid >= Q) return;
@@ -218,27 +258,31 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     int* tmp = bsum + (nb + 1);             // [E]
     int* heavy_count = tmp + E;             // [1] (+3 pad)
     int* heavy_list = heavy_count + 4;      // [<= E / HEAVY_DEG + 1]
-    hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(Q + 1), st);
-    hipMemsetAsync(heavy_count, 0, sizeof(int) * 4, st);
+    int* unsorted = heavy_count + 1;        // cleared together with heavy_count
+    (void)hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(Q + 1), st);
+    (void)hipMemsetAsync(heavy_count, 0, sizeof(int) * 4, st);
     if (E == 0) {
-        hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
+        (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
         return GAOT_OK;
     }
     const int tb = 256;
     const int gb = (int)std::min<int64_t>(ceil_div(E, tb), 256 * 16);
-    hipLaunchKernelGGL((k_hist<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, counts);
+    hipLaunchKernelGGL((k_check_sorted<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, unsorted);
+    hipLaunchKernelGGL((k_sorted_build<IDX>), dim3(gb), dim3(tb), 0, st, keys, other, E, Q, unsorted, rowptr, perm,
+                       key_sorted, other_sorted);
+    hipLaunchKernelGGL((k_hist<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, counts, unsorted);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum, rowptr, cursor);
-    hipLaunchKernelGGL((k_fill<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, cursor, tmp);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum, rowptr, cursor, unsorted);
+    hipLaunchKernelGGL((k_fill<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, cursor, tmp, unsorted);
     if (E / (Q > 0 ? Q : 1) >= 16) {
         const int64_t threads = Q * 64;
         hipLaunchKernelGGL((k_row_sort<IDX, 64>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list);
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list, unsorted);
     } else {
         const int64_t threads = Q * 8;
         hipLaunchKernelGGL((k_row_sort<IDX, 8>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list);
+                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list, unsorted);
     }
     hipLaunchKernelGGL((k_row_sort_heavy<IDX>), dim3(1024), dim3(256), 0, st, other, rowptr, tmp, perm, key_sorted,
                        other_sorted, heavy_count, heavy_list);

@@ -62,6 +62,31 @@ def test_csr_build(dtype, e, nr):
         assert torch.equal(s.other.cpu().long(), ei[1 - sort_row].long()[order])
 
 
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("e,nr", [(1, 4), (1000, 37), (50000, 4096), (200000, 70000)])
+def test_csr_build_sorted_input(dtype, e, nr):
+    """neighbour lists that arrive grouped by query (what a neighbour search emits) take the streaming path:
+    same bit-exact result as the counting sort, including empty rows before, between and after the keys"""
+    from gaot_3d_amd import ops
+    ei = rand_graph(max(nr, 1) * 2, nr, e, seed=e + nr + 1, dtype=dtype)
+    order0 = torch.sort(ei[1], stable=True).indices
+    ei = ei[:, order0].contiguous()                                  # sorted by row 1 (query)
+    if nr > 8:
+        ei[1] = torch.clamp(ei[1], 3, nr - 3)                         # empty rows at both ends
+    for sort_row, rows in ((1, nr), (0, max(nr, 1) * 2)):            # sort_row 0 stays unsorted: general path
+        s = ops.csr_build(ei.to(DEV), sort_row, rows)
+        torch.cuda.synchronize()
+        key = ei[sort_row].long()
+        order = torch.sort(key, stable=True).indices
+        cnt = torch.bincount(key, minlength=rows)
+        rowptr = torch.zeros(rows + 1, dtype=torch.long)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        assert torch.equal(s.rowptr.cpu().long(), rowptr)
+        assert torch.equal(s.perm.cpu().long(), order)
+        assert torch.equal(s.key.cpu().long(), key[order])
+        assert torch.equal(s.other.cpu().long(), ei[1 - sort_row].long()[order])
+
+
 def _mlp_sd(layers, seed):
     g = torch.Generator().manual_seed(seed)
     sd = {}
