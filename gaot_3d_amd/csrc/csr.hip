@@ -4,16 +4,15 @@
 // torch_scatter-style segmented reductions (reference scatter_native.py:21-31) become contiguous
 // wavefront segmented sums with no atomics in the data path.
 //
-// Stable counting sort, all on device, no host sync:
-//   1. histogram of keys (int atomics, L2)         2. exclusive scan -> rowptr
-//   3. scatter edge ids through per-row cursors     4. per-row rank sort of the edge ids
-// Step 4 makes the order inside a row = original edge order, so every later floating-point
-// segmented sum is bit-reproducible run to run.
+// Stable sort by key, all on device, no host sync, no global atomics: LSD radix sort of (key, edge id)
+// with 6-8 bit digits (2-3 passes for 64 K-16 M rows), then one streaming pass that writes rowptr (from
+// the key changes), the permutation and the sorted copies.  The order inside a row = original edge
+// order, so every later floating-point segmented sum is bit-reproducible run to run.
 //
 // Fast path: neighbour searches emit their lists grouped by query, so one of the two orders a
 // bipartite graph needs is usually sorted already.  A first pass checks that on the device (no host
 // sync, graph-capturable); if the keys are non-decreasing the list IS its own stable sort: one
-// streaming pass writes rowptr / perm / the copies, and steps 1-4 return at their first instruction.
+// streaming pass writes rowptr / perm / the copies, and the sort kernels return at their first instruction.
 #include "common.h"
 
 namespace {
@@ -46,14 +45,6 @@ __global__ void k_sorted_build(const IDX* __restrict__ keys, const IDX* __restri
         if (i == E - 1)
             for (int64_t r = (int64_t)k + 1; r <= Q; ++r) rowptr[r] = (int)E;
     }
-}
-
-template <typename IDX>
-__global__ void k_hist(const IDX* __restrict__ keys, int64_t E, int* __restrict__ counts, const int* __restrict__ unsorted) {
-    if (!*unsorted) return;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < E; i += stride) atomicAdd(&counts[(int)keys[i]], 1);
 }
 
 // ---- 3-phase exclusive scan over n ints (n up to ~2^31) -------------------------------------
@@ -109,11 +100,10 @@ __global__ void k_scan_blocksums(int* __restrict__ block_sums, int nb) {
     }
 }
 
-// out[i] = exclusive prefix; also copies to cursor[i]; writes out[n] = total when i==n-1
+// out[i] = exclusive prefix; writes out[n] = total when i==n-1
 __global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* __restrict__ block_offs,
-                             int* __restrict__ out, int* __restrict__ cursor, const int* __restrict__ unsorted) {
+                             int* __restrict__ out) {
     __shared__ int wsum[SCAN_BLOCK / 64];
-    if (!*unsorted) return;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
@@ -138,111 +128,114 @@ __global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* _
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         if (base + j < n) {
             out[base + j] = run;
-            cursor[base + j] = run;
         }
         run += v[j];
         if (base + j == n - 1) out[n] = run;
     }
 }
 
+// ---- stable LSD radix sort of (key, edge id), 6-8 bit digits, 4096 keys per workgroup ----------------------
+// Per pass: per-workgroup digit histogram -> exclusive scan of the [digit][workgroup] table -> scatter with a
+// stable rank (ballot matching inside a wave round, per-wave running counts, waves in order).  No global atomics:
+// the result is the unique stable order, so every later fp32 segmented sum is bit-reproducible.
+constexpr int RS_TILE = 4096;
+constexpr int RS_ROUNDS = RS_TILE / 256;   // keys per thread
+
+template <typename KIN>
+__global__ __launch_bounds__(256) void k_rs_hist(const KIN* __restrict__ keys, int64_t E, int shift, int nd, int nblk,
+                                                 int* __restrict__ table, const int* __restrict__ unsorted) {
+    __shared__ int h[256];
+    if (!*unsorted) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < E) atomicAdd(&h[((int)keys[i] >> shift) & (nd - 1)], 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nd) table[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename KIN>
+__global__ __launch_bounds__(256) void k_rs_scatter(const KIN* __restrict__ keys_in, const int* __restrict__ ids_in,
+                                                    int64_t E, int shift, int nbits, int nblk,
+                                                    const int* __restrict__ table, int* __restrict__ keys_out,
+                                                    int* __restrict__ ids_out, const int* __restrict__ unsorted) {
+    __shared__ int wcnt[4][256];
+    if (!*unsorted) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nd = 1 << nbits;
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (RS_ROUNDS * 64);
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    int key[RS_ROUNDS], rnk[RS_ROUNDS];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const int64_t idx = base + j * 64 + lane;
+        const bool valid = idx < E;
+        const int k = valid ? (int)keys_in[idx] : 0;
+        const int d = (k >> shift) & (nd - 1);
+        unsigned long long m = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        const int r = __popcll(m & lt);
+        const int before = wcnt[wave][d];
+        rnk[j] = before + r;
+        key[j] = k;
+        if (valid && r == 0) wcnt[wave][d] = before + __popcll(m);   // the group's first lane; same-wave LDS ops stay in order
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nd) {
+        int run = table[(int64_t)threadIdx.x * nblk + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = wcnt[w][threadIdx.x];
+            wcnt[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+        const int64_t idx = base + j * 64 + lane;
+        if (idx < E) {
+            const int pos = wcnt[wave][(key[j] >> shift) & (nd - 1)] + rnk[j];
+            keys_out[pos] = key[j];
+            ids_out[pos] = ids_in ? ids_in[idx] : (int)idx;
+        }
+    }
+}
+
+// sorted (key, id) pairs -> rowptr / perm / key / other (general path; mirrors k_sorted_build)
 template <typename IDX>
-__global__ void k_fill(const IDX* __restrict__ keys, int64_t E, int* __restrict__ cursor, int* __restrict__ tmp,
-                       const int* __restrict__ unsorted) {
+__global__ void k_emit_sorted(const int* __restrict__ keys, const int* __restrict__ ids, const IDX* __restrict__ other,
+                              int64_t E, int64_t Q, const int* __restrict__ unsorted, int* __restrict__ rowptr,
+                              int* __restrict__ perm, int* __restrict__ key_sorted, int* __restrict__ other_sorted) {
     if (!*unsorted) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < E; i += stride) {
-        int p = atomicAdd(&cursor[(int)keys[i]], 1);
-        tmp[p] = (int)i;
+        const int k = keys[i], id = ids[i];
+        perm[i] = id;
+        key_sorted[i] = k;
+        other_sorted[i] = (int)other[id];
+        const int kprev = (i > 0) ? keys[i - 1] : -1;
+        for (int r = kprev + 1; r <= k; ++r) rowptr[r] = (int)i;
+        if (i == E - 1)
+            for (int64_t r = (int64_t)k + 1; r <= Q; ++r) rowptr[r] = (int)E;
     }
 }
 
-constexpr int HEAVY_DEG = 128;     // rows longer than this go to the block-wide LDS sort
-constexpr int BITONIC_MAX = 8192;  // ints in LDS (32 KB)
-
-template <typename IDX>
-__device__ __forceinline__ void emit_sorted(int p, int id, int64_t row, const IDX* __restrict__ other, int* perm,
-                                            int* key_sorted, int* other_sorted) {
-    perm[p] = id;
-    key_sorted[p] = (int)row;
-    other_sorted[p] = (int)other[id];
-}
-
-// Light rows: G lanes cooperate on one row with a rank sort of the (unique) edge ids -- O(n^2/G) L1 hits,
-// fine for short rows.  Rows longer than HEAVY_DEG are queued for k_row_sort_heavy instead.  G in {8, 64}.
-template <typename IDX, int G>
-__global__ void k_row_sort(const IDX* __restrict__ keys, const IDX* __restrict__ other, int64_t Q,
-                           const int* __restrict__ rowptr, const int* __restrict__ tmp, int* __restrict__ perm,
-                           int* __restrict__ key_sorted, int* __restrict__ other_sorted, int* __restrict__ heavy_count,
-                           int* __restrict__ heavy_list, const int* __restrict__ unsorted) {
-    if (!*unsorted) return;
-    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int gl = threadIdx.x % G;
-    if (gid >= Q) return;
-    const int b = rowptr[gid], e = rowptr[gid + 1];
-    const int n = e - b;
-    if (n > HEAVY_DEG) {
-        if (gl == 0) heavy_list[atomicAdd(heavy_count, 1)] = (int)gid;
-        return;
-    }
-    for (int i = gl; i < n; i += G) {
-        const int id = tmp[b + i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (tmp[b + j] < id) ? 1 : 0;
-        emit_sorted<IDX>(b + rank, id, gid, other, perm, key_sorted, other_sorted);
-    }
-}
-
-// Heavy rows: one workgroup per row (persistent over the queue).  n <= BITONIC_MAX: bitonic sort of the ids
-// in LDS (n log^2 n); longer rows: chunked rank sort against LDS-resident chunks.  Which block sorts which
-// row does not matter: the result (ascending edge id inside the row) is unique.
-template <typename IDX>
-__global__ __launch_bounds__(256) void k_row_sort_heavy(const IDX* __restrict__ other, const int* __restrict__ rowptr,
-                                                        const int* __restrict__ tmp, int* __restrict__ perm,
-                                                        int* __restrict__ key_sorted, int* __restrict__ other_sorted,
-                                                        const int* __restrict__ heavy_count,
-                                                        const int* __restrict__ heavy_list) {
-    __shared__ int sh[BITONIC_MAX];
-    const int nheavy = *heavy_count;
-    for (int w = blockIdx.x; w < nheavy; w += gridDim.x) {
-        const int row = heavy_list[w];
-        const int b = rowptr[row], n = rowptr[row + 1] - b;
-        __syncthreads();
-        if (n <= BITONIC_MAX) {
-            int np = 1;
-            while (np < n) np <<= 1;
-            for (int i = threadIdx.x; i < np; i += 256) sh[i] = (i < n) ? tmp[b + i] : 0x7fffffff;
-            __syncthreads();
-            for (int k = 2; k <= np; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = threadIdx.x; i < np; i += 256) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const int a = sh[i], c = sh[ixj];
-                            const bool up = (i & k) == 0;
-                            if ((a > c) == up) { sh[i] = c; sh[ixj] = a; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (int i = threadIdx.x; i < n; i += 256) emit_sorted<IDX>(b + i, sh[i], row, other, perm, key_sorted, other_sorted);
-        } else {
-            for (int t0 = 0; t0 < n; t0 += 256) {       // 256 targets per pass, one per thread
-                const int ti = t0 + threadIdx.x;
-                const int id = (ti < n) ? tmp[b + ti] : 0;
-                int rank = 0;
-                for (int c0 = 0; c0 < n; c0 += BITONIC_MAX) {
-                    const int cn = min(BITONIC_MAX, n - c0);
-                    __syncthreads();
-                    for (int i = threadIdx.x; i < cn; i += 256) sh[i] = tmp[b + c0 + i];
-                    __syncthreads();
-                    if (ti < n)
-                        for (int i = 0; i < cn; ++i) rank += (sh[i] < id) ? 1 : 0;
-                }
-                if (ti < n) emit_sorted<IDX>(b + rank, id, row, other, perm, key_sorted, other_sorted);
-            }
-        }
-    }
+static int rs_bits(int64_t Q) {
+    int b = 1;
+    while (((int64_t)1 << b) < Q) ++b;
+    return b;
 }
 
 template <typename IDX>
@@ -250,17 +243,18 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
                 int32_t* key_sorted, int32_t* other_sorted, void* ws, hipStream_t st) {
     const IDX* keys = edge_index + (sort_row ? E : 0);
     const IDX* other = edge_index + (sort_row ? 0 : E);
-    const int64_t n = Q;  // counts has Q entries (+1 slot for the total)
-    const int nb = (int)ceil_div(n, SCAN_TILE);
-    int* counts = (int*)ws;                 // [Q+1]
-    int* cursor = counts + (Q + 1);         // [Q+1]
-    int* bsum = cursor + (Q + 1);           // [nb+1]
-    int* tmp = bsum + (nb + 1);             // [E]
-    int* heavy_count = tmp + E;             // [1] (+3 pad)
-    int* heavy_list = heavy_count + 4;      // [<= E / HEAVY_DEG + 1]
-    int* unsorted = heavy_count + 1;        // cleared together with heavy_count
-    (void)hipMemsetAsync(counts, 0, sizeof(int) * (size_t)(Q + 1), st);
-    (void)hipMemsetAsync(heavy_count, 0, sizeof(int) * 4, st);
+    const int nblk = (int)ceil_div(E, RS_TILE);
+    const int64_t tn = (int64_t)256 * nblk;              // [digit][workgroup] table, sized for 8-bit digits
+    int* flags = (int*)ws;                  // [4]: flags[1] = unsorted
+    int* unsorted = flags + 1;
+    int* kbuf0 = flags + 4;                 // [E] x4: key / id ping-pong
+    int* kbuf1 = kbuf0 + E;
+    int* ibuf0 = kbuf1 + E;
+    int* ibuf1 = ibuf0 + E;
+    int* table = ibuf1 + E;                 // [tn + 1]
+    int* tscan = table + tn + 1;            // [tn + 1]
+    int* bsum = tscan + tn + 1;             // [nbt + 1]
+    (void)hipMemsetAsync(flags, 0, sizeof(int) * 4, st);
     if (E == 0) {
         (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
         return GAOT_OK;
@@ -270,30 +264,46 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     hipLaunchKernelGGL((k_check_sorted<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, unsorted);
     hipLaunchKernelGGL((k_sorted_build<IDX>), dim3(gb), dim3(tb), 0, st, keys, other, E, Q, unsorted, rowptr, perm,
                        key_sorted, other_sorted);
-    hipLaunchKernelGGL((k_hist<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, counts, unsorted);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, counts, n, bsum, rowptr, cursor, unsorted);
-    hipLaunchKernelGGL((k_fill<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, cursor, tmp, unsorted);
-    if (E / (Q > 0 ? Q : 1) >= 16) {
-        const int64_t threads = Q * 64;
-        hipLaunchKernelGGL((k_row_sort<IDX, 64>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list, unsorted);
-    } else {
-        const int64_t threads = Q * 8;
-        hipLaunchKernelGGL((k_row_sort<IDX, 8>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, keys, other,
-                           Q, rowptr, tmp, perm, key_sorted, other_sorted, heavy_count, heavy_list, unsorted);
+    // general path (every kernel returns at once when the keys were sorted)
+    const int bits = rs_bits(Q);
+    const int passes = (bits + 7) / 8;
+    const int width = (bits + passes - 1) / passes;
+    const int* kin = nullptr;
+    const int* iin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * width;
+        const int nd = 1 << width;
+        int* kout = (p & 1) ? kbuf1 : kbuf0;
+        int* iout = (p & 1) ? ibuf1 : ibuf0;
+        const int64_t n = (int64_t)nd * nblk;
+        const int nb = (int)ceil_div(n, SCAN_TILE);
+        if (p == 0) hipLaunchKernelGGL((k_rs_hist<IDX>), dim3(nblk), dim3(256), 0, st, keys, E, shift, nd, nblk, table, unsorted);
+        else hipLaunchKernelGGL((k_rs_hist<int>), dim3(nblk), dim3(256), 0, st, kin, E, shift, nd, nblk, table, unsorted);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum, tscan);
+        if (p == 0)
+            hipLaunchKernelGGL((k_rs_scatter<IDX>), dim3(nblk), dim3(256), 0, st, keys, (const int*)nullptr, E, shift, width,
+                               nblk, tscan, kout, iout, unsorted);
+        else
+            hipLaunchKernelGGL((k_rs_scatter<int>), dim3(nblk), dim3(256), 0, st, kin, iin, E, shift, width, nblk, tscan,
+                               kout, iout, unsorted);
+        kin = kout;
+        iin = iout;
     }
-    hipLaunchKernelGGL((k_row_sort_heavy<IDX>), dim3(1024), dim3(256), 0, st, other, rowptr, tmp, perm, key_sorted,
-                       other_sorted, heavy_count, heavy_list);
+    hipLaunchKernelGGL((k_emit_sorted<IDX>), dim3(gb), dim3(tb), 0, st, kin, iin, other, E, Q, unsorted, rowptr, perm,
+                       key_sorted, other_sorted);
     return GAOT_OK;
 }
 
 }  // namespace
 
 extern "C" size_t gaot_csr_workspace_bytes(int64_t num_edges, int64_t num_rows) {
-    const int64_t nb = ceil_div(num_rows, SCAN_TILE);
-    return sizeof(int) * (size_t)(2 * (num_rows + 1) + (nb + 1) + num_edges + 4 + num_edges / HEAVY_DEG + 1) + 64;
+    (void)num_rows;
+    const int64_t nblk = ceil_div(num_edges, RS_TILE);
+    const int64_t tn = 256 * nblk;
+    const int64_t nbt = ceil_div(tn, SCAN_TILE);
+    return sizeof(int) * (size_t)(4 + 4 * num_edges + 2 * (tn + 1) + nbt + 1) + 64;
 }
 
 extern "C" int gaot_csr_build(const void* edge_index, int index_is_i64, int64_t num_edges, int sort_row,

@@ -44,7 +44,7 @@ def rand_graph(n_src, n_dst, e, seed, empty_rows=True, heavy=True, dtype=torch.i
 
 
 @pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
-@pytest.mark.parametrize("e,nr", [(0, 5), (1, 1), (1000, 37), (50000, 4096), (200000, 70000)])
+@pytest.mark.parametrize("e,nr", [(0, 5), (1, 1), (1000, 37), (50000, 4096), (200000, 70000), (5000, 20_000_000)])
 def test_csr_build(dtype, e, nr):
     from gaot_3d_amd import ops
     ei = rand_graph(max(nr, 1) * 2, nr, e, seed=e + nr, dtype=dtype)
