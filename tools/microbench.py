@@ -46,12 +46,14 @@ if what == "attn":
         timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, b, s, h, h, 32 ** -0.5), "attn_bwd_f32", 4 * att)
 elif what == "gemm":
     m = 16384
-    for (n, k) in ((256, 256), (1024, 256), (256, 1024), (256, 512)):
+    for (n, k) in ((768, 256), (256, 256), (2048, 256), (256, 1024), (256, 512)):
         x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev); dy = torch.randn(m, n, device=dev)
         fl = 2 * m * n * k
         timeit(lambda: ops.gemm(x, w, m, n, k, k, k, False, True), f"fwd  x[{m},{k}] W[{n},{k}]^T", fl)
         timeit(lambda: ops.gemm(dy, w, m, k, n, n, k, False, False), f"dx   dy[{m},{n}] W[{n},{k}]", fl)
         timeit(lambda: ops.gemm(dy, x, n, k, m, n, k, True, False), f"dW   dy^T[{n},{m}] x[{m},{k}]", fl)
+        mb = (m * k + m * n + n * k) * 4 / 1e6
+        print(f"     (operand + result bytes {mb:.0f} MB -> {mb / 5e3 * 1e3:.1f} us at 5 TB/s)")
 elif what == "gno":
     from gaot_3d_amd.data import make_synthetic_sample
     batch, tokens = make_synthetic_sample(500000, (64, 64, 32), k=8, seed=0, device=dev)
