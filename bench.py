@@ -105,9 +105,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
+    # GAOT_BENCH_ONE_DEVICE=1 (testing only): every rank on cuda:0 over gloo, to exercise the N>1 code path -- sharding,
+    # exchange steps, max-over-ranks timing -- on a single-GPU box.  The number it prints is not a scaling result.
+    one_device = os.environ.get("GAOT_BENCH_ONE_DEVICE", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if one_device else "nccl", init_method="env://")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

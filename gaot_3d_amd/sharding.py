@@ -137,6 +137,7 @@ class ShardedStep:
         self.n_total = n_total
         self.partial = partial_grad_parameters(model)
         model.encoder._shard_group = group
+        model.decoder._shard_group = group
         model._shard_group = group
 
     def forward_backward(self, batch: MeshBatch, tokens_pos: Optional[Tensor]):
