@@ -47,6 +47,8 @@ SIGNATURES = {
     "gaot_geoembed_stats": (_i, [_p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "gaot_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
+    "gaot_gemm_ex": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p, _i, _p,
+                          _sz, _p]),
     "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
     "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "gaot_rope": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _p, _i, _p]),
     "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
+    "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
     "gaot_patchify": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -84,7 +88,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 1:
+    if lib.gaot_abi_version() != 2:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -285,10 +285,10 @@ struct GemmPlan {
     int splits;
     int64_t kps;
 };
-int gaot_gemm_bf16_dispatch(const float* A, const float* B, float* C, float* preact, const float* bias,
+int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact, const float* bias,
                             const float* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                             int64_t ldc, int64_t ldr, int a_trans, int b_trans, int act, int splits, int64_t kps,
-                            int a_vec, int b_vec, hipStream_t st);
+                            int a_vec, int b_vec, int dt, hipStream_t st);
 
 static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
     GemmPlan p;
@@ -312,25 +312,29 @@ extern "C" size_t gaot_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return p.splits > 1 ? sizeof(float) * (size_t)(p.splits * M * N) + 64 : 0;
 }
 
-extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                         int64_t ldb, int64_t ldc, int a_trans, int b_trans, const float* bias, int act,
-                         const float* residual, int64_t ldr, float* preact, int precision, void* workspace,
-                         size_t workspace_bytes, gaot_stream_t stream) {
-    GAOT_ENTER();
+static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                     int64_t ldc, int a_trans, int b_trans, int dt, const float* bias, int act, const float* residual,
+                     int64_t ldr, float* preact, int precision, void* workspace, size_t workspace_bytes,
+                     gaot_stream_t stream) {
     GAOT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     GAOT_CHECK_ARG(act >= 0 && act <= 3, "bad activation id");
     GAOT_CHECK_ARG(precision == 0 || precision == 1, "precision must be 0 (fp32) or 1 (bf16 operands)");
     if (M == 0 || N == 0) return GAOT_OK;
     GAOT_CHECK_ARG(A && B && C, "null pointer");
     hipStream_t st = (hipStream_t)stream;
+    const int ea = (dt & 1) ? 8 : 4, eb = (dt & 2) ? 8 : 4;   // elements per 16-byte chunk
+    const int a_vec = (lda % ea == 0) && (((uintptr_t)A & 15) == 0);
+    const int b_vec = (ldb % eb == 0) && (((uintptr_t)B & 15) == 0);
+    const bool wide_bf16 = precision == 1 && N > 64;
+    if (dt && !wide_bf16) {
+        gaot_set_error("gemm: bf16 operands in memory are implemented by the bf16 matrix-core kernel only (precision 1, N > 64)");
+        return GAOT_ERR_UNSUPPORTED;
+    }
     GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.preact = preact; g.bias = bias; g.residual = residual;
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C; g.preact = preact; g.bias = bias; g.residual = residual;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.act = act; g.splits = 1; g.k_per_split = K;
-    const int a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
-    const int b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
 
-    const bool wide_bf16 = precision == 1 && N > 64;
     const GemmPlan p = plan_gemm(M, N, K, wide_bf16 ? 64 : BK);
     GemmArgs gk = g;
     float* part = (float*)workspace;
@@ -341,8 +345,8 @@ extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, in
         gk.C = part;
     }
     if (wide_bf16) {
-        int rc = gaot_gemm_bf16_dispatch(A, B, gk.C, preact, bias, residual, M, N, K, lda, ldb, ldc, ldr, a_trans, b_trans,
-                                         act, gk.splits, gk.k_per_split, a_vec, b_vec, st);
+        int rc = gaot_gemm_bf16_dispatch(A, B, gk.splits > 1 ? (void*)part : C, preact, bias, residual, M, N, K, lda, ldb, ldc,
+                                         ldr, a_trans, b_trans, act, gk.splits, gk.k_per_split, a_vec, b_vec, dt, st);
         if (rc != GAOT_OK) return rc;
     } else if (p.cfg == 0) launch_cfg<4, 1, 1, 1>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else if (p.cfg == 1) launch_cfg<4, 1, 1, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
@@ -352,4 +356,23 @@ extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, in
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
+}
+
+extern "C" int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                         int64_t ldb, int64_t ldc, int a_trans, int b_trans, const float* bias, int act,
+                         const float* residual, int64_t ldr, float* preact, int precision, void* workspace,
+                         size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, a_trans, b_trans, 0, bias, act, residual, ldr, preact, precision,
+                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                            int64_t ldb, int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int c_bf16,
+                            const float* bias, int act, const float* residual, int64_t ldr, float* preact, int precision,
+                            void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    const int dt = (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0) | (c_bf16 ? 4 : 0);
+    return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, a_trans, b_trans, dt, bias, act, residual, ldr, preact, precision,
+                     workspace, workspace_bytes, stream);
 }

@@ -21,7 +21,7 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
 struct GArgs {
-    const float* A; const float* B; float* C; float* preact; const float* bias; const float* residual;
+    const void* A; const void* B; void* C; float* preact; const float* bias; const float* residual;
     int64_t M, N, K, lda, ldb, ldc, ldr;
     int act, splits;
     int64_t k_per_split;
@@ -175,10 +175,62 @@ struct VTile : Tile<KS, ROWS> {
     }
 };
 
-template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC>
+// The same tile for an operand that already IS bf16 in memory (an activation written by a previous kernel of the
+// bf16 path): half the bytes per element on the way in, no conversion, 16-byte LDS stores.  8 elements per 16-B
+// chunk: rows / k-rows must be multiples of 8 elements and 16-byte aligned.
+template <bool KS, int ROWS>
+struct VTile16 : Tile<KS, ROWS> {
+    using Base = Tile<KS, ROWS>;
+    static constexpr int NV = ROWS / 32;       // 16-B chunks per thread per tile
+    static constexpr int CPR = ROWS / 8;       // KS: chunks per k-row
+    static constexpr int KR = 256 / CPR;       // KS: k-rows covered by one pass of the 256 threads
+    __amdgpu_buffer_rsrc_t rs;
+    int voff, ld2, kk;
+    uint4 r16[NV];
+
+    __device__ __forceinline__ void setup(const void* __restrict__ Xv, int64_t ld, int64_t row0, int64_t nrows, int64_t K) {
+        const unsigned short* X = (const unsigned short*)Xv;
+        const unsigned short* base = KS ? X + row0 : X + row0 * ld;
+        int64_t bytes = KS ? ((K - 1) * ld + (nrows - row0)) * 2 : ((nrows - row0 - 1) * ld + K) * 2;
+        bytes = bytes < 0 ? 0 : (bytes > 0x7fffffff ? 0x7fffffff : bytes);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+        ld2 = (int)ld * 2;
+        if (!KS) {
+            kk = 8 * (threadIdx.x & 7);
+            voff = (threadIdx.x >> 3) * ld2 + kk * 2;
+        } else {
+            kk = threadIdx.x / CPR;
+            voff = kk * ld2 + (threadIdx.x % CPR) * 16;
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kend) {
+        if (!KS) {
+            const int vo = (k0 + kk < kend) ? voff : (int)0x80000000;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                r16[v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, v * 32 * ld2 + k0 * 2, 0));
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int vo = (k0 + v * KR + kk < kend) ? voff : (int)0x80000000;
+                r16[v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (k0 + v * KR) * ld2, 0));
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!KS) *reinterpret_cast<uint4*>(lds + ((threadIdx.x >> 3) + v * 32) * Base::PITCH + (threadIdx.x & 7) * 16) = r16[v];
+            else *reinterpret_cast<uint4*>(lds + (kk + v * KR) * Base::PITCH + (threadIdx.x % CPR) * 16) = r16[v];
+        }
+    }
+};
+
+template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC, bool A16 = false, bool B16 = false, bool C16 = false>
 __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int b_vec) {
-    using TA = typename std::conditional<VEC, VTile<A_KS, BM>, Tile<A_KS, BM>>::type;
-    using TB = typename std::conditional<VEC, VTile<B_KS, BN>, Tile<B_KS, BN>>::type;
+    static_assert(VEC || !(A16 || B16), "bf16 operands in memory only on the buffer-addressed path");
+    using TA = typename std::conditional<A16, VTile16<A_KS, BM>, typename std::conditional<VEC, VTile<A_KS, BM>, Tile<A_KS, BM>>::type>::type;
+    using TB = typename std::conditional<B16, VTile16<B_KS, BN>, typename std::conditional<VEC, VTile<B_KS, BN>, Tile<B_KS, BN>>::type>::type;
     constexpr int MT = BM / 64;   // 32-row MFMA tiles per wave along M (waves are 2 x 2)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* la = lds;
@@ -203,15 +255,17 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
     TA ta;
     TB tb;
     if constexpr (VEC) {
-        ta.setup(g.A, g.lda, bm, g.M, g.K);
-        tb.setup(g.B, g.ldb, bn, g.N, g.K);
+        if constexpr (A16) ta.setup(g.A, g.lda, bm, g.M, g.K);
+        else ta.setup((const float*)g.A, g.lda, bm, g.M, g.K);
+        if constexpr (B16) tb.setup(g.B, g.ldb, bn, g.N, g.K);
+        else tb.setup((const float*)g.B, g.ldb, bn, g.N, g.K);
         if (kbeg < kend) {
             ta.load((int)kbeg, (int)kend);
             tb.load((int)kbeg, (int)kend);
         }
     } else if (kbeg < kend) {
-        ta.load(g.A, g.lda, bm, g.M, kbeg, kend, a_vec);
-        tb.load(g.B, g.ldb, bn, g.N, kbeg, kend, b_vec);
+        ta.load((const float*)g.A, g.lda, bm, g.M, kbeg, kend, a_vec);
+        tb.load((const float*)g.B, g.ldb, bn, g.N, kbeg, kend, b_vec);
     }
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         ta.store(la);
@@ -222,8 +276,8 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
                 ta.load((int)k0 + BK, (int)kend);
                 tb.load((int)k0 + BK, (int)kend);
             } else {
-                ta.load(g.A, g.lda, bm, g.M, k0 + BK, kend, a_vec);
-                tb.load(g.B, g.ldb, bn, g.N, k0 + BK, kend, b_vec);
+                ta.load((const float*)g.A, g.lda, bm, g.M, k0 + BK, kend, a_vec);
+                tb.load((const float*)g.B, g.ldb, bn, g.N, k0 + BK, kend, b_vec);
             }
         }
 #pragma unroll
@@ -261,22 +315,23 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
                 if (m >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.splits > 1) {
-                    g.C[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                    ((float*)g.C)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
                 } else {
                     v += bv;
                     if (g.preact) g.preact[m * g.ldc + n] = v;
                     v = act_apply(v, g.act);
                     if (g.residual) v += g.residual[m * g.ldr + n];
-                    g.C[m * g.ldc + n] = v;
+                    if constexpr (C16) ((bf16_t*)g.C)[m * g.ldc + n] = __builtin_bit_cast(bf16_t, (__bf16)v);
+                    else ((float*)g.C)[m * g.ldc + n] = v;
                 }
             }
         }
 }
 
-template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC>
+template <bool A_KS, bool B_KS, int BM, bool VEC, int OCC, bool A16 = false, bool B16 = false, bool C16 = false>
 int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
     const size_t lds = Tile<A_KS, BM>::BYTES + Tile<B_KS, BN>::BYTES;
-    auto kern = k_gemm_bf16<A_KS, B_KS, BM, VEC, OCC>;
+    auto kern = k_gemm_bf16<A_KS, B_KS, BM, VEC, OCC, A16, B16, C16>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -292,21 +347,34 @@ int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) 
 }
 
 template <bool A_KS, bool B_KS>
-int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
+int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t st) {
     // fewer than two 128x128 workgroups per CU: halve the tile height so that twice as many workgroups hide latency
     const int64_t blocks128 = ceil_div(g.N, BN) * ceil_div(g.M, 128) * splits;
     static const int thr = getenv("GAOT_GEMM_THR") ? atoi(getenv("GAOT_GEMM_THR")) : 2100;
     const bool small = blocks128 < thr && g.M > 64;
-    // buffer-addressed tiles need 16-byte aligned rows, whole float4s along k and 31-bit byte offsets inside a tile
+    // buffer-addressed tiles need 16-byte aligned rows, whole 16-byte chunks along k and 31-bit byte offsets inside a tile
     const int64_t span_a = (A_KS ? g.K : 128) * g.lda * 4, span_b = (B_KS ? g.K : 128) * g.ldb * 4;
-    const bool vec = a_vec && b_vec && g.K % 4 == 0 && span_a < 0x7fffffff && span_b < 0x7fffffff;
-    static const int occ = getenv("GAOT_GEMM_OCC") ? atoi(getenv("GAOT_GEMM_OCC")) : 2;
-    if (vec) {
-        if (small) {
-            if (occ == 4) return launch_bm<A_KS, B_KS, 64, true, 4>(g, a_vec, b_vec, splits, st);
-            if (occ == 3) return launch_bm<A_KS, B_KS, 64, true, 3>(g, a_vec, b_vec, splits, st);
-            return launch_bm<A_KS, B_KS, 64, true, 2>(g, a_vec, b_vec, splits, st);
+    const bool k4 = (!A_KS && !(dt & 1)) || (!B_KS && !(dt & 2));   // an fp32 operand read in float4s along k
+    const bool vec = a_vec && b_vec && (!k4 || g.K % 4 == 0) && span_a < 0x7fffffff && span_b < 0x7fffffff;
+    if (dt) {   // some operand / the result is bf16 in memory (dt bits: 1 = A, 2 = B, 4 = C): 64-row tiles only
+        const bool k8 = ((dt & 1) && !A_KS) || ((dt & 2) && !B_KS);   // a bf16 operand whose 16-byte chunks run along k
+        if (!vec || (k8 && g.K % 8 != 0) || ((dt & 4) && splits > 1)) {
+            gaot_set_error("gemm: bf16 operands need 16-byte aligned rows, K %% 8 == 0 along contiguous k, and no split-K result");
+            return GAOT_ERR_UNSUPPORTED;
         }
+        switch (dt) {
+            case 1: return launch_bm<A_KS, B_KS, 64, true, 2, true, false, false>(g, a_vec, b_vec, splits, st);
+            case 2: return launch_bm<A_KS, B_KS, 64, true, 2, false, true, false>(g, a_vec, b_vec, splits, st);
+            case 3: return launch_bm<A_KS, B_KS, 64, true, 2, true, true, false>(g, a_vec, b_vec, splits, st);
+            case 4: return launch_bm<A_KS, B_KS, 64, true, 2, false, false, true>(g, a_vec, b_vec, splits, st);
+            case 5: return launch_bm<A_KS, B_KS, 64, true, 2, true, false, true>(g, a_vec, b_vec, splits, st);
+            default:
+                gaot_set_error("gemm: unsupported bf16 operand combination %d", dt);
+                return GAOT_ERR_UNSUPPORTED;
+        }
+    }
+    if (vec) {
+        if (small) return launch_bm<A_KS, B_KS, 64, true, 2>(g, a_vec, b_vec, splits, st);
         return launch_bm<A_KS, B_KS, 128, true, 2>(g, a_vec, b_vec, splits, st);
     }
     if (small) return launch_bm<A_KS, B_KS, 64, false, 2>(g, a_vec, b_vec, splits, st);
@@ -315,16 +383,17 @@ int launch(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) {
 
 }  // namespace
 
-// called by gaot_gemm (gemm.hip) for precision == 1 when the output is wide enough for the 128x128 tile
-int gaot_gemm_bf16_dispatch(const float* A, const float* B, float* C, float* preact, const float* bias,
+// called by gaot_gemm / gaot_gemm_ex (gemm.hip) for precision == 1 when the output is wide enough for the 128-wide tile.
+// dt: bit 0 = A is bf16 in memory, bit 1 = B, bit 2 = C (leading dimensions always in elements).
+int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact, const float* bias,
                             const float* residual, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                             int64_t ldc, int64_t ldr, int a_trans, int b_trans, int act, int splits, int64_t kps,
-                            int a_vec, int b_vec, hipStream_t st) {
+                            int a_vec, int b_vec, int dt, hipStream_t st) {
     GArgs g{A, B, C, preact, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, splits, kps};
     const bool a_ks = a_trans != 0;   // A(m,k) = A[k*lda + m]
     const bool b_ks = b_trans == 0;   // B(k,n) = B[k*ldb + n]
-    if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, st);
-    if (!a_ks && b_ks) return launch<false, true>(g, a_vec, b_vec, splits, st);
-    if (a_ks && !b_ks) return launch<true, false>(g, a_vec, b_vec, splits, st);
-    return launch<true, true>(g, a_vec, b_vec, splits, st);
+    if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, dt, st);
+    if (!a_ks && b_ks) return launch<false, true>(g, a_vec, b_vec, splits, dt, st);
+    if (a_ks && !b_ks) return launch<true, false>(g, a_vec, b_vec, splits, dt, st);
+    return launch<true, true>(g, a_vec, b_vec, splits, dt, st);
 }

@@ -195,6 +195,59 @@ __global__ void k_swiglu_bwd(const float* __restrict__ ag, const float* __restri
     reinterpret_cast<float4*>(dag + r * 2 * F + F)[c] = dg;
 }
 
+// bf16-in-memory variants (the FFN intermediates of the bf16 path): 8 elements per thread, fp32 arithmetic
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f[2 * i]) |
+               ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ void k_swiglu_fwd_bf16(const unsigned short* __restrict__ ag, unsigned short* __restrict__ u, int64_t rows, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte chunk index
+    const int fv = F / 8;
+    if (i >= rows * fv) return;
+    const int64_t r = i / fv;
+    const int c = (int)(i % fv);
+    float a[8], g[8], o[8];
+    unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F)[c], a);
+    unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F + F)[c], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = a[j] * sigmoid_f(a[j]) * g[j];
+    reinterpret_cast<uint4*>(u + r * F)[c] = pack8(o);
+}
+
+__global__ void k_swiglu_bwd_bf16(const unsigned short* __restrict__ ag, const unsigned short* __restrict__ du,
+                                  unsigned short* __restrict__ dag, int64_t rows, int F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int fv = F / 8;
+    if (i >= rows * fv) return;
+    const int64_t r = i / fv;
+    const int c = (int)(i % fv);
+    float a[8], g[8], d[8], da[8], dg[8];
+    unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F)[c], a);
+    unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F + F)[c], g);
+    unpack8(reinterpret_cast<const uint4*>(du + r * F)[c], d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float s = sigmoid_f(a[j]);
+        da[j] = d[j] * g[j] * s * (1.f + a[j] * (1.f - s));
+        dg[j] = d[j] * a[j] * s;
+    }
+    reinterpret_cast<uint4*>(dag + r * 2 * F)[c] = pack8(da);
+    reinterpret_cast<uint4*>(dag + r * 2 * F + F)[c] = pack8(dg);
+}
+
 // dz = dh * act'(z)
 __global__ void k_act_bwd(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n,
                           int act) {
@@ -428,6 +481,30 @@ extern "C" int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int
     GAOT_CHECK_ARG(ag && du && dag, "null pointer");
     hipLaunchKernelGGL(k_swiglu_bwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, du, dag,
                        rows, F);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 8 == 0, "F must be a positive multiple of 8");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(ag && u, "null pointer");
+    GAOT_CHECK_ARG((((uintptr_t)ag | (uintptr_t)u) & 15) == 0, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_swiglu_fwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)ag, (unsigned short*)u, rows, F);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 8 == 0, "F must be a positive multiple of 8");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(ag && du && dag, "null pointer");
+    GAOT_CHECK_ARG((((uintptr_t)ag | (uintptr_t)du | (uintptr_t)dag) & 15) == 0, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_swiglu_bwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)ag, (const unsigned short*)du, (unsigned short*)dag, rows, F);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -176,6 +176,58 @@ class SwiGLUFn(Function):
         return ops.swiglu_bwd(ag, d, ctx.f), None
 
 
+class FFNFn(Function):
+    """w2(silu(w1 x) * w3 x) [+ residual] (reference FFN.forward, attn.py:150-157) for the bf16 path with the
+    intermediates kept as bf16 in memory: [rows, 2F] = w1 x | w3 x, silu(a)*g and both of their gradients are written
+    once as bf16 by their producer (GEMM epilogue / SwiGLU kernel) and read as bf16 by their consumers -- they are the
+    widest tensors of a block (134 MB each as fp32 at S = 16 384, F = 1024) and every GEMM that touches them rounds them
+    to bf16 anyway.  Needs w1 | w3 co-located (one [2F, d] matrix)."""
+
+    @staticmethod
+    def eligible(x: Tensor, w1: Tensor, w3: Tensor, w2: Tensor) -> bool:
+        f, d = w1.shape
+        return (ops.get_precision() == "bf16" and x.is_cuda and d > 64 and d % 8 == 0 and f % 8 == 0 and 2 * f > 64
+                and w3.shape == w1.shape and tuple(w2.shape) == (d, f) and _adjacent([_w2d(w1), _w2d(w3)])
+                and all(t.requires_grad for t in (w1, w3, w2)))
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, w3: Tensor, w2: Tensor, residual: Optional[Tensor]):
+        f, d = w1.shape
+        x2 = x.reshape(-1, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        m = x2.shape[0]
+        wcat = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1))
+        w2c = _w2d(w2)
+        ag = ops.gemm(x2, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+        u = ops.swiglu_fwd_bf16(ag, f)
+        res = None
+        if residual is not None:
+            res = residual.reshape(m, d)
+            if not res.is_contiguous():
+                res = res.contiguous()
+        y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
+        ctx.save_for_backward(x2, wcat, w2c, ag, u)
+        ctx.meta = (f, d, x.shape, residual.shape if residual is not None else None, w1.shape, w2.shape)
+        return y.view(*x.shape[:-1], d)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, wcat, w2c, ag, u = ctx.saved_tensors
+        f, d, xshape, rshape, w1shape, w2shape = ctx.meta
+        m = x2.shape[0]
+        dy2 = dy.reshape(m, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
+        dw2 = ops.gemm(dy2, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
+        dag = ops.swiglu_bwd_bf16(ag, du, f)
+        dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, precision=1).view(xshape) if ctx.needs_input_grad[0] else None
+        dwcat = ops.gemm(dag, x2, 2 * f, d, m, 2 * f, d, True, False, precision=1)
+        dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
+        return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres
+
+
 class AddFn(Function):
     """a + b (b optionally broadcast over leading rows with `period` elements)."""
 

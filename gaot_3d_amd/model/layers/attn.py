@@ -119,6 +119,8 @@ class FFN(nn.Module):
         """``residual`` (extension): added inside the w2 GEMM epilogue (the block's `h + ffn(h)`)."""
         shp = x.shape
         GF.colocate([self.w1.weight, self.w3.weight])
+        if GF.FFNFn.eligible(x, self.w1.weight, self.w3.weight, self.w2.weight):   # bf16 path: bf16 intermediates
+            return GF.FFNFn.apply(x, self.w1.weight, self.w3.weight, self.w2.weight, residual)
         ag = GF.multi_linear(x, [self.w1.weight, self.w3.weight])   # [rows, 2F] = [w1 x | w3 x]
         u = GF.SwiGLUFn.apply(ag, self.hidden)
         res = None if residual is None else residual.reshape(-1, residual.shape[-1])

@@ -214,12 +214,13 @@ ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3}
 def gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_trans: bool, b_trans: bool,
          bias: Optional[Tensor] = None, act: int = 0, residual: Optional[Tensor] = None, ldr: int = 0,
          want_preact: bool = False, out: Optional[Tensor] = None, ldc: Optional[int] = None,
-         precision: Optional[int] = None):
-    """Raw GEMM on 2-D row-major fp32 buffers (see include/gaot3d_hip.h: gaot_gemm)."""
+         precision: Optional[int] = None, out_dtype: torch.dtype = torch.float32):
+    """Raw GEMM on 2-D row-major buffers (see include/gaot3d_hip.h: gaot_gemm / gaot_gemm_ex).  Operands are fp32;
+    a bf16 tensor (an FFN intermediate of the bf16 path) is passed through as bf16-in-memory."""
     lib = _lib.load()
     dev = a.device
     if out is None:
-        out = torch.empty(m, n, dtype=torch.float32, device=dev)
+        out = torch.empty(m, n, dtype=out_dtype, device=dev)
         ldc = n
     pre = torch.empty(m, n, dtype=torch.float32, device=dev) if want_preact else None
     if want_preact and ldc != n:
@@ -227,9 +228,15 @@ def gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_tra
     nb = lib.gaot_gemm_workspace_bytes(m, n, k)
     ws = _ws(nb, dev) if nb else None
     prec = _PRECISION["mode"] if precision is None else precision
-    check(lib.gaot_gemm(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, ldc, int(a_trans), int(b_trans), _ptr(bias),
-                        act, _ptr(residual), ldr, _ptr(pre), prec, _ptr(ws), ws.numel() if ws is not None else 0,
-                        _stream()), "gaot_gemm")
+    a16, b16, c16 = a.dtype == torch.bfloat16, b.dtype == torch.bfloat16, out.dtype == torch.bfloat16
+    if a16 or b16 or c16:
+        check(lib.gaot_gemm_ex(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, ldc, int(a_trans), int(b_trans), int(a16),
+                               int(b16), int(c16), _ptr(bias), act, _ptr(residual), ldr, _ptr(pre), prec, _ptr(ws),
+                               ws.numel() if ws is not None else 0, _stream()), "gaot_gemm_ex")
+    else:
+        check(lib.gaot_gemm(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, ldc, int(a_trans), int(b_trans), _ptr(bias),
+                            act, _ptr(residual), ldr, _ptr(pre), prec, _ptr(ws), ws.numel() if ws is not None else 0,
+                            _stream()), "gaot_gemm")
     return (out, pre) if want_preact else out
 
 
@@ -355,6 +362,21 @@ def swiglu_bwd(ag: Tensor, du: Tensor, f: int) -> Tensor:
     lib = _lib.load()
     dag = torch.empty_like(ag)
     check(lib.gaot_swiglu_bwd(_ptr(ag), _ptr(du), _ptr(dag), ag.shape[0], f, _stream()), "gaot_swiglu_bwd")
+    return dag
+
+
+def swiglu_fwd_bf16(ag: Tensor, f: int) -> Tensor:
+    """bf16 [rows, 2F] -> bf16 [rows, F]"""
+    lib = _lib.load()
+    u = torch.empty(ag.shape[0], f, dtype=torch.bfloat16, device=ag.device)
+    check(lib.gaot_swiglu_fwd_bf16(_ptr(ag), _ptr(u), ag.shape[0], f, _stream()), "gaot_swiglu_fwd_bf16")
+    return u
+
+
+def swiglu_bwd_bf16(ag: Tensor, du: Tensor, f: int) -> Tensor:
+    lib = _lib.load()
+    dag = torch.empty_like(ag)
+    check(lib.gaot_swiglu_bwd_bf16(_ptr(ag), _ptr(du), _ptr(dag), ag.shape[0], f, _stream()), "gaot_swiglu_bwd_bf16")
     return dag
 
 

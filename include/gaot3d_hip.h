@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 1
+#define GAOT_ABI_VERSION 2
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -111,6 +111,15 @@ size_t gaot_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
               int64_t ldc, int a_trans, int b_trans, const float* bias, int act, const float* residual, int64_t ldr,
               float* preact, int precision, void* workspace, size_t workspace_bytes, gaot_stream_t stream);
+/* gaot_gemm with operands / result that already ARE bf16 in memory (a_bf16 / b_bf16 / c_bf16 != 0; leading dimensions
+ * in elements): the FFN intermediates of the bf16 path ([rows, 2F] = w1 x | w3 x, silu(a)*g, and their gradients,
+ * reference attn.py:156) are written once as bf16 by their producer and never exist as fp32 in HBM.  precision must
+ * be 1 and N > 64; rows must be 16-byte aligned and K a multiple of 8; a bf16 result excludes split-K.  Supported
+ * combinations: A, B, A+B, C, A+C; anything else returns GAOT_ERR_UNSUPPORTED. */
+int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                 int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int c_bf16, const float* bias, int act,
+                 const float* residual, int64_t ldr, float* preact, int precision, void* workspace,
+                 size_t workspace_bytes, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention: softmax(Q K^T * scale) V per head, no mask, no dropout (reference
@@ -165,6 +174,9 @@ int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head
               int inverse, gaot_stream_t stream);
 int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, gaot_stream_t stream);
 int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int64_t rows, int F, gaot_stream_t stream);
+/* the same with every buffer bf16 in memory (fp32 arithmetic); F % 8 == 0, 16-byte aligned buffers */
+int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream);
+int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
 int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream);
 int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period, gaot_stream_t stream);
 int gaot_patchify(const float* src, float* dst, int B, int D, int H, int W, int P, int C, int to_tokens,

@@ -216,6 +216,86 @@ def test_multi_linear_colocated(m, k, ns, precision):
         close(f"mlc_dw{i}_{precision}_{m}", a.grad, r.grad, gr, ga_w)
 
 
+@pytest.mark.parametrize("m,n,k,at,bt,a16,b16,c16", [
+    (300, 256, 64, False, True, False, False, True),      # x W^T -> bf16 result (w1|w3 forward)
+    (300, 64 + 64, 512, False, True, True, False, False),  # bf16 A, k-contiguous (w2 forward)
+    (1000, 256, 2048, False, False, True, False, False),  # bf16 A x row-major W (input gradient of w1|w3)
+    (2048, 256, 1004, True, False, True, False, False),   # bf16 A^T (weight gradient of w1|w3), split-K, K % 8 != 0
+    (256, 1024, 1203, True, False, False, True, False),   # bf16 B, k-strided (weight gradient of w2), split-K, odd K
+    (333, 1024, 256, False, False, False, False, True),   # dy W -> bf16 result (input gradient of w2)
+    (64, 128, 72, False, True, True, False, True),        # A and C bf16, ragged K tail (72 = 64 + 8)
+])
+def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
+    """gaot_gemm_ex: operands / result that are bf16 in memory must give what the fp32-in-memory bf16 GEMM gives on the
+    same (bf16-representable) values -- the only difference is where the rounding happens (tolerance: one bf16 ulp of
+    the result when C is bf16, fp32 accumulation-order noise otherwise)."""
+    import gaot_3d_amd
+    from gaot_3d_amd import ops
+    A = gen(k, m, seed=1) if at else gen(m, k, seed=1)
+    B = gen(n, k, seed=2) if bt else gen(k, n, seed=2)
+    A, B = A.bfloat16().float(), B.bfloat16().float()          # values exactly representable in bf16
+    ref = (A.t() if at else A).double() @ (B.t() if bt else B).double()
+    Ad = (A.bfloat16() if a16 else A).to(DEV)
+    Bd = (B.bfloat16() if b16 else B).to(DEV)
+    out = ops.gemm(Ad, Bd, m, n, k, A.shape[1], B.shape[1], at, bt, precision=1,
+                   out_dtype=torch.bfloat16 if c16 else torch.float32)
+    torch.cuda.synchronize()
+    assert out.dtype == (torch.bfloat16 if c16 else torch.float32)
+    tol = (2.0 ** -8 if c16 else 1e-5) * float(ref.abs().max()) + 1e-6
+    err = float((out.double().cpu() - ref).abs().max())
+    print(f"[parity] gemm_ex m={m} n={n} k={k} a16={a16} b16={b16} c16={c16}: max_abs={err:.3e} tol={tol:.3e}")
+    assert err <= tol
+
+
+def test_gemm_bf16_in_memory_rejects_unsupported():
+    from gaot_3d_amd import ops
+    from gaot_3d_amd._lib import GaotError
+    a = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros(32, 64, device=DEV)
+    with pytest.raises(GaotError):
+        ops.gemm(a, b, 64, 32, 64, 64, 64, False, True, precision=1)       # N <= 64: fp32-tile kernel, no bf16 operands
+    b2 = torch.zeros(128, 64, device=DEV)
+    with pytest.raises(GaotError):
+        ops.gemm(a, b2, 64, 128, 64, 64, 64, False, True, precision=0)     # exact-fp32 mode has no bf16 operands
+
+
+@pytest.mark.parametrize("rows,d,f", [(300, 256, 1024), (1000, 128, 256)])
+def test_ffn_bf16_intermediates(rows, d, f):
+    """FFN.forward/backward with bf16-in-memory intermediates (bf16 mode) against the fp64 formula w2(silu(w1 x)*w3 x)
+    + residual (attn.py:150-157): outputs rtol 2e-2 on the peak scale, every gradient cosine >= 0.999."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.model.layers.attn import FFN
+    torch.manual_seed(rows)
+    ffn = FFN(d, d, hidden_size=f)
+    x = gen(1, rows, d, seed=5)
+    res = gen(1, rows, d, seed=6)
+    g = gen(1, rows, d, seed=7)
+    xr = x.double().requires_grad_(True)
+    w1, w2, w3 = (p.detach().double().requires_grad_(True) for p in (ffn.w1.weight, ffn.w2.weight, ffn.w3.weight))
+    ref = (torch.nn.functional.silu(xr @ w1.t()) * (xr @ w3.t())) @ w2.t() + res.double()
+    (ref * g.double()).sum().backward()
+    ffn = ffn.to(DEV)
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        rd = res.to(DEV).requires_grad_(True)
+        y = ffn(xd, residual=rd)
+        assert GF.FFNFn.eligible(xd, ffn.w1.weight, ffn.w3.weight, ffn.w2.weight)
+        (y * g.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    err = float((y.detach().cpu().double() - ref.detach()).abs().max())
+    assert err <= 2e-2 * float(ref.abs().max()), err
+    for name, got, want in (("x", xd.grad, xr.grad), ("w1", ffn.w1.weight.grad, w1.grad), ("w3", ffn.w3.weight.grad, w3.grad),
+                            ("w2", ffn.w2.weight.grad, w2.grad), ("res", rd.grad, g.double())):
+        a, r = got.detach().cpu().double().flatten(), want.detach().double().flatten()
+        cos = float(a @ r / (a.norm() * r.norm()))
+        print(f"[parity] ffn_bf16 rows={rows} grad {name}: cosine={cos:.6f}")
+        assert cos >= 0.999, (name, cos)
+
+
 def test_attention_spike_rows():
     """online-softmax rescale path: one key dominates late in the sequence"""
     from gaot_3d_amd import functional as GF
