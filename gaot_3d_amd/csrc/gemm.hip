@@ -244,12 +244,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int a_vec, int b_ve
         }
 }
 
-__global__ void k_splitk_reduce(const float* __restrict__ part, int splits, GemmArgs g) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.M * g.N) return;
-    const int64_t m = i / g.N, n = i % g.N;
+// Fixed-order reduction of the split-K partials [split][M*N]: a workgroup owns 64 consecutive outputs; its 4 waves
+// each sum every 4th split (coalesced 256-byte rows), then the 4 partial sums are added in wave order -- the order
+// never depends on timing, so the result is bit-reproducible.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, int splits, GemmArgs g) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t mn = g.M * g.N;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += part[(int64_t)s * g.M * g.N + i];
+    if (i < mn)
+        for (int s = sl; s < splits; s += 4) v += part[(int64_t)s * mn + i];
+    red[sl][o] = v;
+    __syncthreads();
+    if (sl != 0 || i >= mn) return;
+    v = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    const int64_t m = i / g.N, n = i % g.N;
     if (g.bias) v += g.bias[n];
     if (g.preact) g.preact[m * g.ldc + n] = v;
     v = apply_act(v, g.act);
@@ -297,9 +307,11 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
     const int64_t tiles = ceil_div(M, bm) * ceil_div(N, bn);
     int64_t s = 1;
     if (tiles < 128 && K >= 4096) {
-        const int64_t cap = K >= 131072 ? 256 : 64;
-        s = std::min<int64_t>(cap, std::max<int64_t>(1, 1024 / tiles));
-        s = std::min<int64_t>(s, ceil_div(K, 1024));
+        // weight gradients of the per-point MLPs reduce over 500 K rows into ONE tile: a split walks its rows in
+        // sequential 16-row steps (each a memory round trip), so such shapes get ~4 workgroups per CU
+        const int64_t cap = K >= 131072 ? 1024 : 64;
+        s = std::min<int64_t>(cap, std::max<int64_t>(1, (K >= 131072 ? 2048 : 1024) / tiles));
+        s = std::min<int64_t>(s, ceil_div(K, K >= 131072 ? 256 : 1024));
     }
     p.kps = ceil_div(ceil_div(K, s), bk) * bk;
     p.splits = (int)std::max<int64_t>(1, ceil_div(K, std::max<int64_t>(p.kps, 1)));
@@ -352,7 +364,7 @@ static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N
     else if (p.cfg == 1) launch_cfg<4, 1, 1, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else launch_cfg<2, 2, 2, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     if (gk.splits > 1) {
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, part, gk.splits, g);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(M * N, 64)), dim3(256), 0, st, part, gk.splits, g);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

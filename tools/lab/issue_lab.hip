@@ -79,6 +79,45 @@ __global__ __launch_bounds__(256, LB) void k_lab(float* out, int iters, float se
         }
         a0 = dk; a1 = dv;
     }
+    if (MODE == 8) {
+        // forward-attention unit: 2 MFMA (S) -> max over 16 + cross-half + branch -> 16 exp, 16 add, 8 cvt_pk -> 2 MFMA (PV)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        f32x16 acc = a0, negm;
+        for (int r = 0; r < 16; ++r) negm[r] = -50.f;
+        float l = 0.f, m = 50.f;
+        for (int it = 0; it < iters; ++it) {
+            f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, negm, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, sc, 0, 0, 0);
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+            mx = fmaxf(mx, sc[15]);
+            const unsigned u = __builtin_bit_cast(unsigned, mx);
+            const auto rr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)rr[0]), __builtin_bit_cast(float, (unsigned)rr[1]));
+            if (__any(mx > 1e30f)) {
+                m += mx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] -= mx; acc[r] *= 0.5f; negm[r] = -m; }
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+            u4 pw0, pw1;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float pa = __builtin_amdgcn_exp2f(sc[2 * g] * 1e-30f), pb = __builtin_amdgcn_exp2f(sc[2 * g + 1] * 1e-30f);
+                ps0 += pa; ps1 += pb;
+                const f2 pv = {pa, pb};
+                const unsigned pw = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, b2));
+                if (g < 4) pw0[g & 3] = pw; else pw1[g & 3] = pw;
+            }
+            l += ps0 + ps1;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, __builtin_bit_cast(bf16x8, pw0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, __builtin_bit_cast(bf16x8, pw1), acc, 0, 0, 0);
+        }
+        a0 = acc; a1[0] = l + m;
+    }
     if (MODE == 4) {
         // software-pipelined + hand-interleaved: per unit 8 slots of [1 MFMA | 2 exp, 2 mul, 2 cvt_pk]; the MFMAs of a
         // slot never depend on the VALU work beside them (S/dP of the NEXT unit, dV/dK of the previous half)
@@ -189,6 +228,7 @@ int main() {
         run<4>("8 MFMA + VALU pipelined+interleaved", w, out);
         run<2, 2>("independent, VGPR accumulators", w, out);
         run<7, 4>("real dkv mix, dependent, no memory", w, out);
+        run<8, 4>("fwd-attention mix, dependent, no memory", w, out);
         run<4, 2>("pipelined+interleaved, VGPR acc", w, out);
     }
     {
