@@ -128,7 +128,8 @@ def main():
     torch.manual_seed(args.seed)
     model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
     use_graph = (not args.no_graph) and (world == 1 or args.graph)
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5, capturable=use_graph)
+    from gaot_3d_amd.optim import AdamW   # fused multi-tensor HIP step, same semantics as torch.optim.AdamW (tests)
+    opt = AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5)
 
     batch, tokens = make_synthetic_sample(args.points, latent, k=args.knn, seed=args.seed, device=str(dev))
     tokens = tokens.to(dev)

@@ -30,7 +30,7 @@ class MlpGradT(C.Structure):
 
 _lib = None
 
-_p, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_p, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol include/gaot3d_hip.h declares
 SIGNATURES = {
@@ -62,6 +62,7 @@ SIGNATURES = {
     "gaot_rope": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _p, _i, _p]),
     "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_adamw_step": (_i, [_p, _i, _p, _p, _d, _d, _d, _d, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),

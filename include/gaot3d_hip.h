@@ -195,6 +195,22 @@ int gaot_scale_mix_fwd(const float* const* xs, int num_scales, const float* logi
 int gaot_scale_mix_bwd(const float* const* xs, int num_scales, const float* weights, const float* dout,
                        float* const* dxs, float* dlogits, int64_t n, int channels, gaot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW step: stands in for torch.optim.AdamW(params, lr, weight_decay).step()
+ * (reference src/trainer/optimizers.py:210, 272-275; defaults betas (0.9, 0.999), eps 1e-8).  The
+ * tensor table is a HOST array of device pointers; lr and the step counter are DEVICE scalars
+ * (step is advanced by this call), so the call can be captured into a graph.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} gaot_adamw_tensor_t;
+int gaot_adamw_step(const gaot_adamw_tensor_t* tensors, int num_tensors, const float* lr, float* step, double beta1,
+                    double beta2, double eps, double weight_decay, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
