@@ -63,6 +63,14 @@ SIGNATURES = {
     "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_adamw_step": (_i, [_p, _i, _p, _p, _d, _d, _d, _d, _p]),
+    "gaot_knn_grid": (_i, [_p, _i64, _p, _p, _i, _p, _p]),
+    "gaot_radius_grid_count": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p]),
+    "gaot_radius_grid_fill": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "gaot_exclusive_scan_workspace_bytes": (_sz, [_i64]),
+    "gaot_exclusive_scan_i32": (_i, [_p, _i64, _p, _p, _sz, _p]),
+    "gaot_segment_cap_flags": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "gaot_unique_pair_flags": (_i, [_p, _p, _i64, _p, _p]),
+    "gaot_compact_pairs": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),

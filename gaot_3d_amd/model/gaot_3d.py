@@ -33,6 +33,8 @@ class GAOT3D(nn.Module):
         self.encoder = MAGNOEncoder(in_channels=input_size, out_channels=self.node_latent_size, gno_config=magno_config)
         self.processor = self.init_processor(self.node_latent_size, attn_config)
         self.decoder = MAGNODecoder(in_channels=self.node_latent_size, out_channels=output_size, gno_config=magno_config)
+        # precompute_edges=False: the graphs are built on the device against the regular D x H x W token grid
+        self.encoder.latent_dims = self.decoder.latent_dims = (self.D, self.H, self.W)
 
     def init_processor(self, node_latent_size, config):
         tok = self.patch_size ** 3 * node_latent_size

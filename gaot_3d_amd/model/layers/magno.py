@@ -89,11 +89,19 @@ def _per_graph(fn, phys_pos, batch_idx_phys, latent_pos, batch_idx_latent):
 
 
 def get_neighbor_strategy(neighbor_strategy: str, phys_pos, batch_idx_phys, latent_tokens_pos, batch_idx_latent,
-                          radius: float, k_neighbors: int = 1, is_decoder: bool = False):
+                          radius: float, k_neighbors: int = 1, is_decoder: bool = False, latent_dims=None):
     """Edge construction with the reference's conventions (magno.py:116-295): encoder edges are
     [phys_idx, latent_idx], decoder edges [latent_idx, phys_idx]; 'bidirectional' = coalesce(knn U radius);
     'reverse' (decoder only) = flip of the *bidirectional* encoder graph; PyG radius keeps at most 32
-    neighbours per centre.  Brute-force torch implementation (host-side data preparation)."""
+    neighbours per centre.  With the points on the HIP device and ``latent_dims`` given (the tokens are the
+    model's regular D x H x W grid) the graph is built by the device kernels (gaot_3d_amd/graph.py,
+    csrc/graph.hip); otherwise by the brute-force torch restatement below (host-side data preparation, also
+    the checker of the device path in tests/test_graph_gpu.py)."""
+    if latent_dims is not None and phys_pos.is_cuda:
+        from ... import graph as device_graph
+        return device_graph.get_neighbor_strategy(neighbor_strategy, phys_pos, batch_idx_phys, latent_tokens_pos,
+                                                  batch_idx_latent, radius, k_neighbors, is_decoder, latent_dims=latent_dims)
+
     def enc(strategy, p, l):
         knn = rad = None
         if strategy in ("knn", "bidirectional"):
@@ -243,7 +251,7 @@ class MAGNOEncoder(nn.Module):
             else:
                 edge_index = get_neighbor_strategy(self.encoder_strategy, phys_pos, batch.batch, latent_tokens_pos,
                                                    latent_tokens_batch_idx, self.gno_radius * scale, self.k_neighbors,
-                                                   False).to(device)
+                                                   False, latent_dims=getattr(self, "latent_dims", None)).to(device)
             g = graph_for(edge_index, phys_pos.shape[0], latent_tokens_pos.shape[0], batch, ("enc", si))
             enc = self.gno(y_pos=phys_pos, x_pos=latent_tokens_pos, edge_index=edge_index, f_y=lifted,
                            graph=g) if self.use_gno else None
@@ -317,7 +325,8 @@ class MAGNODecoder(nn.Module):
             else:
                 edge_index = get_neighbor_strategy(self.decoder_strategy, phys_pos_query, batch_idx_phys_query,
                                                    latent_tokens_pos, latent_tokens_batch_idx, self.gno_radius * scale,
-                                                   self.k_neighbors, True).to(device)
+                                                   self.k_neighbors, True,
+                                                   latent_dims=getattr(self, "latent_dims", None)).to(device)
             g = graph_for(edge_index, latent_tokens_pos.shape[0], phys_pos_query.shape[0], batch, ("dec", si))
             dec = self.gno(y_pos=latent_tokens_pos, x_pos=phys_pos_query, edge_index=edge_index, f_y=rndata_flat, graph=g)
             if self.use_geoembed:

@@ -211,6 +211,41 @@ typedef struct {
 int gaot_adamw_step(const gaot_adamw_tensor_t* tensors, int num_tensors, const float* lr, float* step, double beta1,
                     double beta2, double eps, double weight_decay, gaot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Neighbour-graph construction on the device (reference get_neighbor_strategy, magno.py:116-295;
+ * torch_cluster knn / radius on the CPU in the reference).  The latent tokens are a regular
+ * D x H x W grid (gaot_3d.py:35-46, stat.py:238-252): gaot_grid_t bounds the search window,
+ * token_pos [D*H*W, 3] supplies the coordinates the distances are measured to.
+ *   gaot_knn_grid          pyg_knn(x=latent, y=phys, k): out_idx[i*k + j] = j-th nearest token of
+ *                          point i, ordered by (distance, token index); k in {1..8, 12, 16, 32}
+ *   gaot_radius_grid_*     pyg_radius(x=latent, y=phys, r, max_num_neighbors=cap): tokens with d <= r
+ *                          of every point, ascending token index, at most cap; count pass, exclusive
+ *                          scan (gaot_exclusive_scan_i32 -> offsets[n+1]), fill pass
+ *   gaot_segment_cap_flags on a list sorted by key (gaot_csr_build): 1 for the first cap elements of
+ *                          every segment (the per-centre cap of pyg_radius(x=phys, y=latent))
+ *   gaot_unique_pair_flags / gaot_compact_pairs   coalesce (magno.py:219-220) after two stable sorts
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dims[3];
+    float lo[3];
+    float hi[3];
+} gaot_grid_t;
+int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_grid_t* grid, const float* token_pos, int k,
+                  int32_t* out_idx, gaot_stream_t stream);
+int gaot_radius_grid_count(const float* pos, int64_t num_points, const gaot_grid_t* grid, const float* token_pos,
+                           float radius, int cap, int32_t* counts, gaot_stream_t stream);
+int gaot_radius_grid_fill(const float* pos, int64_t num_points, const gaot_grid_t* grid, const float* token_pos,
+                          float radius, int cap, const int32_t* offsets, int32_t* out_point, int32_t* out_token,
+                          gaot_stream_t stream);
+size_t gaot_exclusive_scan_workspace_bytes(int64_t n);
+int gaot_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* workspace, size_t workspace_bytes,
+                            gaot_stream_t stream);
+int gaot_segment_cap_flags(const int32_t* rowptr, const int32_t* key_sorted, int64_t n, int cap, int32_t* flags,
+                           gaot_stream_t stream);
+int gaot_unique_pair_flags(const int32_t* a, const int32_t* b, int64_t n, int32_t* flags, gaot_stream_t stream);
+int gaot_compact_pairs(const int32_t* a, const int32_t* b, const int32_t* flags, const int32_t* offsets, int64_t n,
+                       int32_t* out_a, int32_t* out_b, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+"""Device graph construction (csrc/graph.hip, gaot_3d_amd/graph.py) against the brute-force restatement of the
+reference's get_neighbor_strategy (gaot_3d_amd/data.py helpers + model/layers/magno.get_neighbor_strategy, themselves
+the construction used for the golden model cases): identical edge lists, integer-exact."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _points(n, seed, lo=-1.1, hi=1.1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, 3, generator=g) * (hi - lo) + lo       # some points lie outside the token box
+
+
+def _grid(dims, lo=(-1.0, -1.0, -1.0), hi=(1.0, 1.0, 1.0)):
+    from gaot_3d_amd.data import latent_grid
+    return latent_grid(dims, lo, hi)
+
+
+@pytest.mark.parametrize("dims,lo,hi", [((8, 8, 8), (-1, -1, -1), (1, 1, 1)), ((16, 16, 8), (-1, -1, -1), (1, 1, 1)),
+                                         ((5, 9, 3), (-0.5, -1.0, 0.0), (0.7, 1.0, 0.4)), ((6, 1, 7), (-1, 0, -1), (1, 0, 1))])
+@pytest.mark.parametrize("k", [1, 4, 8, 16])
+def test_knn_to_grid_matches_bruteforce(dims, lo, hi, k):
+    from gaot_3d_amd import graph
+    lat = _grid(dims, lo, hi)
+    if k > lat.shape[0]:
+        pytest.skip("k larger than the token count")
+    pos = _points(3001, seed=k + dims[0])
+    g = graph.as_latent_grid(lat.to(DEV), dims)
+    got = graph.knn_to_grid(pos.to(DEV), g, k).cpu().long()
+    d = torch.cdist(pos.double(), lat.double())
+    # reference order: (distance, index); fp32 distances on the device -> compare through the distances, exactly on
+    # the index sets wherever the k-th and (k+1)-th distances are separated
+    order = torch.argsort(d, dim=1, stable=True)[:, :k]
+    dk = d.gather(1, order)
+    dgot = d.gather(1, got)
+    assert torch.allclose(dgot, dk, rtol=1e-5, atol=1e-6), (dgot - dk).abs().max()
+    if lat.shape[0] > k:
+        nxt = torch.sort(d, dim=1).values[:, k]
+        clear = (nxt - dk[:, -1]) > 1e-5
+        assert clear.float().mean() > 0.9
+        assert torch.equal(torch.sort(got[clear], dim=1).values, torch.sort(order[clear], dim=1).values)
+
+
+def _as_set(e):
+    return set(map(tuple, e.t().tolist()))
+
+
+@pytest.mark.parametrize("dims,radius", [((8, 8, 8), 0.2), ((8, 8, 8), 0.45), ((12, 10, 4), 0.3), ((4, 4, 4), 1.2)])
+@pytest.mark.parametrize("centers", ["latent", "phys"])
+def test_radius_matches_bruteforce(dims, radius, centers):
+    """both orientations, the 32-per-centre cap included (radius 0.45 / 1.2 overflow it)"""
+    from gaot_3d_amd import graph
+    from gaot_3d_amd.data import radius_edges_bruteforce
+    lat = _grid(dims)
+    pos = _points(1500, seed=int(radius * 100), lo=-1.0, hi=1.0)
+    ref = radius_edges_bruteforce(pos, lat, radius, 32, centers=centers)
+    g = graph.as_latent_grid(lat.to(DEV), dims)
+    strat = graph._encoder_edges if centers == "latent" else graph._decoder_edges
+    got = strat("radius", pos.to(DEV), g, radius, 1).cpu().long()
+    assert got.dtype == torch.int64 and got.shape[0] == 2
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.equal(got, ref)      # same pairs in the same order (grouped by centre, other index ascending)
+
+
+@pytest.mark.parametrize("strategy,is_decoder", [("knn", False), ("radius", False), ("bidirectional", False), ("knn", True),
+                                                 ("radius", True), ("bidirectional", True), ("reverse", True)])
+def test_get_neighbor_strategy_matches_host(strategy, is_decoder):
+    """the reference function's conventions (orientation, coalesce, reverse = flip of the bidirectional encoder graph),
+    two graphs in the batch"""
+    from gaot_3d_amd import graph
+    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy as host_strategy
+    dims = (6, 5, 4)
+    lat1 = _grid(dims)
+    lat = lat1.repeat(2, 1)
+    pos = torch.cat([_points(700, 1, -1, 1), _points(450, 2, -1, 1)])
+    bp = torch.cat([torch.zeros(700, dtype=torch.long), torch.ones(450, dtype=torch.long)])
+    bl = torch.cat([torch.zeros(lat1.shape[0], dtype=torch.long), torch.ones(lat1.shape[0], dtype=torch.long)])
+    ref = host_strategy(strategy, pos, bp, lat, bl, 0.45, 3, is_decoder)   # per graph + EnrichedData.__inc__-style offsets
+    got = graph.get_neighbor_strategy(strategy, pos.to(DEV), bp.to(DEV), lat.to(DEV), bl.to(DEV), 0.45, 3, is_decoder,
+                                      latent_dims=dims).cpu().long()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if strategy in ("knn",):
+        assert _as_set(got) == _as_set(ref)            # neighbour order inside a point may differ on ties
+    else:
+        assert torch.equal(got, ref)
+
+
+def test_irregular_tokens_and_cpu_inputs_raise():
+    from gaot_3d_amd import graph
+    from gaot_3d_amd._lib import GaotError
+    lat = _grid((4, 4, 4))
+    bad = lat.clone()
+    bad[5, 0] += 0.1
+    with pytest.raises(GaotError):
+        graph.as_latent_grid(bad.to(DEV), (4, 4, 4))
+    g = graph.as_latent_grid(lat.to(DEV), (4, 4, 4))
+    with pytest.raises(GaotError):
+        graph.knn_to_grid(_points(10, 0), g, 2)        # CPU tensor: no fallback
+    with pytest.raises(GaotError):
+        graph.knn_to_grid(_points(10, 0).to(DEV), g, 9)   # k not instantiated
+
+
+def test_full_size_knn_feeds_the_model_graph():
+    """configs[1]: 500 000 points against the 64x64x32 grid, k = 8 -> E = 4.0 M; spot-check 2 000 points against brute
+    force, and the list must be what the CSR builder's sorted-input fast path expects (grouped by point)"""
+    from gaot_3d_amd import graph, ops
+    from gaot_3d_amd.data import make_synthetic_sample
+    batch, tokens = make_synthetic_sample(500_000, (64, 64, 32), k=8, seed=0, device=DEV)
+    g = graph.as_latent_grid(tokens.to(DEV), (64, 64, 32))
+    e = graph.get_neighbor_strategy("knn", batch.pos, None, tokens.to(DEV), None, 0.033, 8, False, latent_dims=(64, 64, 32))
+    assert e.shape == (2, 4_000_000) and e.dtype == torch.int32
+    assert bool((e[0, 1:] >= e[0, :-1]).all())
+    sel = torch.randperm(500_000, generator=torch.Generator().manual_seed(0))[:2000].to(DEV)
+    d = torch.cdist(batch.pos[sel].double(), tokens.to(DEV).double())
+    ref = torch.sort(torch.argsort(d, dim=1, stable=True)[:, :8], dim=1).values
+    got = torch.sort(e[1].view(500_000, 8)[sel].long(), dim=1).values
+    assert (got == ref).all(dim=1).float().mean() > 0.999     # distance ties at fp32 resolution aside
+    s = ops.csr_build(e, 0, 500_000)
+    assert torch.equal(s.perm.long(), torch.arange(4_000_000, device=DEV))
+
+
+@pytest.mark.parametrize("strategy", ["knn", "bidirectional", ["radius", "reverse"]])
+def test_model_builds_its_graphs_on_device(strategy):
+    """precompute_edges=False: GAOT3D.forward builds encoder and decoder graphs with the device kernels; loss and
+    gradients equal the run that is handed the brute-force edges (precompute_edges=True) on the same weights."""
+    import types
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from gaot_3d_amd.model.layers.magno import MAGNOConfig, get_neighbor_strategy as host_strategy, parse_neighbor_strategy
+    gaot_3d_amd.set_precision("fp32")
+
+    def cfg(pre):
+        return types.SimpleNamespace(
+            magno=MAGNOConfig(use_gno=True, gno_coord_dim=3, neighbor_strategy=strategy, k_neighbors=3, projection_channels=64,
+                              in_gno_channel_mlp_hidden_layers=[64, 64], out_gno_channel_mlp_hidden_layers=[64, 64],
+                              lifting_channels=32, gno_radius=0.4, use_geoembed=[True, False], embedding_method="statistical",
+                              encoder_feature_attr=["pos", "c"], mlp_type="linear", precompute_edges=pre),
+            transformer=TransformerConfig(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="rope",
+                                          attn_config=AttentionConfig(hidden_size=64, num_heads=2, num_kv_heads=2, atten_dropout=0.0),
+                                          ffn_config=FFNConfig(hidden_size=128)),
+            latent_tokens=(6, 6, 4))
+
+    batch, tokens = make_synthetic_sample(1500, (6, 6, 4), k=3, seed=4, device=DEV)
+    tokens = tokens.to(DEV)
+    es, ds = parse_neighbor_strategy(strategy)
+    lb = torch.zeros(tokens.shape[0], dtype=torch.long)
+    batch.encoder_edge_index_s0 = host_strategy(es, batch.pos.cpu(), batch.batch.cpu(), tokens.cpu(), lb, 0.4, 3, False).to(DEV)
+    batch.decoder_edge_index_s0 = host_strategy(ds, batch.pos.cpu(), batch.batch.cpu(), tokens.cpu(), lb, 0.4, 3, True).to(DEV)
+    res = {}
+    for pre in (True, False):
+        torch.manual_seed(0)
+        model = init_model(6, 1, "gaot_3d", cfg(pre)).to(DEV).train()
+        gaot_3d_amd.clear_graph_cache(batch)
+        loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens), batch.x)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[pre] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[True][0]), (res[True][0], res[False][0])
+    for k, g in res[True][1].items():
+        assert torch.allclose(res[False][1][k], g, rtol=1e-3, atol=1e-5 * max(1.0, float(g.abs().max()))), k

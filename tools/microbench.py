@@ -54,6 +54,23 @@ elif what == "gemm":
         timeit(lambda: ops.gemm(dy, x, n, k, m, n, k, True, False), f"dW   dy^T[{n},{m}] x[{m},{k}]", fl)
         mb = (m * k + m * n + n * k) * 4 / 1e6
         print(f"     (operand + result bytes {mb:.0f} MB -> {mb / 5e3 * 1e3:.1f} us at 5 TB/s)")
+elif what == "graph":
+    # device graph construction at configs[1]: 500 000 surface points against the 64x64x32 token grid
+    from gaot_3d_amd import graph
+    from gaot_3d_amd.data import make_synthetic_sample
+    batch, tokens = make_synthetic_sample(500000, (64, 64, 32), k=8, seed=0, device=dev)
+    tokens = tokens.to(dev)
+    pos = batch.pos
+    g = graph.as_latent_grid(tokens, (64, 64, 32))
+    timeit(lambda: graph.knn_to_grid(pos, g, 8), "knn_to_grid k=8 (E = 4.0 M)")
+    timeit(lambda: graph.knn_to_grid(pos, g, 1), "knn_to_grid k=1")
+    for r in (0.033, 0.05):
+        e = graph._decoder_edges("radius", pos, g, r, 1)
+        timeit(lambda: graph._decoder_edges("radius", pos, g, r, 1), f"radius r={r} centres=phys (E = {e.shape[1]})")
+        e = graph._encoder_edges("radius", pos, g, r, 1)
+        timeit(lambda: graph._encoder_edges("radius", pos, g, r, 1), f"radius r={r} centres=latent, cap 32 per token (E = {e.shape[1]})")
+        e = graph._encoder_edges("bidirectional", pos, g, r, 1)
+        timeit(lambda: graph._encoder_edges("bidirectional", pos, g, r, 1), f"bidirectional k=1 r={r} encoder (E = {e.shape[1]})")
 elif what == "gno":
     from gaot_3d_amd.data import make_synthetic_sample
     batch, tokens = make_synthetic_sample(500000, (64, 64, 32), k=8, seed=0, device=dev)
