@@ -630,26 +630,102 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dQ with QB query blocks per wave (4 waves x QB x 32 queries): one LDS read of a K / V fragment serves QB
+// (key tile, query block) units and the units are independent instruction streams (same idea and same
+// measurements as k_attn_bwd_dkv_kb).
+// ------------------------------------------------------------------------------------------------
+template <int QB, int NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * NT * TILE_BYTES];  // K tiles, then V tiles
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int hkv = head / (a.H / a.HKV);
+    const int64_t q0 = (int64_t)blockIdx.x * (128 * QB) + wave * (32 * QB);
+    const int64_t rowbase = (int64_t)b * a.S;
+    const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
+    const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
+    bf16x8 qf[QB][2], dof[QB][2];
+    f32x16 dqt[QB], negl[QB], negd[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qi = q0 + 32 * qb + l31;
+        const bf16_t* qp = a.qkv + (rowbase + qi) * a.ld + head * D;
+        const bf16_t* dop = a.dob + (rowbase + qi) * (a.H * D) + head * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (qi < a.S) {
+                qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hf);
+                dof[qb][s] = *reinterpret_cast<const bf16x8*>(dop + 16 * s + 8 * hf);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { qf[qb][s][j] = 0; dof[qb][s][j] = 0; }
+            }
+        }
+        const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
+        const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dqt[qb][r] = 0.f; negl[qb][r] = -lse2; negd[qb][r] = -del; }
+    }
+    uint4 regs[NT];
+    stage_loadN<NT>(regs, kp, a.ld, vp, a.ld, 0, a.S);
+    for (int64_t k0 = 0; k0 < a.S; k0 += 32 * NT) {
+        __syncthreads();
+        stage_storeN<NT>(regs, lds);
+        __syncthreads();
+        if (k0 + 32 * NT < a.S) stage_loadN<NT>(regs, kp, a.ld, vp, a.ld, k0 + 32 * NT, a.S);
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            const int64_t kb = k0 + 32 * t;
+            if (kb >= a.S) break;
+            const char* kt = lds + t * TILE_BYTES;
+            const char* vt = lds + (NT + t) * TILE_BYTES;
+            const bf16x8 ka0 = frag_rows(kt, l31, hf, 0), va0 = frag_rows(vt, l31, hf, 0);
+            const bf16x8 ka1 = frag_rows(kt, l31, hf, 1), va1 = frag_rows(vt, l31, hf, 1);
+            f32x16 sc[QB], dp[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[qb][0], negl[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, dof[qb][0], negd[qb], 0, 0, 0);
+                sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qf[qb][1], sc[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, dof[qb][1], dp[qb], 0, 0, 0);
+            }
+            if (kb + 32 > a.S) {   // wave-uniform: last tile only
+                const int nv = (int)(a.S - kb);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (mfma32_row(r, hf) >= nv) sc[qb][r] = -INFINITY;
+            }
+            const bf16x8 kc0 = frag_cols(kt, lane, 0), kc1 = frag_cols(kt, lane, 1);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[qb][r] = __builtin_amdgcn_exp2f(sc[qb][r]) * dp[qb][r];
+                bf16x8 d0, d1;
+                acc_to_frags(dp[qb], d0, d1);
+                dqt[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc0, d0, dqt[qb], 0, 0, 0);
+                dqt[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc1, d1, dqt[qb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qi = q0 + 32 * qb + l31;
+        if (qi < a.S) {
+            float* dqp = a.dqkv + (rowbase + qi) * a.ld + head * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t = make_float4(dqt[qb][4 * g] * a.scale, dqt[qb][4 * g + 1] * a.scale, dqt[qb][4 * g + 2] * a.scale,
+                                       dqt[qb][4 * g + 3] * a.scale);
+                *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
+            }
+        }
+    }
+}
+
 }  // namespace
-
-// forward kernel variant: 5 waves/SIMD (rolled tile loop, 96 VGPRs) or 4 (unrolled); tuning knob GAOT_ATTN_OCC
-static int attn_occ() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GAOT_ATTN_OCC");
-        v = e ? atoi(e) : 4;
-    }
-    return v;
-}
-
-static int dkv_occ() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GAOT_DKV_OCC");
-        v = e ? atoi(e) : 4;
-    }
-    return v;
-}
 
 // fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
 extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
@@ -674,11 +750,10 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
                        HKV, S, rope_freqs, scale * LOG2E);
     FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
     const dim3 fgrid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
-    switch (attn_occ()) {
-        case 5: hipLaunchKernelGGL((k_attn_fwd_bf16<5, 2>), fgrid, dim3(256), 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_fwd_bf16<4, 4>), fgrid, dim3(256), 0, st, a); break;   // 128-key stages
-        default: hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2>), fgrid, dim3(256), 0, st, a); break;
-    }
+    // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
+    // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
+    // its max / exp / sum VALU work and loses more from the halved occupancy)
+    hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2>), fgrid, dim3(256), 0, st, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -703,15 +778,16 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 2) {
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups
-        if (dkv_occ() == 4 && (int64_t)ceil_div(S, 256) * HKV * B >= 512)
+        if ((int64_t)ceil_div(S, 256) * HKV * B >= 512)
             hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2>), dim3((unsigned)ceil_div(S, 256), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
-        else if (dkv_occ() == 4)
-            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<3>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
     }
     if (phase_mask & 4) {
-        hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+        if ((int64_t)ceil_div(S, 256) * H * B >= 512)   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
+            hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2>), dim3((unsigned)ceil_div(S, 256), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -350,8 +350,7 @@ template <bool A_KS, bool B_KS>
 int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t st) {
     // fewer than two 128x128 workgroups per CU: halve the tile height so that twice as many workgroups hide latency
     const int64_t blocks128 = ceil_div(g.N, BN) * ceil_div(g.M, 128) * splits;
-    static const int thr = getenv("GAOT_GEMM_THR") ? atoi(getenv("GAOT_GEMM_THR")) : 2100;
-    const bool small = blocks128 < thr && g.M > 64;
+    const bool small = blocks128 < 2100 && g.M > 64;   // measured: 64-row tiles win up to ~8 workgroups per CU
     // buffer-addressed tiles need 16-byte aligned rows, whole 16-byte chunks along k and 31-bit byte offsets inside a tile
     const int64_t span_a = (A_KS ? g.K : 128) * g.lda * 4, span_b = (B_KS ? g.K : 128) * g.ldb * 4;
     const bool k4 = (!A_KS && !(dt & 1)) || (!B_KS && !(dt & 2));   // an fp32 operand read in float4s along k
