@@ -63,6 +63,9 @@ SIGNATURES = {
     "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_adamw_step": (_i, [_p, _i, _p, _p, _d, _d, _d, _d, _p]),
+    "gaot_mlp2_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "gaot_mlp2_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "gaot_mlp2_bwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gaot_knn_grid": (_i, [_p, _i64, _p, _p, _i, _p, _p]),
     "gaot_radius_grid_count": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p]),
     "gaot_radius_grid_fill": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p, _p, _p]),

@@ -228,6 +228,42 @@ class FFNFn(Function):
         return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres
 
 
+class Mlp2Fn(Function):
+    """Per-node two-layer MLP  W2 gelu(W1 x + b1) + b2  with the hidden layer kept in registers (csrc/mlp2.hip): the
+    decoder's projection C -> 256 -> out (reference magno.py:793-797), bf16 path.  The unfused chain moves the
+    [N, 256] fp32 hidden tensor through HBM eight times per step."""
+
+    @staticmethod
+    def eligible(x: Tensor, fcs, non_linearity: str) -> bool:
+        if len(fcs) != 2 or non_linearity != "gelu" or ops.get_precision() != "bf16" or not x.is_cuda:
+            return False
+        w1, w2 = _w2d(fcs[0].weight), _w2d(fcs[1].weight)
+        return (x.shape[-1] == 32 and w1.shape[1] == 32 and w1.shape[0] in (64, 128, 256) and 1 <= w2.shape[0] <= 4
+                and w2.shape[1] == w1.shape[0] and fcs[0].bias is not None and x.dtype == torch.float32)
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Optional[Tensor]):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w1c, w2c = _w2d(w1), _w2d(w2)
+        out = ops.mlp2_forward(x2, w1c, b1, w2c, b2)
+        ctx.save_for_backward(x2, w1c, b1, w2c)
+        ctx.meta = (x.shape, w1.shape, w2.shape, b2 is not None)
+        return out.view(*x.shape[:-1], w2c.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x2, w1c, b1, w2c = ctx.saved_tensors
+        xshape, w1shape, w2shape, has_b2 = ctx.meta
+        d = dout.reshape(x2.shape[0], w2c.shape[0])
+        if not d.is_contiguous():
+            d = d.contiguous()
+        dx, dw1, db1, dw2 = ops.mlp2_backward(x2, w1c, b1, w2c, d)
+        db2 = ops.colsum(d, d.shape[0], d.shape[1], d.shape[1]) if has_b2 else None
+        return dx.view(xshape), dw1.view(w1shape), db1, dw2.view(w2shape), db2
+
+
 class AddFn(Function):
     """a + b (b optionally broadcast over leading rows with `period` elements)."""
 

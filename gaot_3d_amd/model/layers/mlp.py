@@ -5,8 +5,8 @@ import torch.nn as nn
 
 from ... import functional as GF
 
-# per-node MLPs (lifting / recovery / projection / geoembed) stay in exact-fp32 MFMA in every mode:
-# they are HBM-bound, so bf16 operands would buy nothing
+# per-node single linears (lifting / recovery / geoembed) stay in exact-fp32 MFMA in every mode: they are HBM-bound, so
+# bf16 operands would buy nothing.  The two-layer projection is fused (Mlp2Fn) in bf16 mode.
 _FP32 = 0
 
 
@@ -23,6 +23,8 @@ class LinearChannelMLP(nn.Module):
         self.fcs = nn.ModuleList([nn.Linear(layers[j], layers[j + 1]) for j in range(self.n_layers)])
 
     def forward(self, x):
+        if GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused, no [N, hidden] in HBM
+            return GF.Mlp2Fn.apply(x, self.fcs[0].weight, self.fcs[0].bias, self.fcs[1].weight, self.fcs[1].bias)
         for i, fc in enumerate(self.fcs):
             x = GF.linear(x, fc.weight, fc.bias, act=self.non_linearity if i < self.n_layers - 1 else None,
                           precision=_FP32)
@@ -52,6 +54,8 @@ class ChannelMLP(nn.Module):
             self.fcs.append(nn.Conv1d(cin, cout, 1))
 
     def forward(self, x):
+        if GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused, no [N, hidden] in HBM
+            return GF.Mlp2Fn.apply(x, self.fcs[0].weight, self.fcs[0].bias, self.fcs[1].weight, self.fcs[1].bias)
         for i, fc in enumerate(self.fcs):
             x = GF.linear(x, fc.weight, fc.bias, act=self.non_linearity if i < self.n_layers - 1 else None,
                           precision=_FP32)

@@ -442,3 +442,24 @@ def scale_mix_bwd(xs, w: Tensor, dout: Tensor):
     check(lib.gaot_scale_mix_bwd(_ptr_array(xs), len(xs), _ptr(w), _ptr(dout), _ptr_array(dxs), _ptr(dlog), n, c,
                                  _stream()), "gaot_scale_mix_bwd")
     return dxs, dlog
+
+
+def mlp2_forward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Optional[Tensor]) -> Tensor:
+    """out = w2 gelu(w1 x + b1) + b2, x [rows, 32] (include/gaot3d_hip.h: gaot_mlp2_fwd)"""
+    lib = _lib.load()
+    rows, hid, oc = x.shape[0], w1.shape[0], w2.shape[0]
+    out = torch.empty(rows, oc, dtype=torch.float32, device=x.device)
+    check(lib.gaot_mlp2_fwd(_ptr(x), rows, x.shape[1], hid, oc, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _stream()),
+          "gaot_mlp2_fwd")
+    return out
+
+
+def mlp2_backward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, dout: Tensor):
+    lib = _lib.load()
+    rows, hid, oc = x.shape[0], w1.shape[0], w2.shape[0]
+    dx = torch.empty_like(x)
+    dw1, db1, dw2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2)
+    ws = _ws(lib.gaot_mlp2_bwd_workspace_bytes(hid, oc), x.device)
+    check(lib.gaot_mlp2_bwd(_ptr(x), rows, x.shape[1], hid, oc, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(dout), _ptr(dx), _ptr(dw1),
+                            _ptr(db1), _ptr(dw2), _ptr(ws), ws.numel(), _stream()), "gaot_mlp2_bwd")
+    return dx, dw1, db1, dw2

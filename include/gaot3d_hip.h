@@ -246,6 +246,21 @@ int gaot_unique_pair_flags(const int32_t* a, const int32_t* b, int64_t n, int32_
 int gaot_compact_pairs(const int32_t* a, const int32_t* b, const int32_t* flags, const int32_t* offsets, int64_t n,
                        int32_t* out_a, int32_t* out_b, gaot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-node two-layer MLP  out = W2 gelu(W1 x + b1) + b2  and its autograd: the decoder's
+ * projection C -> 256 -> out (reference magno.py:793-797 -> LinearChannelMLP / ChannelMLP with GELU,
+ * mlp.py:227-335), bf16 operands / fp32 accumulation.  x [rows, 32], w1 [hidden, 32], w2 [out, hidden]
+ * row-major fp32; hidden in {64, 128, 256}, out in 1..4.  The [rows, hidden] activations never reach
+ * HBM; backward recomputes them and reduces the weight gradients in a fixed order.  d_b2 is the
+ * column sum of d_out (gaot_colsum).
+ * ------------------------------------------------------------------------------------------- */
+int gaot_mlp2_fwd(const float* x, int64_t num_rows, int in_dim, int hidden, int out_dim, const float* w1, const float* b1,
+                  const float* w2, const float* b2, float* out, gaot_stream_t stream);
+size_t gaot_mlp2_bwd_workspace_bytes(int hidden, int out_dim);
+int gaot_mlp2_bwd(const float* x, int64_t num_rows, int in_dim, int hidden, int out_dim, const float* w1, const float* b1,
+                  const float* w2, const float* d_out, float* d_x, float* d_w1, float* d_b1, float* d_w2, void* workspace,
+                  size_t workspace_bytes, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
