@@ -389,20 +389,35 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd_bf16(
     };
 
     const int64_t n_tiles = (E + 31) / 32;
+    // The tile's edge ids and endpoint coordinates are two DEPENDENT global round trips (ids, then y[src] / x[dst]);
+    // with one wave per SIMD nothing else hides them, so they are fetched one iteration ahead.
+    int s_nx = 0, q_nx = 0;
+    bool v_nx = false;
+    float bin_nx[3] = {0.f, 0.f, 0.f};
+    auto fetch_ids = [&](int64_t tb_) {
+        const int64_t e = (tb_ + wave) * 32 + l31;
+        v_nx = tb_ < n_tiles && e < E;
+        s_nx = v_nx ? src_s[e] : 0;
+        q_nx = v_nx ? dst_s[e] : 0;
+    };
+    auto fetch_pos = [&]() {
+        const float* ys = y_pos + (int64_t)s_nx * 3;
+        const float* xq = x_pos + (int64_t)q_nx * 3;
+        bin_nx[0] = ys[hf];
+        bin_nx[1] = hf ? xq[0] : ys[2];
+        bin_nx[2] = xq[1 + hf];
+    };
+    fetch_ids((int64_t)blockIdx.x * 4);
+    fetch_pos();
     for (int64_t tb = (int64_t)blockIdx.x * 4; tb < n_tiles; tb += (int64_t)gridDim.x * 4) {
         const int64_t base = (tb + wave) * 32;
-        // ---- gather indices and coordinates ------------------------------------------------------------
+        // ---- indices and coordinates of this tile (prefetched); start the next tile's id fetch ------------------
         float bin[3];
         {
-            const int64_t e = base + l31;
-            const bool valid = e < E;
-            const int s = valid ? src_s[e] : 0;
-            const int q = valid ? dst_s[e] : 0;
-            const float* ys = y_pos + (int64_t)s * 3;
-            const float* xq = x_pos + (int64_t)q * 3;
-            bin[0] = ys[hf];
-            bin[1] = hf ? xq[0] : ys[2];
-            bin[2] = xq[1 + hf];
+            const bool valid = v_nx;
+            const int s = s_nx, q = q_nx;
+            bin[0] = bin_nx[0]; bin[1] = bin_nx[1]; bin[2] = bin_nx[2];
+            fetch_ids(tb + (int64_t)gridDim.x * 4);
             if (hf == 0) {
                 ids[l31] = valid ? s : -1;
                 ids[32 + l31] = valid ? q : -1;
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd_bf16(
                 to_frags(z[ob], hb[ob][0], hb[ob][1]);
             }
         }
+        fetch_pos();   // next tile's coordinates: its ids were requested at the top of this tile
         // ---- gather f[src] / g[dst] rows (latency hides under the last layer) ----------------------------------
         wave_lds_fence();
         float fv[16], gv[16];

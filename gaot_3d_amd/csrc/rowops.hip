@@ -213,6 +213,17 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+__global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n8, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n8) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reinterpret_cast<uint4*>(dst)[i] = pack8(f);
+    } else if (i == n8) {
+        for (int64_t j = 8 * n8; j < n; ++j) dst[j] = __builtin_bit_cast(unsigned short, (__bf16)src[j]);
+    }
+}
+
 __global__ void k_swiglu_fwd_bf16(const unsigned short* __restrict__ ag, unsigned short* __restrict__ u, int64_t rows, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte chunk index
     const int fv = F / 8;
@@ -481,6 +492,18 @@ extern "C" int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int
     GAOT_CHECK_ARG(ag && du && dag, "null pointer");
     hipLaunchKernelGGL(k_swiglu_bwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, du, dag,
                        rows, F);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0, "negative size");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(src && dst, "null pointer");
+    GAOT_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "buffers must be 16-byte aligned");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(k_cast_bf16, dim3(blocks_for(n8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n8, n);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -21,6 +21,17 @@ def _w2d(w: Tensor) -> Tensor:
     return w if w.is_contiguous() else w.contiguous()
 
 
+def _wb(w: Tensor, precision: Optional[int]) -> Tensor:
+    """the weight as the bf16 GEMMs' B operand: in bf16 mode a wide weight ([out > 64, in > 64], 16-byte rows) is rounded
+    to bf16 ONCE per use instead of once per workgroup that streams it (a 64-row tile re-reads the whole matrix: at
+    M = 16 384 that is 256 x); everything else stays fp32"""
+    prec = (1 if ops.get_precision() == "bf16" else 0) if precision is None else precision
+    n, k = w.shape
+    if prec == 1 and w.is_cuda and n > 64 and k > 64 and n % 8 == 0 and k % 8 == 0 and w.data_ptr() % 16 == 0:
+        return ops.cast_bf16(w)
+    return w
+
+
 class LinearFn(Function):
     """y = act(x W^T + b) [+ residual].  Stands in for nn.Linear (+ F.gelu / ReLU, + the residual add that follows
     it in the Transformer block) and its autograd."""
@@ -41,6 +52,7 @@ class LinearFn(Function):
             res = residual.reshape(m, n)
             if not res.is_contiguous():
                 res = res.contiguous()
+        w = _wb(w, precision)
         if act:
             y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, act, residual=res, ldr=n, want_preact=True,
                             precision=precision)
@@ -197,8 +209,8 @@ class FFNFn(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         m = x2.shape[0]
-        wcat = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1))
-        w2c = _w2d(w2)
+        wcat = _wb(w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1)), 1)
+        w2c = _wb(_w2d(w2), 1)
         ag = ops.gemm(x2, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
         u = ops.swiglu_fwd_bf16(ag, f)
         res = None
@@ -370,7 +382,7 @@ class MultiLinearFn(Function):
         out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
         ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[2 + i] for i in range(len(ws)))
         if ctx.fused:   # the weights are slices of one buffer (colocate): one [ntot, k] matrix, one GEMM
-            wcat = ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1))
+            wcat = _wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), precision)
             ops.gemm(x2, wcat, m, ntot, k, k, k, False, True, out=out, ldc=ntot, precision=precision)
             ctx.save_for_backward(x2, wcat)
         else:
@@ -430,6 +442,8 @@ class CatLinearFn(Function):
         if sum(x.shape[1] for x in xs2) != k:
             raise GaotError(f"cat_linear: inputs have {sum(x.shape[1] for x in xs2)} features, weight expects {k}")
         m = xs2[0].shape[0]
+        if all(x.shape[1] > 64 and x.shape[1] % 8 == 0 for x in xs2):
+            w = _wb(w, precision)
         y = None
         col = 0
         for i, x in enumerate(xs2):

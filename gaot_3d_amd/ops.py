@@ -365,6 +365,14 @@ def swiglu_bwd(ag: Tensor, du: Tensor, f: int) -> Tensor:
     return dag
 
 
+def cast_bf16(x: Tensor) -> Tensor:
+    """bf16 copy (round to nearest even) of a contiguous fp32 tensor"""
+    lib = _lib.load()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.gaot_cast_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "gaot_cast_bf16")
+    return out
+
+
 def swiglu_fwd_bf16(ag: Tensor, f: int) -> Tensor:
     """bf16 [rows, 2F] -> bf16 [rows, F]"""
     lib = _lib.load()

@@ -115,7 +115,7 @@ int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, in
  * in elements): the FFN intermediates of the bf16 path ([rows, 2F] = w1 x | w3 x, silu(a)*g, and their gradients,
  * reference attn.py:156) are written once as bf16 by their producer and never exist as fp32 in HBM.  precision must
  * be 1 and N > 64; rows must be 16-byte aligned and K a multiple of 8; a bf16 result excludes split-K.  Supported
- * combinations: A, B, A+B, C, A+C; anything else returns GAOT_ERR_UNSUPPORTED. */
+ * combinations: A, B, A+B, C, A+C, B+C; anything else returns GAOT_ERR_UNSUPPORTED. */
 int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                  int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int c_bf16, const float* bias, int act,
                  const float* residual, int64_t ldr, float* preact, int precision, void* workspace,
@@ -174,6 +174,9 @@ int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head
               int inverse, gaot_stream_t stream);
 int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, gaot_stream_t stream);
 int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int64_t rows, int F, gaot_stream_t stream);
+/* fp32 -> bf16 (round to nearest even) copy of a weight matrix: the B operand of the bf16 GEMMs of one step is
+ * rounded once instead of once per workgroup that streams it (gaot_gemm_ex, b_bf16) */
+int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_stream_t stream);
 /* the same with every buffer bf16 in memory (fp32 arithmetic); F % 8 == 0, 16-byte aligned buffers */
 int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
