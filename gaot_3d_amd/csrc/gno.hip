@@ -603,12 +603,18 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd(
 }
 
 // grad[p] = sum over waves (fixed order) of the per-wave partials; scattered to the per-tensor outputs
-__global__ void k_reduce_params(const float* __restrict__ wpart, int n_waves, int total, float* __restrict__ flat) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
+// (a workgroup owns 64 parameters; its 4 waves each sum every 4th partial, then the 4 sums are added in wave order)
+__global__ __launch_bounds__(256) void k_reduce_params(const float* __restrict__ wpart, int n_waves, int total,
+                                                       float* __restrict__ flat) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int w = 0; w < n_waves; ++w) s += wpart[(int64_t)w * total + p];
-    flat[p] = s;
+    if (p < total)
+        for (int w = sl; w < n_waves; w += 4) s += wpart[(int64_t)w * total + p];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && p < total) flat[p] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
 }
 
 struct ScatterDesc {
@@ -828,7 +834,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
             case 3: rc = launch_bwd<3, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
         }
         if (rc != GAOT_OK) return rc;
-        hipLaunchKernelGGL(k_reduce_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, wpart, n_waves,
+        hipLaunchKernelGGL(k_reduce_params, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, st, wpart, n_waves,
                            total, flat);
     }
     hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, flat, sd);

@@ -295,13 +295,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
     }
 }
 
-// out[i] = sum over workgroups of part[g * stride + i], i < count, in workgroup order
-__global__ void k_mlp2_reduce(const float* __restrict__ part, int groups, int64_t stride, int64_t count, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// out[i] = sum over workgroups of part[g * stride + i], i < count: a workgroup owns 64 outputs, its 4 waves each sum
+// every 4th partial, the 4 sums are added in wave order (fixed order -> bit-reproducible)
+__global__ __launch_bounds__(256) void k_mlp2_reduce(const float* __restrict__ part, int groups, int64_t stride, int64_t count,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += part[(int64_t)g * stride + i];
-    out[i] = s;
+    if (i < count)
+        for (int g = sl; g < groups; g += 4) s += part[(int64_t)g * stride + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < count) out[i] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
 }
 
 constexpr size_t bwd_lds_bytes(int nob, int oc) {
@@ -402,9 +408,9 @@ extern "C" int gaot_mlp2_bwd(const float* x, int64_t num_rows, int in_dim, int h
     if (rc != GAOT_OK) return rc;
     // partial layout [dW1 | db1 | dW2] -> the three outputs (contiguous pieces of one reduction)
     const int64_t n1 = (int64_t)hidden * MLP_IN, n2 = hidden, n3 = (int64_t)out_dim * hidden;
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st, wpart, grid, np, n1, d_w1);
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st, wpart + n1, grid, np, n2, d_b1);
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n3, 256)), dim3(256), 0, st, wpart + n1 + n2, grid, np, n3, d_w2);
+    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n1, 64)), dim3(256), 0, st, wpart, grid, np, n1, d_w1);
+    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n2, 64)), dim3(256), 0, st, wpart + n1, grid, np, n2, d_b1);
+    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n3, 64)), dim3(256), 0, st, wpart + n1 + n2, grid, np, n3, d_w2);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

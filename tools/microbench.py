@@ -52,6 +52,9 @@ elif what == "gemm":
         timeit(lambda: ops.gemm(x, w, m, n, k, k, k, False, True), f"fwd  x[{m},{k}] W[{n},{k}]^T", fl)
         timeit(lambda: ops.gemm(dy, w, m, k, n, n, k, False, False), f"dx   dy[{m},{n}] W[{n},{k}]", fl)
         timeit(lambda: ops.gemm(dy, x, n, k, m, n, k, True, False), f"dW   dy^T[{n},{m}] x[{m},{k}]", fl)
+        wb = w.bfloat16()
+        timeit(lambda: ops.gemm(x, wb, m, n, k, k, k, False, True), f"fwd  (bf16 W)", fl)
+        timeit(lambda: ops.gemm(dy, wb, m, k, n, n, k, False, False), f"dx   (bf16 W)", fl)
         mb = (m * k + m * n + n * k) * 4 / 1e6
         print(f"     (operand + result bytes {mb:.0f} MB -> {mb / 5e3 * 1e3:.1f} us at 5 TB/s)")
 elif what == "graph":
