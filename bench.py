@@ -131,9 +131,12 @@ def main():
     from gaot_3d_amd.optim import AdamW   # fused multi-tensor HIP step, same semantics as torch.optim.AdamW (tests)
     opt = AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5)
 
-    batch, tokens = make_synthetic_sample(args.points, latent, k=args.knn, seed=args.seed, device=str(dev))
+    # Weak scaling (the path shards by mesh points): every GPU owns --points points of ONE sample of
+    # world x --points points (N = 1: configs[1], 500 K points; N = 8: a 4 M-point sample, between configs[1] and the
+    # 8-10 M-point configs[4]); latent grid, Transformer and parameters are replicated, as the north star prescribes.
+    n_total = args.points * world
+    batch, tokens = make_synthetic_sample(n_total, latent, k=args.knn, seed=args.seed, device=str(dev))
     tokens = tokens.to(dev)
-    n_total = args.points
     if world > 1:
         from gaot_3d_amd import sharding
         batch = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
@@ -258,16 +261,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: one {n_total}-point car-like surface sample (pos+normals), latent "
+            "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] x ' + str(world) + ' points'}: one {n_total}-point car-like surface sample (pos+normals), latent "
                                    f"{latent[0]}x{latent[1]}x{latent[2]}, knn k={args.knn} encoder + flipped decoder, "
                                    f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, MSE + AdamW step; CSR build and "
                                    f"geoembed stats inside the step",
                        "points": n_total, "latent_tokens": list(latent), "edges": e, "layers": args.layers,
-                       "precision": args.precision, "sharding": f"point-shard x{world}" if world > 1 else "none"},
+                       "precision": args.precision, "points_per_gpu": args.points,
+                       "sharding": f"point-shard x{world}, latent grid / Transformer replicated" if world > 1 else "none"},
             "loss": float(loss.detach()),
             "launch": "hipGraph replay of one captured step" if graph is not None else "eager",
             # wall time of the two instrumented eager steps (only meaningful without a captured graph: right after a
