@@ -94,6 +94,75 @@ __global__ void k_geo_raw(const float* __restrict__ src_pos, const float* __rest
     }
 }
 
+// ---- point-sharded form: additive moments per query row, combined across ranks, then finished ---------------------
+// mom[row][12] = {N, sum d, sum d^2, sum u (3), sum u u^T (xx, xy, xz, yy, yz, zz)} with u = x - q in fp64: every entry is
+// a plain sum over the row's edges, so the rows of a sample whose edges are spread over several GPUs are obtained by a
+// SUM all-reduce of the per-rank moments (gaot_3d_amd/sharding.py) -- no rank needs the full geometry.
+constexpr int NM = 12;
+__global__ void k_geo_moments(const float* __restrict__ src_pos, const float* __restrict__ q_pos,
+                              const int* __restrict__ rowptr, const int* __restrict__ src_sorted, int64_t Q,
+                              double* __restrict__ mom) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    if (row >= Q) return;
+    const int b = rowptr[row], e = rowptr[row + 1];
+    const float qxf = q_pos[row * 3 + 0], qyf = q_pos[row * 3 + 1], qzf = q_pos[row * 3 + 2];
+    double m[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) m[i] = 0.0;
+    for (int i = b + gl; i < e; i += G) {
+        const int s = src_sorted[i];
+        const float fx = src_pos[(int64_t)s * 3 + 0], fy = src_pos[(int64_t)s * 3 + 1], fz = src_pos[(int64_t)s * 3 + 2];
+        const float dx = fx - qxf, dy = fy - qyf, dz = fz - qzf;          // fp32 difference and norm, as the reference
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        const double ux = (double)fx - (double)qxf, uy = (double)fy - (double)qyf, uz = (double)fz - (double)qzf;
+        m[1] += dist; m[2] += (double)dist * (double)dist;
+        m[3] += ux; m[4] += uy; m[5] += uz;
+        m[6] += ux * ux; m[7] += ux * uy; m[8] += ux * uz; m[9] += uy * uy; m[10] += uy * uz; m[11] += uz * uz;
+    }
+#pragma unroll
+    for (int i = 1; i < NM; ++i) m[i] = grp_sum(m[i]);
+    m[0] = (double)(e - b);
+    if (gl == 0) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mom[row * NM + i] = m[i];
+    }
+}
+
+__global__ void k_geo_from_moments(const double* __restrict__ mom, int64_t Q, float* __restrict__ feat) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Q) return;
+    const double* m = mom + row * NM;
+    float out[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) out[i] = 0.f;
+    const double n = m[0];
+    if (n > 0.5) {
+        const double inv = 1.0 / n;
+        const double davg = m[1] * inv;
+        double dvar = m[2] * inv - davg * davg;
+        if (dvar < 0.0) dvar = 0.0;
+        const double ux = m[3] * inv, uy = m[4] * inv, uz = m[5] * inv;     // centroid - query
+        double a00 = m[6] * inv - ux * ux + 1e-6, a11 = m[9] * inv - uy * uy + 1e-6, a22 = m[11] * inv - uz * uz + 1e-6;
+        double a01 = m[7] * inv - ux * uy, a02 = m[8] * inv - ux * uz, a12 = m[10] * inv - uy * uz;
+#pragma unroll 1
+        for (int sweep = 0; sweep < 8; ++sweep) {
+            jacobi_rot(a00, a11, a01, a02, a12);
+            jacobi_rot(a00, a22, a02, a01, a12);
+            jacobi_rot(a11, a22, a12, a01, a02);
+        }
+        double l0 = a00, l1 = a11, l2 = a22, t;
+        if (l0 < l1) { t = l0; l0 = l1; l1 = t; }
+        if (l0 < l2) { t = l0; l0 = l2; l2 = t; }
+        if (l1 < l2) { t = l1; l1 = l2; l2 = t; }
+        out[0] = (float)n; out[1] = (float)davg; out[2] = (float)dvar;
+        out[3] = (float)ux; out[4] = (float)uy; out[5] = (float)uz;
+        out[6] = (float)l0; out[7] = (float)l1; out[8] = (float)l2;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) feat[row * NF + i] = out[i];
+}
+
 // per-block partial column sums (sum, sum of squares) in double
 __global__ void k_geo_colpart(const float* __restrict__ feat, int64_t Q, double* __restrict__ part) {
     __shared__ double sm[4][2 * NF];
@@ -163,6 +232,38 @@ extern "C" int gaot_geoembed_stats(const float* source_pos, const float* query_p
     const int64_t threads = num_queries * G;
     hipLaunchKernelGGL(k_geo_raw, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, source_pos, query_pos,
                        rowptr_dst, src_sorted, num_queries, features);
+    const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
+    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);
+    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+                       num_queries, stats);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_geoembed_moments(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
+                                     const int32_t* src_sorted, int64_t num_queries, double* moments, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_queries >= 0, "negative size");
+    if (num_queries == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && moments, "null pointer");
+    hipLaunchKernelGGL(k_geo_moments, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, (hipStream_t)stream, source_pos,
+                       query_pos, rowptr_dst, src_sorted, num_queries, moments);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_geoembed_from_moments(const double* moments, int64_t num_queries, float* features, void* workspace,
+                                          size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_queries >= 0, "negative size");
+    if (num_queries == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(moments && features && workspace, "null pointer");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    float* stats = (float*)(part + 256 * 2 * NF);
+    hipLaunchKernelGGL(k_geo_from_moments, dim3((unsigned)ceil_div(num_queries, 256)), dim3(256), 0, st, moments, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
     hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
     hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);

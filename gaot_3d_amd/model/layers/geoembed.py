@@ -31,11 +31,19 @@ class GeometricEmbedding(nn.Module):
 
     def forward(self, source_pos, query_pos, edge_index, batch_source: Optional[torch.Tensor] = None,
                 batch_query: Optional[torch.Tensor] = None, neighbors_counts: Optional[torch.Tensor] = None,
-                graph=None):
+                graph=None, shard_group=None):
+        """``shard_group`` (extension, gaot_3d_amd/sharding.py): the edges of this sample are spread over the ranks of
+        the group; the per-row statistics are assembled from additive fp64 moments with one SUM all-reduce."""
         if self.method != "statistical":
             raise NotImplementedError("GeometricEmbedding(method='pointnet') is not implemented on the HIP path")
         if graph is None:
             graph = graph_for(edge_index.to(query_pos.device), source_pos.shape[0], query_pos.shape[0])
-        feats = ops.geoembed_stats(source_pos, query_pos, graph)  # geometry only: no autograd through it
+        if shard_group is not None:
+            import torch.distributed as dist
+            mom = ops.geoembed_moments(source_pos, query_pos, graph)
+            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group)
+            feats = ops.geoembed_from_moments(mom)
+        else:
+            feats = ops.geoembed_stats(source_pos, query_pos, graph)  # geometry only: no autograd through it
         h = GF.linear(feats, self.mlp[0].weight, self.mlp[0].bias, act="relu", precision=0)
         return GF.linear(h, self.mlp[2].weight, self.mlp[2].bias, precision=0)

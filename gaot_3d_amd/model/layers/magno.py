@@ -256,19 +256,14 @@ class MAGNOEncoder(nn.Module):
             enc = self.gno(y_pos=phys_pos, x_pos=latent_tokens_pos, edge_index=edge_index, f_y=lifted,
                            graph=g) if self.use_gno else None
             shard_group = getattr(self, "_shard_group", None)
-            geo_pos, geo_edges, geo_graph = phys_pos, edge_index, g
-            if shard_group is not None:
-                # point-sharded sample (gaot_3d_amd/sharding.py): the local mean becomes the mean over every
-                # rank's edges; the geometry-only GeoEmbed statistics sweep the full point set on every rank
+            if shard_group is not None and enc is not None:
+                # point-sharded sample (gaot_3d_amd/sharding.py): the local mean becomes the mean over every rank's edges
                 from ...sharding import GlobalSegmentMeanFn
-                if enc is not None:
-                    deg = (g.by_dst.rowptr[1:] - g.by_dst.rowptr[:-1]).to(enc.dtype)
-                    enc = GlobalSegmentMeanFn.apply(enc, deg, shard_group)
-                if self.use_geoembed:
-                    geo_pos = batch.geo_pos
-                    geo_edges = getattr(batch, f"geo_encoder_edge_index_s{si}").to(device)
-                    geo_graph = graph_for(geo_edges, geo_pos.shape[0], latent_tokens_pos.shape[0], batch, ("geo", si))
-            geo = self.geoembed(geo_pos, latent_tokens_pos, geo_edges, graph=geo_graph) if self.use_geoembed else None
+                deg = (g.by_dst.rowptr[1:] - g.by_dst.rowptr[:-1]).to(enc.dtype)
+                enc = GlobalSegmentMeanFn.apply(enc, deg, shard_group)
+            # GeoEmbed statistics of a sharded sample: additive moments of the local edges, summed over the ranks
+            geo = self.geoembed(phys_pos, latent_tokens_pos, edge_index, graph=g, shard_group=shard_group) \
+                if self.use_geoembed else None
             if enc is not None and geo is not None:
                 enc = GF.cat_linear([enc, geo], self.recovery.fcs[0].weight, self.recovery.fcs[0].bias, precision=0)
             elif enc is None and geo is not None:

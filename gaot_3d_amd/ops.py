@@ -425,6 +425,28 @@ def geoembed_stats(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> 
     return feat
 
 
+def geoembed_moments(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> Tensor:
+    """fp64 [Q, 12] additive moments of every query row's neighbourhood (include/gaot3d_hip.h: gaot_geoembed_moments)"""
+    lib = _lib.load()
+    source_pos = _req(source_pos, torch.float32, "source_pos")
+    query_pos = _req(query_pos, torch.float32, "query_pos")
+    if source_pos.shape[1] != 3:
+        raise GaotError("geoembed statistical features: coord_dim must be 3 on the HIP path")
+    mom = torch.empty(g.num_dst, 12, dtype=torch.float64, device=query_pos.device)
+    check(lib.gaot_geoembed_moments(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), g.num_dst,
+                                    _ptr(mom), _stream()), "gaot_geoembed_moments")
+    return mom
+
+
+def geoembed_from_moments(mom: Tensor) -> Tensor:
+    lib = _lib.load()
+    q = mom.shape[0]
+    feat = torch.empty(q, 9, dtype=torch.float32, device=mom.device)
+    ws = _ws(lib.gaot_geoembed_stats_workspace_bytes(), mom.device)
+    check(lib.gaot_geoembed_from_moments(_ptr(mom), q, _ptr(feat), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_from_moments")
+    return feat
+
+
 def _ptr_array(ts):
     arr = (C.c_void_p * len(ts))()
     for i, t in enumerate(ts):

@@ -12,8 +12,10 @@ Exchange steps (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gl
   after backward: gradients of the per-point / per-edge parameters (encoder.lifting, encoder.gno, decoder.*)
             are partial sums -> one flat all_reduce (~125 KB).  Per-token parameters (encoder.geoembed,
             encoder.recovery, patch_linear, processor.*) see identical full gradients on every rank.
-The geometry-only GeoEmbed statistics of the encoder need every point of the sample: the shard keeps the full
-coordinate array and the full encoder edge list for that one sweep (no gradients flow through it).
+The geometry-only GeoEmbed statistics of the encoder are sums over each token's edges, which are spread over the
+ranks: every rank reduces its own edges to additive fp64 moments [M,12] (count, sum d, sum d^2, sum u, sum u u^T),
+one SUM all_reduce (12.6 MB) combines them and every rank finishes the features (csrc/geoembed.hip) -- no rank holds
+the full geometry, and the per-step work stays proportional to the local points.
 """
 from __future__ import annotations
 
@@ -35,8 +37,7 @@ def shard_range(n: int, rank: int, world: int):
 
 def shard_batch(batch: MeshBatch, rank: int, world: int, num_latent: int) -> MeshBatch:
     """Rank-local view of a single-graph batch: points [lo,hi), their features/targets, and the edges whose
-    physical endpoint is in the range, re-indexed to local point ids.  Adds ``geo_pos`` /
-    ``geo_encoder_edge_index_s*`` (full geometry) for the encoder's GeoEmbed statistics."""
+    physical endpoint is in the range, re-indexed to local point ids."""
     if getattr(batch, "num_graphs", 1) != 1:
         raise ValueError("point-sharding splits ONE sample; batch several samples with DDP instead")
     n = batch.pos.shape[0]
@@ -53,7 +54,6 @@ def shard_batch(batch: MeshBatch, rank: int, world: int, num_latent: int) -> Mes
             e = v[:, m].clone()
             e[0] -= lo
             setattr(out, k, e)
-            setattr(out, "geo_" + k, v)
         elif k.startswith("decoder_edge_index"):
             m = (v[1] >= lo) & (v[1] < hi)
             e = v[:, m].clone()
@@ -65,7 +65,6 @@ def shard_batch(batch: MeshBatch, rank: int, world: int, num_latent: int) -> Mes
             setattr(out, k, v[lo:hi].contiguous())
         else:
             setattr(out, k, v)
-    out.geo_pos = batch.pos
     out.num_graphs = 1
     out.shard = (rank, world, lo, hi, n)
     out.ptr = torch.tensor([0, hi - lo], dtype=torch.long, device=batch.pos.device)

@@ -97,6 +97,13 @@ size_t gaot_geoembed_stats_workspace_bytes(void);
 int gaot_geoembed_stats(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
                         const int32_t* src_sorted, int64_t num_queries, float* features, void* workspace,
                         size_t workspace_bytes, gaot_stream_t stream);
+/* The same features for a point-sharded sample: moments[row][12] = {N, sum d, sum d^2, sum u (3), sum u u^T (6)}, u = x - q
+ * (fp64) are plain sums over the row's edges -> SUM all-reduce them across the ranks that hold the edges, then
+ * gaot_geoembed_from_moments finishes (variance, centred covariance, eigenvalues, column z-score) on every rank. */
+int gaot_geoembed_moments(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
+                          const int32_t* src_sorted, int64_t num_queries, double* moments, gaot_stream_t stream);
+int gaot_geoembed_from_moments(const double* moments, int64_t num_queries, float* features, void* workspace,
+                               size_t workspace_bytes, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM  C[m][n] = act(sum_k A(m,k) B(k,n) + bias[n]) + residual[m][n]   (row-major, fp32 I/O)
