@@ -149,9 +149,11 @@ template <int OCC, int TPM>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    // head-fastest workgroup order: consecutive workgroup ids go to consecutive XCDs, so with 8 heads every XCD
+    // streams ONE head's K / V (2 MB at S = 16384) through its own 4-MB L2 instead of all eight heads' 16 MB
+    const int head = blockIdx.x % a.H, b = blockIdx.z;
     const int hkv = head / (a.H / a.HKV);
-    const int64_t q0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t q0 = (int64_t)(blockIdx.x / a.H) * 128 + wave * 32;
     const int64_t rowbase = (int64_t)b * a.S;
     const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
     const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
@@ -281,9 +283,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lse_s[64];
     __shared__ __attribute__((aligned(16))) float del_s[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
-    const int hkv = blockIdx.y, b = blockIdx.z;
+    const int hkv = blockIdx.x % a.HKV, b = blockIdx.z;   // head-fastest order: one (kv) head per XCD (see k_attn_fwd_bf16)
     const int rep = a.H / a.HKV;
-    const int64_t key0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t key0 = (int64_t)(blockIdx.x / a.HKV) * 128 + wave * 32;
     const int64_t rowbase = (int64_t)b * a.S;
     const int64_t ki = key0 + l31;
     bf16x8 kf[2], vf[2];
@@ -405,9 +407,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lse_s[QS];
     __shared__ __attribute__((aligned(16))) float del_s[QS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
-    const int hkv = blockIdx.y, b = blockIdx.z;
+    const int hkv = blockIdx.x % a.HKV, b = blockIdx.z;   // head-fastest order: one (kv) head per XCD
     const int rep = a.H / a.HKV;
-    const int64_t key0 = (int64_t)blockIdx.x * (128 * KB) + wave * (32 * KB);
+    const int64_t key0 = (int64_t)(blockIdx.x / a.HKV) * (128 * KB) + wave * (32 * KB);
     const int64_t rowbase = (int64_t)b * a.S;
     bf16x8 kf[KB][2], vf[KB][2];
 #pragma unroll
@@ -523,9 +525,11 @@ template <int OCC>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    // head-fastest workgroup order: consecutive workgroup ids go to consecutive XCDs, so with 8 heads every XCD
+    // streams ONE head's K / V (2 MB at S = 16384) through its own 4-MB L2 instead of all eight heads' 16 MB
+    const int head = blockIdx.x % a.H, b = blockIdx.z;
     const int hkv = head / (a.H / a.HKV);
-    const int64_t q0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t q0 = (int64_t)(blockIdx.x / a.H) * 128 + wave * 32;
     const int64_t rowbase = (int64_t)b * a.S;
     const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
     const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
@@ -604,9 +608,9 @@ template <int QB, int NT, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * NT * TILE_BYTES];  // K tiles, then V tiles
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const int head = blockIdx.x % a.H, b = blockIdx.z;   // head-fastest order: one head per XCD
     const int hkv = head / (a.H / a.HKV);
-    const int64_t q0 = (int64_t)blockIdx.x * (128 * QB) + wave * (32 * QB);
+    const int64_t q0 = (int64_t)(blockIdx.x / a.H) * (128 * QB) + wave * (32 * QB);
     const int64_t rowbase = (int64_t)b * a.S;
     const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
     const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
@@ -714,7 +718,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
     FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
-    const dim3 fgrid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
+    const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
     // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
@@ -744,15 +748,15 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups
         if ((int64_t)ceil_div(S, 256) * HKV * B >= 512)
-            hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2>), dim3((unsigned)ceil_div(S, 256), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2>), dim3((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)(ceil_div(S, 128) * HKV), 1, (unsigned)B), dim3(256), 0, st, a);
     }
     if (phase_mask & 4) {
         if ((int64_t)ceil_div(S, 256) * H * B >= 512)   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
-            hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2>), dim3((unsigned)ceil_div(S, 256), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2>), dim3((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B), dim3(256), 0, st, a);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
     char* lb = lds + TA::BYTES;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t bm = (int64_t)blockIdx.y * BM, bn = (int64_t)blockIdx.x * BN;
+    // row-block-fastest workgroup order: consecutive ids (-> consecutive XCDs) take consecutive row blocks of the SAME
+    // column block, so an XCD keeps re-using its own 1/8 of A (2 MB at M = 16 384, K = 256) from its L2 across all
+    // column blocks, and the column block's weight slice is shared by everyone
+    // (the split-K weight gradients, A_KS, keep column-block-fastest order: measured faster there)
+    const int64_t bm = (int64_t)(A_KS ? blockIdx.y : blockIdx.x) * BM, bn = (int64_t)(A_KS ? blockIdx.x : blockIdx.y) * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
     const int64_t kend = (g.splits > 1) ? ((kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K) : g.K;
     // the two operands must walk k in the same order inside a 16-step: if exactly one of them is k-strided
@@ -341,7 +345,8 @@ int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) 
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits);
+    dim3 grid(A_KS ? (unsigned)ceil_div(g.N, BN) : (unsigned)ceil_div(g.M, BM), A_KS ? (unsigned)ceil_div(g.M, BM) : (unsigned)ceil_div(g.N, BN),
+              (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
     return GAOT_OK;
 }
