@@ -240,9 +240,24 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
     // row-block-fastest workgroup order: consecutive ids (-> consecutive XCDs) take consecutive row blocks of the SAME
     // column block, so an XCD keeps re-using its own 1/8 of A (2 MB at M = 16 384, K = 256) from its L2 across all
     // column blocks, and the column block's weight slice is shared by everyone
-    // (the split-K weight gradients, A_KS, keep column-block-fastest order: measured faster there)
-    const int64_t bm = (int64_t)(A_KS ? blockIdx.y : blockIdx.x) * BM, bn = (int64_t)(A_KS ? blockIdx.x : blockIdx.y) * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    // The split-K weight gradients (A_KS) are launched as a 1-D grid: all row blocks of one (split, column block) group
+    // read the same k-slab of B, so a whole group is given to ONE XCD (id % 8) when the group count allows it.
+    int bxm, bxn, bz;
+    if constexpr (A_KS) {
+        const int nbm = (int)((g.M + BM - 1) / BM), nbn = (int)((g.N + BN - 1) / BN);
+        const int i = blockIdx.x, groups = nbn * g.splits;
+        if (groups % 8 == 0) {
+            const int xcd = i & 7, j = i >> 3;
+            const int grp = (j / nbm) * 8 + xcd;
+            bxm = j % nbm; bxn = grp % nbn; bz = grp / nbn;
+        } else {
+            bxn = i % nbn; bxm = (i / nbn) % nbm; bz = i / (nbn * nbm);
+        }
+    } else {
+        bxm = blockIdx.x; bxn = blockIdx.y; bz = blockIdx.z;
+    }
+    const int64_t bm = (int64_t)bxm * BM, bn = (int64_t)bxn * BN;
+    const int64_t kbeg = (int64_t)bz * g.k_per_split;
     const int64_t kend = (g.splits > 1) ? ((kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K) : g.K;
     // the two operands must walk k in the same order inside a 16-step: if exactly one of them is k-strided
     // (transposed reads), the k-contiguous one gathers its 8 elements in that order as well
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
                 if (m >= g.M) continue;
                 float v = acc[i][j][r];
                 if (g.splits > 1) {
-                    ((float*)g.C)[((int64_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                    ((float*)g.C)[((int64_t)bz * g.M + m) * g.N + n] = v;
                 } else {
                     v += bv;
                     if (g.preact) g.preact[m * g.ldc + n] = v;
@@ -345,8 +360,8 @@ int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) 
         }
         attr_set = true;
     }
-    dim3 grid(A_KS ? (unsigned)ceil_div(g.N, BN) : (unsigned)ceil_div(g.M, BM), A_KS ? (unsigned)ceil_div(g.M, BM) : (unsigned)ceil_div(g.N, BN),
-              (unsigned)splits);
+    dim3 grid((unsigned)ceil_div(g.M, BM), (unsigned)ceil_div(g.N, BN), (unsigned)splits);
+    if (A_KS) grid = dim3((unsigned)(ceil_div(g.M, BM) * ceil_div(g.N, BN) * splits), 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
     return GAOT_OK;
 }
