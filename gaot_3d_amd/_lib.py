@@ -51,11 +51,12 @@ SIGNATURES = {
     "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
     "gaot_gemm_ex": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p, _i, _p,
                           _sz, _p]),
-    "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
+    "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _p]),
+    "gaot_attn_dropout_mask": (_i, [_p, _f, _i, _i, _i, _p, _p]),
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
-    "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
+    "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
@@ -103,7 +104,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 2:
+    if lib.gaot_abi_version() != 3:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

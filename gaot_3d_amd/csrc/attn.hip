@@ -13,6 +13,7 @@
 //   dQ      : S^T, dP^T with the wave's queries on lanes;            dQ^T += K^T dS^T
 // dQ is produced by its own pass (no float atomics: results are bit-reproducible).
 #include "common.h"
+#include "attn_dropout.h"
 
 namespace {
 
@@ -27,6 +28,7 @@ struct AttnArgs {
     int64_t ldq, ldk, ldv, ldo;
     int B, S, H, HKV;
     float scale;
+    gdrop::Drop drop;
 };
 
 struct AttnBwdArgs {
@@ -36,7 +38,29 @@ struct AttnBwdArgs {
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, S, H, HKV;
     float scale;
+    gdrop::Drop drop;
 };
+
+// dropout words (csrc/attn_dropout.h).  Lanes that hold ONE query and the 32 keys of a tile in runs of 4 (forward,
+// dQ) read their 8 key-pair words from bw_s, stored [hf][g][pair]; lanes that hold ONE key and runs of queries
+// (dK/dV) read the row words of the tile's queries, split into halfword copies [parity][32].
+__device__ __forceinline__ void stage_col_words(uint32_t* bw_s, uint32_t ck, int64_t k0) {
+    if (threadIdx.x < 16) {
+        const int jj = threadIdx.x;
+        bw_s[((jj >> 1) & 1) * 8 + (jj >> 2) * 2 + (jj & 1)] = gdrop::col_word(ck, (uint32_t)(k0 >> 1) + jj);
+    }
+}
+// keep flags of the lane's 16 rows (bit r = row r of the accumulator layout)
+__device__ __forceinline__ uint32_t keep_bits_cols(uint32_t aw, const uint32_t* bw_s, int hf, uint32_t thr) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = aw ^ bw_s[hf * 8 + j];
+        bits |= ((x & 0xffffu) >= thr ? 1u : 0u) << (2 * j);
+        bits |= ((x >> 16) >= thr ? 1u : 0u) << (2 * j + 1);
+    }
+    return bits;
+}
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
@@ -56,9 +80,11 @@ __device__ __forceinline__ void tile_st(float* lds, int pitch, float4 t) {
 // ------------------------------------------------------------------------------------------------
 // forward: block = 4 waves x 32 queries; grid (ceil(S/128), H, B)
 // ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_fwd_f32(AttnArgs a) {
     __shared__ float Ks[32 * LDP];
     __shared__ float Vs[32 * LDP];
+    __shared__ uint32_t bw_s[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int hkv = head / (a.H / a.HKV);
@@ -79,12 +105,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_f32(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    uint32_t aw = 0, ck = 0;
+    if constexpr (DROP) {
+        const unsigned long long seed = *a.drop.seed;
+        const int bh = b * a.H + head;
+        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31));
+        ck = gdrop::col_key(seed, bh);
+    }
 
     float4 kt = tile_ld(kp, a.ldk, 0, a.S), vt = tile_ld(vp, a.ldv, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 32) {
         __syncthreads();
         tile_st(Ks, LDP, kt);
         tile_st(Vs, LDP, vt);
+        if constexpr (DROP) stage_col_words(bw_s, ck, k0);
         __syncthreads();
         if (k0 + 32 < a.S) {
             kt = tile_ld(kp, a.ldk, k0 + 32, a.S);
@@ -115,8 +149,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_f32(AttnArgs a) {
             ps += s[r];
         }
         ps += xhalf(ps);
-        l = l * alpha + ps;
+        l = l * alpha + ps;   // the normaliser is the UNdropped row sum
         m = mn;
+        if constexpr (DROP) {
+            const uint32_t kb = keep_bits_cols(aw, bw_s, hf, a.drop.thr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = ((kb >> r) & 1u) ? s[r] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] *= alpha;
         // O^T[d][q] += V^T[d][key] P^T[key][q]
@@ -126,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_f32(AttnArgs a) {
     }
     const int64_t qi = q0 + l31;
     if (qi < a.S) {
-        const float inv = 1.f / l;
+        const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
         float* op = a.o + (rowbase + qi) * a.ldo + head * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -162,11 +201,18 @@ __global__ void k_attn_delta(AttnBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV: block = 4 waves x 32 keys; grid (ceil(S/128), HKV, B); loops over the group's q heads
 // ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
     __shared__ float Qs[32 * LDP];
     __shared__ float dOs[32 * LDP];
     __shared__ float lse_s[32];
     __shared__ float del_s[32];
+    __shared__ uint32_t aw_s[64];
+    // dropout: dP = keep * (dO.V) / (1-p); the kernel forms (1-p) * dS (delta staged times (1-p)) and rescales
+    // dK -- and dV, accumulated from keep * P -- by 1/(1-p) at the end
+    const float dscale = DROP ? a.drop.keep : 1.f;
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.y, b = blockIdx.z;
     const int rep = a.H / a.HKV;
@@ -198,13 +244,27 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
         float lt = 0.f, et = 0.f;
         if (threadIdx.x < 32) {
             lt = (threadIdx.x < a.S) ? lsep[threadIdx.x] * LOG2E : INFINITY;
-            et = (threadIdx.x < a.S) ? delp[threadIdx.x] : 0.f;
+            et = (threadIdx.x < a.S) ? delp[threadIdx.x] * dscale : 0.f;
+        }
+        uint32_t rk = 0, bsel = 0;
+        if constexpr (DROP) {
+            const int bh = b * a.H + head;
+            rk = gdrop::row_key(seed, bh);
+            const uint32_t bw = gdrop::col_word(gdrop::col_key(seed, bh), (uint32_t)(ki >> 1));
+            bsel = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
         }
         for (int64_t q0 = 0; q0 < a.S; q0 += 32) {
             __syncthreads();
             tile_st(Qs, LDP, qt);
             tile_st(dOs, LDP, dt);
             if (threadIdx.x < 32) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if constexpr (DROP) {
+                if (threadIdx.x < 32) {
+                    const uint32_t w = gdrop::row_word(rk, (uint32_t)q0 + threadIdx.x);
+                    aw_s[threadIdx.x] = w & 0xffffu;
+                    aw_s[32 + threadIdx.x] = w >> 16;
+                }
+            }
             __syncthreads();
             if (q0 + 32 < a.S) {
                 qt = tile_ld(qp, a.ldq, q0 + 32, a.S);
@@ -212,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
                 if (threadIdx.x < 32) {
                     const int64_t qq = q0 + 32 + threadIdx.x;
                     lt = (qq < a.S) ? lsep[qq] * LOG2E : INFINITY;
-                    et = (qq < a.S) ? delp[qq] : 0.f;
+                    et = (qq < a.S) ? delp[qq] * dscale : 0.f;
                 }
             }
             // S[q][key] ; dP[q][key]
@@ -228,8 +288,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int qr = mfma32_row(r, hf);
                 const float p = exp2f(s[r] - lse_s[qr]);
-                s[r] = p;                          // P
-                dp[r] = p * (dp[r] - del_s[qr]);   // dS (without the 1/sqrt(d) factor)
+                bool keep = true;
+                if constexpr (DROP) keep = (aw_s[(l31 & 1) * 32 + qr] ^ bsel) >= a.drop.thr;
+                s[r] = keep ? p : 0.f;                                  // (kept) P
+                dp[r] = p * ((keep ? dp[r] : 0.f) - del_s[qr]);         // dS (without the 1/sqrt(d) factor)
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
@@ -246,10 +308,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
         float* dvp = a.dv + (rowbase + ki) * a.lddv + hkv * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 t = make_float4(dkt[4 * g] * a.scale, dkt[4 * g + 1] * a.scale, dkt[4 * g + 2] * a.scale,
-                                   dkt[4 * g + 3] * a.scale);
+            const float vsc = DROP ? a.drop.inv_keep : 1.f, ksc = a.scale * vsc;
+            float4 t = make_float4(dkt[4 * g] * ksc, dkt[4 * g + 1] * ksc, dkt[4 * g + 2] * ksc, dkt[4 * g + 3] * ksc);
             *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
-            float4 u = make_float4(dvt[4 * g], dvt[4 * g + 1], dvt[4 * g + 2], dvt[4 * g + 3]);
+            float4 u = make_float4(dvt[4 * g] * vsc, dvt[4 * g + 1] * vsc, dvt[4 * g + 2] * vsc, dvt[4 * g + 3] * vsc);
             *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
         }
     }
@@ -258,9 +320,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dQ: block = 4 waves x 32 queries; grid (ceil(S/128), H, B)
 // ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_f32(AttnBwdArgs a) {
     __shared__ float Ks[32 * LDP];
     __shared__ float Vs[32 * LDP];
+    __shared__ uint32_t bw_s[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int hkv = head / (a.H / a.HKV);
@@ -281,16 +345,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_f32(AttnBwdArgs a) {
         }
     }
     const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
-    const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
+    const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] * (DROP ? a.drop.keep : 1.f) : 0.f;
     f32x16 dqt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+    uint32_t aw = 0, ck = 0;
+    if constexpr (DROP) {
+        const unsigned long long seed = *a.drop.seed;
+        const int bh = b * a.H + head;
+        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
+        ck = gdrop::col_key(seed, bh);
+    }
 
     float4 kt = tile_ld(kp, a.ldk, 0, a.S), vt = tile_ld(vp, a.ldv, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 32) {
         __syncthreads();
         tile_st(Ks, LDP, kt);
         tile_st(Vs, LDP, vt);
+        if constexpr (DROP) stage_col_words(bw_s, ck, k0);
         __syncthreads();
         if (k0 + 32 < a.S) {
             kt = tile_ld(kp, a.ldk, k0 + 32, a.S);
@@ -304,11 +376,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_f32(AttnBwdArgs a) {
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * LDP + 2 * i + hf], qreg[i], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[l31 * LDP + 2 * i + hf], doreg[i], dp, 0, 0, 0);
         }
+        uint32_t kbits = 0xffffu;
+        if constexpr (DROP) kbits = keep_bits_cols(aw, bw_s, hf, a.drop.thr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float p = exp2f(s[r] - lse2);
             if (k0 + mfma32_row(r, hf) >= a.S) p = 0.f;
-            dp[r] = p * (dp[r] - del);
+            dp[r] = p * ((((kbits >> r) & 1u) ? dp[r] : 0.f) - del);
         }
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
@@ -319,11 +393,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_f32(AttnBwdArgs a) {
         float* dqp = a.dq + (rowbase + qi) * a.lddq + head * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 t = make_float4(dqt[4 * g] * a.scale, dqt[4 * g + 1] * a.scale, dqt[4 * g + 2] * a.scale,
-                                   dqt[4 * g + 3] * a.scale);
+            const float qsc = DROP ? a.scale * a.drop.inv_keep : a.scale;
+            float4 t = make_float4(dqt[4 * g] * qsc, dqt[4 * g + 1] * qsc, dqt[4 * g + 2] * qsc, dqt[4 * g + 3] * qsc);
             *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
         }
     }
+}
+
+// keep[b][h][q][k] of the dropout mask, one byte per element (checks and the oracle comparison only)
+__global__ void k_dropout_mask(gdrop::Drop d, int H, int S, int64_t n, unsigned char* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long seed = *d.seed;
+    const int k = (int)(i % S);
+    const int q = (int)((i / S) % S);
+    const int bh = (int)(i / ((int64_t)S * S));
+    keep[i] = gdrop::keep_elem(gdrop::row_key(seed, bh), gdrop::col_key(seed, bh), (uint32_t)q, (uint32_t)k, d.thr) ? 1 : 0;
 }
 
 bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
@@ -332,7 +417,8 @@ bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) &&
 
 extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim,
-                             float scale, int precision, gaot_stream_t stream) {
+                             float scale, float dropout_p, const unsigned long long* dropout_seed, int precision,
+                             gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_fwd: head_dim %d unsupported (only 32)", head_dim);
@@ -342,9 +428,11 @@ extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, flo
     GAOT_CHECK_ARG(q && k && v && o && lse, "null pointer");
     GAOT_CHECK_ARG(aligned16(q, ldq) && aligned16(k, ldk) && aligned16(v, ldv) && aligned16(o, ldo),
                    "q/k/v/o must be 16-byte aligned with row strides that are multiples of 4 floats");
-    AttnArgs a{q, k, v, o, lse, ldq, ldk, ldv, ldo, B, S, H, HKV, scale};
+    GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
+    AttnArgs a{q, k, v, o, lse, ldq, ldk, ldv, ldo, B, S, H, HKV, scale, gdrop::make_drop(dropout_seed, dropout_p)};
     dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(k_attn_fwd_f32, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (a.drop.thr) hipLaunchKernelGGL(k_attn_fwd_f32<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_attn_fwd_f32<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -352,7 +440,8 @@ extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, flo
 extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                              const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk,
                              int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B,
-                             int S, int H, int HKV, int head_dim, float scale, int precision, int phase_mask,
+                             int S, int H, int HKV, int head_dim, float scale, float dropout_p,
+                             const unsigned long long* dropout_seed, int precision, int phase_mask,
                              gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
@@ -364,14 +453,35 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
     GAOT_CHECK_ARG(aligned16(q, ldq) && aligned16(k, ldk) && aligned16(v, ldv) && aligned16(o, ldo) &&
                        aligned16(d_o, lddo) && aligned16(dq, lddq) && aligned16(dk, lddk) && aligned16(dv, lddv),
                    "tensors must be 16-byte aligned with row strides that are multiples of 4 floats");
-    AttnBwdArgs a{q, k, v, o, d_o, lse, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, S, H, HKV, scale};
+    GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
+    AttnBwdArgs a{q, k, v, o, d_o, lse, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, S, H, HKV, scale,
+                  gdrop::make_drop(dropout_seed, dropout_p)};
+    const bool drop = a.drop.thr != 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 1) hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a);
-    if (phase_mask & 2)
-        hipLaunchKernelGGL(k_attn_bwd_dkv_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B), dim3(256), 0, st, a);
-    if (phase_mask & 4)
-        hipLaunchKernelGGL(k_attn_bwd_dq_f32, dim3((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B), dim3(256), 0, st, a);
+    if (phase_mask & 2) {
+        const dim3 g((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B);
+        if (drop) hipLaunchKernelGGL(k_attn_bwd_dkv_f32<true>, g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_attn_bwd_dkv_f32<false>, g, dim3(256), 0, st, a);
+    }
+    if (phase_mask & 4) {
+        const dim3 g((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
+        if (drop) hipLaunchKernelGGL(k_attn_bwd_dq_f32<true>, g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_attn_bwd_dq_f32<false>, g, dim3(256), 0, st, a);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout_p, int B, int H, int S,
+                                      unsigned char* keep, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(B > 0 && H > 0 && S > 0 && dropout_seed && keep, "bad arguments");
+    GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0,1)");
+    const int64_t n = (int64_t)B * H * S * S;
+    hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gdrop::make_drop(dropout_seed, dropout_p), H, S, n, keep);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

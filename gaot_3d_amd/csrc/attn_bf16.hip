@@ -17,6 +17,7 @@
 
 #include <type_traits>
 
+#include "attn_dropout.h"
 #include "common.h"
 #include "tile32.h"
 
@@ -140,14 +141,41 @@ struct FwdArgs {
     float* lse;          // [B][H][S]
     int64_t ld;
     int B, S, H, HKV;
+    gdrop::Drop drop;
 };
+
+// dropout words of one 32-key tile for the lanes that hold ONE query and runs of 4 consecutive keys (rows
+// 8g + 4hf + 0..3): 16 key-pair words per tile, stored as [hf][g][pair] so that a lane reads its 8 words with two
+// ds_read_b128.  Called by the first 16*NTILES threads while they stage the keys k0...
+template <int NTILES>
+__device__ __forceinline__ void stage_col_words(uint32_t* bw_s, uint32_t ck, int64_t k0) {
+    if (threadIdx.x < 16 * NTILES) {
+        const int t = threadIdx.x >> 4, jj = threadIdx.x & 15;
+        bw_s[t * 16 + ((jj >> 1) & 1) * 8 + (jj >> 2) * 2 + (jj & 1)] = gdrop::col_word(ck, (uint32_t)(k0 >> 1) + threadIdx.x);
+    }
+}
+// v[r] = keep(q, key of row r) ? v[r] : other[r]   (aw = the lane's row word, wd = its 8 pair words of the tile)
+template <bool ZERO>
+__device__ __forceinline__ void drop_select(f32x16& v, const f32x16& other, uint32_t aw, const uint32_t* bw_tile, int hf,
+                                            uint32_t thr) {
+    const uint4 w0 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8);
+    const uint4 w1 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8 + 4);
+    const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t x = aw ^ wd[j];
+        v[2 * j] = ((x & 0xffffu) >= thr) ? v[2 * j] : (ZERO ? 0.f : other[2 * j]);
+        v[2 * j + 1] = ((x >> 16) >= thr) ? v[2 * j + 1] : (ZERO ? 0.f : other[2 * j + 1]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
 // ------------------------------------------------------------------------------------------------
-template <int OCC, int TPM>
+template <int OCC, int TPM, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
+    __shared__ __attribute__((aligned(16))) uint32_t bw_s[DROP ? 16 * TPM : 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     // head-fastest workgroup order: consecutive workgroup ids go to consecutive XCDs, so with 8 heads every XCD
     // streams ONE head's K / V (2 MB at S = 16384) through its own 4-MB L2 instead of all eight heads' 16 MB
@@ -175,6 +203,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; negm[r] = 0.f; }
     float m = 0.f, l = 0.f;
+    uint32_t aw = 0, ck = 0;
+    if constexpr (DROP) {
+        const unsigned long long seed = *a.drop.seed;
+        const int bh = b * a.H + head;
+        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31));
+        ck = gdrop::col_key(seed, bh);
+    }
 
     // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
@@ -184,6 +219,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     for (int64_t k0 = 0; k0 < a.S; k0 += 32 * TPM) {
         __syncthreads();
         stage_storeN<TPM>(regs, lds);
+        if constexpr (DROP) stage_col_words<TPM>(bw_s, ck, k0);
         __syncthreads();
         if (k0 + 32 * TPM < a.S) stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, k0 + 32 * TPM, a.S);
         // one 32-key tile at a time.  Fast path (no running max grows): p = exp2(S - m) needs no subtraction and
@@ -228,6 +264,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                 ps1 += sc[r + 1];
             }
             l += ps0 + ps1;   // per-half partial; the halves are added once, after the key loop
+            if constexpr (DROP) drop_select<true>(sc, sc, aw, bw_s + 16 * t, hf, a.drop.thr);   // l stays undropped
             bf16x8 p0, p1;
             acc_to_frags(sc, p0, p1);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
@@ -252,7 +289,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     const int64_t qi = q0 + l31;
     l += xhalf(l);
     if (qi < a.S) {
-        const float inv = 1.f / l;
+        const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
         float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -272,16 +309,41 @@ struct BwdArgs {
     int64_t ld;
     int B, S, H, HKV;
     float scale;
+    gdrop::Drop drop;
 };
+
+// dropout words for the lanes that hold ONE key and runs of queries (dK/dV): the row words of the staged queries,
+// split into their two halfwords (copy 0 = low, copy 1 = high) so that a lane reads the copy its key's parity selects
+template <int QS>
+__device__ __forceinline__ void stage_row_words(uint32_t* aw_s, uint32_t rk, int64_t q0) {
+    if (threadIdx.x < QS) {
+        const uint32_t w = gdrop::row_word(rk, (uint32_t)q0 + threadIdx.x);
+        aw_s[threadIdx.x] = w & 0xffffu;
+        aw_s[QS + threadIdx.x] = w >> 16;
+    }
+}
+__device__ __forceinline__ void load_row_words(uint32_t (&w)[16], const uint32_t* rows32, int hf) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(rows32 + 8 * g4 + 4 * hf);
+        w[4 * g4] = v.x; w[4 * g4 + 1] = v.y; w[4 * g4 + 2] = v.z; w[4 * g4 + 3] = v.w;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // dK / dV: 4 waves x 32 keys; Q / dO tiles stream through LDS; grid (ceil(S/128), HKV, B)
 // ------------------------------------------------------------------------------------------------
-template <int OCC>
+template <int OCC, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // Q0 Q1 dO0 dO1
     __shared__ __attribute__((aligned(16))) float lse_s[64];
     __shared__ __attribute__((aligned(16))) float del_s[64];
+    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 128 : 4];
+    // with dropout the dP tile is (keep ? dO.V : 0) / (1-p) - delta; the kernel works with (1-p) times that, i.e.
+    // delta is staged pre-multiplied by (1-p), and dK is rescaled by 1/(1-p) once at the end (dV likewise)
+    const float dscale = DROP ? a.drop.keep : 1.f;
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.x % a.HKV, b = blockIdx.z;   // head-fastest order: one (kv) head per XCD (see k_attn_fwd_bf16)
     const int rep = a.H / a.HKV;
@@ -318,19 +380,27 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         float lt = 0.f, et = 0.f;
         if (threadIdx.x < 64) {
             lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;   // staged NEGATED: they are the
-            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] : 0.f;                  // initial accumulator values
+            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;         // initial accumulator values
+        }
+        uint32_t rk = 0, bsel = 0;
+        if constexpr (DROP) {
+            const int bh = b * a.H + head;
+            rk = gdrop::row_key(seed, bh);
+            const uint32_t bw = gdrop::col_word(gdrop::col_key(seed, bh), (uint32_t)(ki >> 1));
+            bsel = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
         }
         for (int64_t q0 = 0; q0 < a.S; q0 += 64) {
             __syncthreads();
             stage_store<4>(regs, lds);
             if (threadIdx.x < 64) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if constexpr (DROP) stage_row_words<64>(aw_s, rk, q0);
             __syncthreads();
             if (q0 + 64 < a.S) {
                 stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + 64, a.S);
                 if (threadIdx.x < 64) {
                     const int64_t qq = q0 + 64 + threadIdx.x;
                     lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
-                    et = (qq < a.S) ? -delp[qq] : 0.f;
+                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
                 }
             }
 #pragma unroll 1
@@ -339,7 +409,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                 const char* qt = lds + t * TILE_BYTES;
                 const char* dt = lds + (2 + t) * TILE_BYTES;
                 // accumulators start at -lse[q] / -delta[q] (rows of this lane: 4 runs of 4 consecutive q)
-                f32x16 sc, dp;
+                f32x16 sc, dp, dneg;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const float4 lv = *reinterpret_cast<const float4*>(&lse_s[32 * t + 8 * g4 + 4 * hf]);
@@ -347,16 +417,34 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                     sc[4 * g4] = lv.x; sc[4 * g4 + 1] = lv.y; sc[4 * g4 + 2] = lv.z; sc[4 * g4 + 3] = lv.w;
                     dp[4 * g4] = dv.x; dp[4 * g4 + 1] = dv.y; dp[4 * g4 + 2] = dv.z; dp[4 * g4 + 3] = dv.w;
                 }
+                dneg = dp;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qt, l31, hf, ks), kf[ks], sc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dt, l31, hf, ks), vf[ks], dp, 0, 0, 0);
                 }
+                if constexpr (DROP) {
+                    const uint32_t* awp = aw_s + (l31 & 1) * 64 + 32 * t + 4 * hf;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(sc[r]);   // rows beyond S carry lse = +inf -> p = 0
-                    sc[r] = p;
-                    dp[r] = p * dp[r];
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
+                        const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 4 * g4 + i;
+                            const float p = __builtin_amdgcn_exp2f(sc[r]);
+                            const bool keep = (ww[i] ^ bsel) >= a.drop.thr;
+                            sc[r] = keep ? p : 0.f;
+                            dp[r] = p * (keep ? dp[r] : dneg[r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sc[r]);   // rows beyond S carry lse = +inf -> p = 0
+                        sc[r] = p;
+                        dp[r] = p * dp[r];
+                    }
                 }
                 bf16x8 p0, p1, d0, d1;
                 acc_to_frags(sc, p0, p1);
@@ -372,12 +460,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     if (ki < a.S) {
         float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
         float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
-        const float ksc = 1.0f / LOG2E;  // Q image carries scale*log2e: dK = dS^T (Q*scale) = dS^T Qimg / log2e
+        const float vsc = DROP ? a.drop.inv_keep : 1.f;
+        const float ksc = vsc / LOG2E;  // Q image carries scale*log2e: dK = dS^T (Q*scale) = dS^T Qimg / log2e
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 t = make_float4(dkt[4 * g] * ksc, dkt[4 * g + 1] * ksc, dkt[4 * g + 2] * ksc, dkt[4 * g + 3] * ksc);
             *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
-            float4 u = make_float4(dvt[4 * g], dvt[4 * g + 1], dvt[4 * g + 2], dvt[4 * g + 3]);
+            float4 u = make_float4(dvt[4 * g] * vsc, dvt[4 * g + 1] * vsc, dvt[4 * g + 2] * vsc, dvt[4 * g + 3] * vsc);
             *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
         }
     }
@@ -400,12 +489,16 @@ __device__ __forceinline__ void load_row_consts(f32x16& acc, const float* rows32
 // constant and transposed-fragment reads from the one-block kernel altogether gave 0.58 ms, finer hand
 // interleaving of the MFMA and exp streams nothing -- the kernel is bound by LDS traffic and its waits.
 // ------------------------------------------------------------------------------------------------
-template <int KB, int NT, int OCC>
+template <int KB, int NT, int OCC, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
     constexpr int QS = 32 * NT;
     __shared__ __attribute__((aligned(16))) char lds[2 * NT * TILE_BYTES];  // Q tiles, then dO tiles
     __shared__ __attribute__((aligned(16))) float lse_s[QS];
     __shared__ __attribute__((aligned(16))) float del_s[QS];
+    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 2 * QS : 4];
+    const float dscale = DROP ? a.drop.keep : 1.f;   // see k_attn_bwd_dkv_bf16
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.x % a.HKV, b = blockIdx.z;   // head-fastest order: one (kv) head per XCD
     const int rep = a.H / a.HKV;
@@ -445,19 +538,32 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
         float lt = 0.f, et = 0.f;
         if (threadIdx.x < QS) {
             lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;
-            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] : 0.f;
+            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;
+        }
+        uint32_t rk = 0, bsel[KB];
+        if constexpr (DROP) {
+            const int bh = b * a.H + head;
+            rk = gdrop::row_key(seed, bh);
+            const uint32_t ck = gdrop::col_key(seed, bh);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int64_t ki = key0 + 32 * kb + l31;
+                const uint32_t bw = gdrop::col_word(ck, (uint32_t)(ki >> 1));
+                bsel[kb] = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
+            }
         }
         for (int64_t q0 = 0; q0 < a.S; q0 += QS) {
             __syncthreads();
             stage_storeN<NT>(regs, lds);
             if (threadIdx.x < QS) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if constexpr (DROP) stage_row_words<QS>(aw_s, rk, q0);
             __syncthreads();
             if (q0 + QS < a.S) {
                 stage_loadN<NT>(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + QS, a.S);
                 if (threadIdx.x < QS) {
                     const int64_t qq = q0 + QS + threadIdx.x;
                     lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
-                    et = (qq < a.S) ? -delp[qq] : 0.f;
+                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
                 }
             }
 #pragma unroll 1
@@ -480,13 +586,33 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
                 }
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
+                if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them
+                    const uint32_t* awp = aw_s + (l31 & 1) * QS + 32 * t + 4 * hf;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
+                        const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int r = 4 * g4 + i;
+                                const float p = __builtin_amdgcn_exp2f(sc[kb][r]);
+                                const bool keep = (ww[i] ^ bsel[kb]) >= a.drop.thr;
+                                sc[kb][r] = keep ? p : 0.f;
+                                dp[kb][r] = p * (keep ? dp[kb][r] : dc[r]);
+                            }
+                    }
+                }
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
+                    if constexpr (!DROP) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(sc[kb][r]);   // rows beyond S carry lse = +inf -> p = 0
-                        sc[kb][r] = p;
-                        dp[kb][r] = p * dp[kb][r];
+                        for (int r = 0; r < 16; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(sc[kb][r]);   // rows beyond S carry lse = +inf -> p = 0
+                            sc[kb][r] = p;
+                            dp[kb][r] = p * dp[kb][r];
+                        }
                     }
                     bf16x8 p0, p1, d0, d1;
                     acc_to_frags(sc[kb], p0, p1);
@@ -500,7 +626,8 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
         }
         __syncthreads();
     }
-    const float ksc = 1.0f / LOG2E;
+    const float vsc = DROP ? a.drop.inv_keep : 1.f;
+    const float ksc = vsc / LOG2E;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int64_t ki = key0 + 32 * kb + l31;
@@ -511,7 +638,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
             for (int g = 0; g < 4; ++g) {
                 float4 t = make_float4(dkt[kb][4 * g] * ksc, dkt[kb][4 * g + 1] * ksc, dkt[kb][4 * g + 2] * ksc, dkt[kb][4 * g + 3] * ksc);
                 *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
-                float4 u = make_float4(dvt[kb][4 * g], dvt[kb][4 * g + 1], dvt[kb][4 * g + 2], dvt[kb][4 * g + 3]);
+                float4 u = make_float4(dvt[kb][4 * g] * vsc, dvt[kb][4 * g + 1] * vsc, dvt[kb][4 * g + 2] * vsc, dvt[kb][4 * g + 3] * vsc);
                 *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
             }
         }
@@ -521,9 +648,10 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dQ: 4 waves x 32 queries; K / V tiles stream through LDS; grid (ceil(S/128), H, B)
 // ------------------------------------------------------------------------------------------------
-template <int OCC>
+template <int OCC, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) uint32_t bw_s[DROP ? 32 : 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     // head-fastest workgroup order: consecutive workgroup ids go to consecutive XCDs, so with 8 heads every XCD
     // streams ONE head's K / V (2 MB at S = 16384) through its own 4-MB L2 instead of all eight heads' 16 MB
@@ -550,18 +678,27 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
         }
     }
     const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
-    const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
+    // dropout: the tile is (1-p) * dS, see k_attn_bwd_dkv_bf16; dQ is rescaled once at the end
+    const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] * (DROP ? a.drop.keep : 1.f) : 0.f;
     // -lse[q] and -delta[q] live in two accumulator-shaped register sets and enter the MFMA chains as the C
     // operand: the score tile arrives as S - lse and the dP tile as dP - delta, at no VALU cost per tile
     f32x16 dqt, negl, negd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dqt[r] = 0.f; negl[r] = -lse2; negd[r] = -del; }
+    uint32_t aw = 0, ck = 0;
+    if constexpr (DROP) {
+        const unsigned long long seed = *a.drop.seed;
+        const int bh = b * a.H + head;
+        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
+        ck = gdrop::col_key(seed, bh);
+    }
 
     uint4 regs[2];
     stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
         __syncthreads();
         stage_store<4>(regs, lds);
+        if constexpr (DROP) stage_col_words<2>(bw_s, ck, k0);
         __syncthreads();
         if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
 #pragma unroll 1
@@ -580,6 +717,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
                 for (int r = 0; r < 16; ++r)
                     if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
             }
+            if constexpr (DROP) drop_select<false>(dp, negd, aw, bw_s + 16 * t, hf, a.drop.thr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(sc[r]) * dp[r];
             bf16x8 d0, d1;
@@ -590,10 +728,10 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     }
     if (qi < a.S) {
         float* dqp = a.dqkv + (rowbase + qi) * a.ld + head * D;
+        const float qsc = DROP ? a.scale * a.drop.inv_keep : a.scale;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 t = make_float4(dqt[4 * g] * a.scale, dqt[4 * g + 1] * a.scale, dqt[4 * g + 2] * a.scale,
-                                   dqt[4 * g + 3] * a.scale);
+            float4 t = make_float4(dqt[4 * g] * qsc, dqt[4 * g + 1] * qsc, dqt[4 * g + 2] * qsc, dqt[4 * g + 3] * qsc);
             *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
         }
     }
@@ -604,9 +742,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
 // (key tile, query block) units and the units are independent instruction streams (same idea and same
 // measurements as k_attn_bwd_dkv_kb).
 // ------------------------------------------------------------------------------------------------
-template <int QB, int NT, int OCC>
+template <int QB, int NT, int OCC, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * NT * TILE_BYTES];  // K tiles, then V tiles
+    __shared__ __attribute__((aligned(16))) uint32_t bw_s[DROP ? 16 * NT : 4];
+    uint32_t aw[QB], ck = 0;
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int head = blockIdx.x % a.H, b = blockIdx.z;   // head-fastest order: one head per XCD
     const int hkv = head / (a.H / a.HKV);
@@ -632,15 +774,22 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
             }
         }
         const float lse2 = (qi < a.S) ? a.lse[((int64_t)b * a.H + head) * a.S + qi] * LOG2E : INFINITY;
-        const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] : 0.f;
+        const float del = (qi < a.S) ? a.delta[((int64_t)b * a.H + head) * a.S + qi] * (DROP ? a.drop.keep : 1.f) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dqt[qb][r] = 0.f; negl[qb][r] = -lse2; negd[qb][r] = -del; }
+        aw[qb] = 0;
+        if constexpr (DROP) {
+            const int bh = b * a.H + head;
+            aw[qb] = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
+            ck = gdrop::col_key(seed, bh);
+        }
     }
     uint4 regs[NT];
     stage_loadN<NT>(regs, kp, a.ld, vp, a.ld, 0, a.S);
     for (int64_t k0 = 0; k0 < a.S; k0 += 32 * NT) {
         __syncthreads();
         stage_storeN<NT>(regs, lds);
+        if constexpr (DROP) stage_col_words<NT>(bw_s, ck, k0);
         __syncthreads();
         if (k0 + 32 * NT < a.S) stage_loadN<NT>(regs, kp, a.ld, vp, a.ld, k0 + 32 * NT, a.S);
 #pragma unroll 1
@@ -670,6 +819,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
             const bf16x8 kc0 = frag_cols(kt, lane, 0), kc1 = frag_cols(kt, lane, 1);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
+                if constexpr (DROP) drop_select<false>(dp[qb], negd[qb], aw[qb], bw_s + 16 * t, hf, a.drop.thr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dp[qb][r] = __builtin_amdgcn_exp2f(sc[qb][r]) * dp[qb][r];
                 bf16x8 d0, d1;
@@ -684,10 +834,10 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
         const int64_t qi = q0 + 32 * qb + l31;
         if (qi < a.S) {
             float* dqp = a.dqkv + (rowbase + qi) * a.ld + head * D;
+            const float qsc = DROP ? a.scale * a.drop.inv_keep : a.scale;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 t = make_float4(dqt[qb][4 * g] * a.scale, dqt[qb][4 * g + 1] * a.scale, dqt[qb][4 * g + 2] * a.scale,
-                                       dqt[qb][4 * g + 3] * a.scale);
+                float4 t = make_float4(dqt[qb][4 * g] * qsc, dqt[qb][4 * g + 1] * qsc, dqt[qb][4 * g + 2] * qsc, dqt[qb][4 * g + 3] * qsc);
                 *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
             }
         }
@@ -702,7 +852,8 @@ extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
 }
 
 extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse,
-                                  int B, int S, int H, int HKV, int head_dim, float scale, gaot_stream_t stream) {
+                                  int B, int S, int H, int HKV, int head_dim, float scale, float dropout_p,
+                                  const unsigned long long* dropout_seed, gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_fwd_bf16: head_dim %d unsupported (only 32)", head_dim);
@@ -711,25 +862,30 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
     GAOT_CHECK_ARG(qkv && qkv_image && o && lse, "null pointer");
     GAOT_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_image | (uintptr_t)o) & 15) == 0, "buffers must be 16-byte aligned");
+    GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
     const int64_t rows = (int64_t)B * S;
     const int64_t n = rows * (ld / 2);
     hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
-    FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV};
+    FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV, gdrop::make_drop(dropout_seed, dropout_p)};
     const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
     // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
-    hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2>), fgrid, dim3(256), 0, st, a);
+    if (a.drop.thr)
+        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, true>), fgrid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
 
 extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse,
                                   void* do_image, float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim,
-                                  float scale, int phase_mask, gaot_stream_t stream) {
+                                  float scale, float dropout_p, const unsigned long long* dropout_seed, int phase_mask,
+                                  gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_bwd_bf16: head_dim %d unsupported (only 32)", head_dim);
@@ -737,9 +893,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     }
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
     GAOT_CHECK_ARG(qkv_image && o && d_o && lse && do_image && delta && dqkv, "null pointer");
+    GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
-    BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, dqkv, ld, B, S, H, HKV, scale};
+    BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, dqkv, ld, B, S, H, HKV, scale,
+              gdrop::make_drop(dropout_seed, dropout_p)};
+    const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 1)
         hipLaunchKernelGGL(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
@@ -747,16 +906,24 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 2) {
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups
-        if ((int64_t)ceil_div(S, 256) * HKV * B >= 512)
-            hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2>), dim3((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_attn_bwd_dkv_bf16<4>, dim3((unsigned)(ceil_div(S, 128) * HKV), 1, (unsigned)B), dim3(256), 0, st, a);
+        const dim3 gkb((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * HKV), 1, (unsigned)B);
+        if ((int64_t)ceil_div(S, 256) * HKV * B >= 512) {
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+        } else {
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, true>), g1, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, false>), g1, dim3(256), 0, st, a);
+        }
     }
     if (phase_mask & 4) {
-        if ((int64_t)ceil_div(S, 256) * H * B >= 512)   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
-            hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2>), dim3((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_attn_bwd_dq_bf16<4>, dim3((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B), dim3(256), 0, st, a);
+        const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
+        if ((int64_t)ceil_div(S, 256) * H * B >= 512) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+        } else {
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, true>), g1, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, false>), g1, dim3(256), 0, st, a);
+        }
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

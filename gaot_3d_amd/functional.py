@@ -138,40 +138,77 @@ class RMSNormFn(Function):
         return dx, dw, None
 
 
+# Attention-dropout seed: one int64 word per device, living ON the device.  Every dropout forward takes a copy (kept for
+# its backward) and advances the word with device ops, so a captured hipGraph draws a fresh mask on every replay.
+# Seeded from torch.initial_seed() (torch.manual_seed controls it) on first use and whenever that seed changes.
+_DROP_STATE: dict = {}
+_DROP_STRIDE = -7046029254386353131   # 0x9E3779B97F4A7C15 as int64
+
+
+def set_dropout_seed(seed: int, device) -> None:
+    dev = torch.device(device)
+    v = int(seed) & 0xFFFFFFFFFFFFFFFF
+    v = v - (1 << 64) if v >= (1 << 63) else v
+    _DROP_STATE[dev] = (torch.tensor([v], dtype=torch.int64, device=dev), torch.initial_seed())
+
+
+def next_dropout_seed(device) -> Tensor:
+    """the seed word for one dropout call (a fresh one-element int64 device tensor); advances the device state"""
+    dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _DROP_STATE.get(dev)
+    if st is None or st[1] != torch.initial_seed():
+        set_dropout_seed(torch.initial_seed() * 0x2545F4914F6CDD1D + 0x632BE59BD9B4E019, dev)
+        st = _DROP_STATE[dev]
+    used = st[0].clone()
+    st[0].add_(_DROP_STRIDE)
+    return used
+
+
+def dropout_seed_sequence(seed0: int, n: int):
+    """the unsigned 64-bit words the next n dropout calls read after set_dropout_seed(seed0) (for checks)"""
+    return [(int(seed0) + i * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
 class AttentionFn(Function):
-    """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k.
+    """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k, optional dropout
+    on the attention weights (reference attn.py:122-127).
     precision fp32: exact-fp32 MFMA kernels (csrc/attn.hip); bf16: csrc/attn_bf16.hip."""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int):
+    def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, dropout_p: float = 0.0):
         scale = 1.0 / (32 ** 0.5)
         bf16 = ops.get_precision() == "bf16"
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
         if bf16:
-            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale)
+            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed)
             keep = img
         else:
             if freqs is not None:
                 qkv = qkv.clone()
                 ops.rope_(qkv, b * s, qkv.shape[1], 0, h + hkv, s, freqs, False)  # q then k heads: adjacent columns
-            o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale)
+            o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale, dropout_p, seed)
             keep = qkv
-        ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else torch.empty(0, device=qkv.device))
-        ctx.dims = (b, s, h, hkv, scale, freqs is not None, bf16)
+        empty = torch.empty(0, device=qkv.device)
+        ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else empty, seed if seed is not None else empty)
+        ctx.dims = (b, s, h, hkv, scale, freqs is not None, bf16, dropout_p)
         return o
 
     @staticmethod
     def backward(ctx, d_o: Tensor):
-        keep, o, lse, freqs = ctx.saved_tensors
-        b, s, h, hkv, scale, rope, bf16 = ctx.dims
+        keep, o, lse, freqs, seed = ctx.saved_tensors
+        b, s, h, hkv, scale, rope, bf16, dropout_p = ctx.dims
+        seed = seed if dropout_p > 0.0 else None
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
         if bf16:
-            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale)
+            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
         else:
-            dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale)
+            dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
         if rope:
             ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
 class SwiGLUFn(Function):

@@ -87,14 +87,12 @@ class GroupQueryFlashAttention(nn.Module):
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None):
         """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`)."""
-        if self.training and self.atten_dropout > 0.0:
-            raise NotImplementedError("attention dropout > 0 in training mode is not implemented on the HIP path; "
-                                      "set atten_dropout=0.0 (reference default 0.1, attn.py:22) or call .eval()")
+        dp = float(self.atten_dropout) if self.training else 0.0     # reference attn.py:122-126
         b, s, _ = x.shape
         GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
-        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads)
+        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp)
         y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
 

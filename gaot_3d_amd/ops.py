@@ -292,7 +292,24 @@ def rope_(buf: Tensor, rows: int, ld: int, col0: int, nheads: int, seq_len: int,
           "gaot_rope")
 
 
-def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float):
+def _drop_args(p: float, seed: Optional[Tensor]):
+    if p <= 0.0:
+        return 0.0, None
+    if seed is None or seed.dtype != torch.int64 or not seed.is_cuda or seed.numel() != 1:
+        raise ValueError("attention dropout needs a one-element int64 device tensor as seed")
+    return float(p), _ptr(seed)
+
+
+def attn_dropout_mask(seed: Tensor, p: float, b: int, h: int, s: int) -> Tensor:
+    """keep[b, h, q, k] (uint8) of the attention dropout mask the kernels regenerate from ``seed`` (checks only)"""
+    lib = _lib.load()
+    keep = torch.empty(b, h, s, s, dtype=torch.uint8, device=seed.device)
+    check(lib.gaot_attn_dropout_mask(_ptr(seed), float(p), b, h, s, _ptr(keep), _stream()), "gaot_attn_dropout_mask")
+    return keep
+
+
+def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float, dropout_p: float = 0.0,
+             seed: Optional[Tensor] = None):
     """qkv: [B*S, (h + 2*hkv)*32] fused projection output (q | k | v column blocks)."""
     lib = _lib.load()
     ld = qkv.shape[1]
@@ -302,13 +319,16 @@ def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float):
     base = qkv.data_ptr()
     q, k, v = C.c_void_p(base), C.c_void_p(base + 4 * h * 32), C.c_void_p(base + 4 * (h + hkv) * 32)
     with _timed("attn_fwd"):
-        check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale),
+        dp, sp = _drop_args(dropout_p, seed)
+        check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale), dp, sp,
                                 _PRECISION["mode"], _stream()), "gaot_attn_fwd")
     return o, lse
 
 
-def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float) -> Tensor:
+def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
+             dropout_p: float = 0.0, seed: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
+    dp, sp = _drop_args(dropout_p, seed)
     ld = qkv.shape[1]
     dev = qkv.device
     dqkv = torch.empty_like(qkv)
@@ -320,11 +340,12 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
             check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
                                     _ptr(d_o), _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
                                     C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
-                                    float(scale), _PRECISION["mode"], mask, _stream()), "gaot_attn_bwd")
+                                    float(scale), dp, sp, _PRECISION["mode"], mask, _stream()), "gaot_attn_bwd")
     return dqkv
 
 
-def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float):
+def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float,
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None):
     """bf16 matrix-core attention on the fused fp32 projection; returns (o, lse, bf16 image kept for backward)"""
     lib = _lib.load()
     dev = qkv.device
@@ -332,13 +353,16 @@ def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, 
     lse = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), dev)
     with _timed("attn_fwd"):
+        dp, sp = _drop_args(dropout_p, seed)
         check(lib.gaot_attn_fwd_bf16(_ptr(qkv), _ptr(freqs), _ptr(img), _ptr(o), _ptr(lse), b, s, h, hkv, 32, float(scale),
-                                     _stream()), "gaot_attn_fwd_bf16")
+                                     dp, sp, _stream()), "gaot_attn_fwd_bf16")
     return o, lse, img
 
 
-def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float) -> Tensor:
+def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
+    dp, sp = _drop_args(dropout_p, seed)
     dev = o.device
     dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
@@ -346,7 +370,7 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: i
     for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
-                                         b, s, h, hkv, 32, float(scale), mask, _stream()), "gaot_attn_bwd_bf16")
+                                         b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()), "gaot_attn_bwd_bf16")
     return dqkv
 
 

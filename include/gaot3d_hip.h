@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 2
+#define GAOT_ABI_VERSION 3
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -129,21 +129,28 @@ int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, in
                  size_t workspace_bytes, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Attention: softmax(Q K^T * scale) V per head, no mask, no dropout (reference
+ * Attention: softmax(Q K^T * scale) V per head, no mask, optional dropout (reference
  * GroupQueryFlashAttention.forward, src/model/layers/attn.py:110-127 -> F.scaled_dot_product_
- * attention) and its autograd.  q/k/v/o are [B*S, heads*32] views with row strides ld* (floats),
+ * attention(dropout_p = atten_dropout when training, attn.py:122-127)) and its autograd.  q/k/v/o are [B*S, heads*32] views with row strides ld* (floats),
  * so the fused QKV projection output can be addressed in place.  lse/delta: [B, H, S] scratch
  * kept from forward / filled by backward (phase 1 of gaot_attn_bwd; phases may be issued one by one).  head_dim must be 32.  HKV < H = grouped-query heads
  * (k = k.repeat_interleave(H/HKV)).
+ * Dropout (dropout_p > 0): O = (P .* keep / (1-p)) V with keep(seed, b, h, q, k) a counter-based Bernoulli(1-p)
+ * mask (csrc/attn_dropout.h; p realised to 1/65536) that forward and backward regenerate from *dropout_seed, a
+ * DEVICE pointer to one 64-bit word read when the kernel runs (so a captured hipGraph sees the value of each
+ * replay); the backward must be given the value the forward saw.  torch's own Philox mask is not reproducible
+ * outside torch; gaot_attn_dropout_mask materialises this one (keep[b][h][q][k], 1 byte each) for checks.
  * ------------------------------------------------------------------------------------------- */
 int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq, int64_t ldk,
-                  int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim, float scale, int precision,
-                  gaot_stream_t stream);
+                  int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim, float scale, float dropout_p,
+                  const unsigned long long* dropout_seed, int precision, gaot_stream_t stream);
 int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                   float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                   int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
-                  float scale, int precision, int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */,
-                  gaot_stream_t stream);
+                  float scale, float dropout_p, const unsigned long long* dropout_seed, int precision,
+                  int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */, gaot_stream_t stream);
+int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout_p, int B, int H, int S,
+                           unsigned char* keep, gaot_stream_t stream);
 
 /* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
@@ -152,10 +159,11 @@ int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o
  * do_image: scratch of B*S*H*32 bf16. */
 size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
-                       int H, int HKV, int head_dim, float scale, gaot_stream_t stream);
+                       int H, int HKV, int head_dim, float scale, float dropout_p,
+                       const unsigned long long* dropout_seed, gaot_stream_t stream);
 int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse, void* do_image,
                        float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim, float scale,
-                       int phase_mask, gaot_stream_t stream);
+                       float dropout_p, const unsigned long long* dropout_seed, int phase_mask, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row / element kernels (HBM-bound).

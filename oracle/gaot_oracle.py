@@ -312,8 +312,60 @@ def rope_rotate(t: Tensor, freqs: Tensor) -> Tensor:
     return t * ang.cos() + rh * ang.sin()
 
 
-def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int, rope: bool) -> Tensor:
-    """attn.py:89-131, eval / atten_dropout=0 path."""
+# Attention dropout (attn.py:122-127: F.scaled_dot_product_attention(dropout_p=atten_dropout) when training).  The
+# mask torch draws comes from its Philox stream and cannot be reproduced outside torch -- "parity unpinned" for the
+# mask itself; SDPA's arithmetic GIVEN a mask (P * keep / (1-p), then @ V) is pinned by the reference golden
+# ``attn_dropout`` (make_goldens.py replays torch's CPU mask through the same generator state).  The product draws
+# its mask from a counter-based integer function (csrc/attn_dropout.h) that is restated here bit for bit.
+_M32 = 0xFFFFFFFF
+
+
+def _mix_a(x):
+    import numpy as np
+    x = x.astype(np.uint64) & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _mix_b(x):
+    import numpy as np
+    x = x.astype(np.uint64) & _M32
+    x ^= x >> np.uint64(17); x = (x * np.uint64(0xed5ad4bb)) & _M32
+    x ^= x >> np.uint64(11); x = (x * np.uint64(0xac4c1b51)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x31848bab)) & _M32
+    x ^= x >> np.uint64(14)
+    return x
+
+
+def dropout_threshold(p: float) -> int:
+    """p is realised to 1/65536: keep iff a 16-bit uniform >= thr"""
+    return max(0, min(65535, int(p * 65536.0 + 0.5)))
+
+
+def dropout_keep_mask(seed: int, b: int, h: int, s: int, p: float) -> Tensor:
+    """keep[b, h, q, k] (bool) of the product's attention dropout: W = A(seed, bh, q) xor B(seed, bh, k >> 1),
+    keep = halfword(W, k & 1) >= thr.  ``seed`` is the unsigned 64-bit word the kernels read."""
+    import numpy as np
+    seed &= 0xFFFFFFFFFFFFFFFF
+    lo, hi = seed & _M32, seed >> 32
+    thr = dropout_threshold(p)
+    bh = np.arange(b * h, dtype=np.uint64)
+    rk = _mix_a((np.uint64(lo) + np.uint64(0x9E3779B9) * (bh + np.uint64(1))) & _M32)        # [BH]
+    ck = _mix_b((np.uint64(hi) + np.uint64(0x85EBCA6B) * (bh + np.uint64(1))) & _M32)
+    q = np.arange(s, dtype=np.uint64)
+    aw = _mix_a((rk[:, None] + q[None, :]) & _M32)                                            # [BH, S]
+    bw = _mix_b((ck[:, None] + (q[None, :] >> np.uint64(1))) & _M32)                          # [BH, S] (pair word of k)
+    w = aw[:, :, None] ^ bw[:, None, :]                                                       # [BH, Sq, Sk]
+    half = np.where((q & np.uint64(1))[None, None, :] == 1, w >> np.uint64(16), w & np.uint64(0xFFFF))
+    return torch.from_numpy((half >= thr).reshape(b, h, s, s))
+
+
+def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int, rope: bool,
+              keep: Optional[Tensor] = None, p_drop: float = 0.0) -> Tensor:
+    """attn.py:89-131; ``keep`` [B,H,S,S] = the dropout mask of the training path (None: eval / atten_dropout=0),
+    ``p_drop`` the probability it was drawn with."""
     q = F.linear(x, sd[prefix + "q_proj.weight"])
     k = F.linear(x, sd[prefix + "k_proj.weight"])
     v = F.linear(x, sd[prefix + "v_proj.weight"])
@@ -331,6 +383,8 @@ def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int,
         q = rope_rotate(q, fr)
         k = rope_rotate(k, fr)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)  # SDPA :126
+    if keep is not None:   # torch.dropout(attn_weight, p, train=True): mask and rescale
+        att = att * keep.to(att.dtype) / (1.0 - p_drop)
     o = (att @ v).transpose(1, 2).contiguous().view(b, s, -1)
     return F.linear(o, sd[prefix + "o_proj.weight"])
 
@@ -342,31 +396,35 @@ def ffn(sd: SD, prefix: str, x: Tensor) -> Tensor:
     return F.linear(F.silu(a) * g, sd[prefix + "w2.weight"])
 
 
-def transformer_block(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, skip: Optional[Tensor]) -> Tensor:
+def transformer_block(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, skip: Optional[Tensor],
+                      keep: Optional[Tensor] = None, p_drop: float = 0.0) -> Tensor:
     """attn.py:205-230 -- note the second residual adds the *normalised* h."""
     ac = tcfg.attn_config
     if skip is not None and (prefix + "skip_proj.weight") in sd:
         x = F.linear(torch.cat([x, skip], dim=-1), sd[prefix + "skip_proj.weight"], sd[prefix + "skip_proj.bias"])
     h = rmsnorm(x, sd[prefix + "attn_norm.weight"], tcfg.norm_eps) if tcfg.use_attn_norm else x
-    h = x + attention(sd, prefix + "attn.", h, ac.num_heads, ac.num_kv_heads, rope)
+    h = x + attention(sd, prefix + "attn.", h, ac.num_heads, ac.num_kv_heads, rope, keep, p_drop)
     h = rmsnorm(h, sd[prefix + "ffn_norm.weight"], tcfg.norm_eps) if tcfg.use_ffn_norm else h
     return h + ffn(sd, prefix + "ffn.", h)
 
 
-def transformer(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool) -> Tensor:
-    """attn.py:298-325"""
+def transformer(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, drop=None) -> Tensor:
+    """attn.py:298-325.  ``drop``: None, or (list of keep masks in block call order, p) for the training path."""
+    masks = iter(drop[0]) if drop is not None else None
+    pd = drop[1] if drop is not None else 0.0
+    nxt = (lambda: next(masks)) if masks is not None else (lambda: None)
     if (prefix + "input_proj.weight") in sd:
         x = F.linear(x, sd[prefix + "input_proj.weight"], sd[prefix + "input_proj.bias"])
     n = tcfg.num_layers
     skips = []
     for i in range(n // 2):
-        x = transformer_block(sd, f"{prefix}encoder_layers.{i}.", x, tcfg, rope, None)
+        x = transformer_block(sd, f"{prefix}encoder_layers.{i}.", x, tcfg, rope, None, nxt(), pd)
         skips.append(x)
     if n % 2 == 1:
-        x = transformer_block(sd, f"{prefix}middle_layer.", x, tcfg, rope, None)
+        x = transformer_block(sd, f"{prefix}middle_layer.", x, tcfg, rope, None, nxt(), pd)
     for i in range(n // 2):
         sk = skips.pop() if tcfg.use_long_range_skip else None
-        x = transformer_block(sd, f"{prefix}decoder_layers.{i}.", x, tcfg, rope, sk)
+        x = transformer_block(sd, f"{prefix}decoder_layers.{i}.", x, tcfg, rope, sk, nxt(), pd)
     if (prefix + "output_proj.weight") in sd:
         x = F.linear(x, sd[prefix + "output_proj.weight"], sd[prefix + "output_proj.bias"])
     return x
@@ -394,7 +452,7 @@ def patch_positions(latent_tokens, p: int) -> Tensor:
                        dim=-1).reshape(-1, 3)
 
 
-def process(sd: SD, tcfg, latent_tokens, rndata: Tensor) -> Tensor:
+def process(sd: SD, tcfg, latent_tokens, rndata: Tensor, drop=None) -> Tensor:
     """gaot_3d.py:166-222"""
     b, m, c = rndata.shape
     d, h, w = latent_tokens
@@ -410,20 +468,20 @@ def process(sd: SD, tcfg, latent_tokens, rndata: Tensor) -> Tensor:
         x = x + absolute_pe(patch_positions(latent_tokens, p), p * p * p * c)
     elif tcfg.positional_embedding == "rope":
         rope = True
-    x = transformer(sd, "processor.", x, tcfg, rope)
+    x = transformer(sd, "processor.", x, tcfg, rope, drop)
     x = x.view(b, nd, nh, nw, p, p, p, c).permute(0, 1, 4, 2, 5, 3, 6, 7).contiguous()
     return x.view(b, d * h * w, c)
 
 
 def gaot3d_forward(sd: SD, mcfg, batch, tokens_pos: Optional[Tensor] = None,
-                   query_coord_pos: Optional[Tensor] = None) -> Tensor:
+                   query_coord_pos: Optional[Tensor] = None, drop=None) -> Tensor:
     """gaot_3d.py:248-332.  ``mcfg`` has .magno, .transformer, .latent_tokens."""
     nb = batch.num_graphs
     lt = sd["latent_tokens"] if tokens_pos is None else tokens_pos
     latent = lt.repeat(nb, 1)  # :283-285
     q_pos = batch.pos if query_coord_pos is None else query_coord_pos
     rn = magno_encoder(sd, mcfg.magno, batch, latent)
-    rn = process(sd, mcfg.transformer, tuple(mcfg.latent_tokens), rn)
+    rn = process(sd, mcfg.transformer, tuple(mcfg.latent_tokens), rn, drop)
     flat = rn.reshape(-1, mcfg.magno.lifting_channels)
     return magno_decoder(sd, mcfg.magno, flat, q_pos, latent, batch)
 
@@ -433,7 +491,7 @@ def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
     return ((pred - target) ** 2).mean()
 
 
-def train_step_grads(sd: SD, mcfg, batch, tokens_pos: Optional[Tensor] = None):
+def train_step_grads(sd: SD, mcfg, batch, tokens_pos: Optional[Tensor] = None, drop=None):
     """One zero_grad -> forward -> MSE -> backward (optimizers.py:272-274) over a
     state_dict; returns (pred, loss, {name: grad}).  Non-float / frozen entries
     (``latent_tokens`` buffer, ``rotary_emb.freqs``) get no grad, as in the reference."""
@@ -443,7 +501,7 @@ def train_step_grads(sd: SD, mcfg, batch, tokens_pos: Optional[Tensor] = None):
         if t.is_floating_point() and k != "latent_tokens" and not k.endswith("rotary_emb.freqs"):
             t.requires_grad_(True)
         leaf[k] = t
-    pred = gaot3d_forward(leaf, mcfg, batch, tokens_pos)
+    pred = gaot3d_forward(leaf, mcfg, batch, tokens_pos, drop=drop)
     loss = mse_loss(pred, batch.x)
     loss.backward()
     grads = {k: v.grad for k, v in leaf.items() if v.requires_grad and v.grad is not None}

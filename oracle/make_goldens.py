@@ -268,12 +268,44 @@ def ops_case():
     save("ops", dict(name="ops", variants=variants, nq=nq), arrays)
 
 
+def attn_dropout_case():
+    """GroupQueryFlashAttention in TRAINING mode with atten_dropout = 0.1 (attn.py:122-127).  torch's CPU SDPA takes its
+    math path for dropout_p > 0 and draws the keep mask as empty_like(attn).bernoulli_(1 - p) from the default
+    generator; the same draw is replayed here (same seed, nothing drawn in between) and stored, so the golden pins
+    the arithmetic GIVEN the mask: P * keep / (1 - p) @ V, and its autograd."""
+    from src.model.layers.attn import GroupQueryFlashAttention
+
+    b, s, d, h, hkv, p = 2, 24, 64, 2, 1, 0.1
+    torch.manual_seed(5)
+    att = GroupQueryFlashAttention(d, d, hidden_size=d, num_heads=h, num_kv_heads=hkv, atten_dropout=p,
+                                   positional_embedding="absolute")
+    att.train()
+    x = torch.randn(b, s, d)
+    w = torch.randn(b, s, d)
+    xin = x.clone().requires_grad_(True)
+    torch.manual_seed(11)
+    out = att(xin)
+    (out * w).sum().backward()
+    torch.manual_seed(11)
+    keep = torch.empty(b, h, s, s).bernoulli_(1 - p)
+    arrays = {"in/x": x, "in/w": w, "in/keep": keep.to(torch.uint8), "out/out": out, "grad/x": xin.grad}
+    for k, v in att.state_dict().items():
+        arrays[f"sd/{k}"] = v
+    for k, g in grads_of(att).items():
+        arrays[f"grad/{k}"] = g
+    save("attn_dropout", dict(name="attn_dropout", b=b, s=s, d=d, h=h, hkv=hkv, p=p), arrays)
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not present: goldens can only be regenerated in the authoring container"
     install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "attn_dropout":   # regenerate just this file
+        attn_dropout_case()
+        return
     ops_case()
+    attn_dropout_case()
     model_case("model_knn_abs", seed=1, n_per_graph=[200], latent_tokens=(4, 4, 4),
                magno_kw=dict(use_geoembed=[True, False], mlp_type="linear", neighbor_strategy="knn", k_neighbors=4),
                tr_kw=dict(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="absolute"),

@@ -80,3 +80,36 @@ def test_geoembed_variants():
         (out * g["in"][f"{tag}/w"]).sum().backward()
         for k, gr in gio.sub(g["grad"], tag).items():
             close(sd[k].grad, gr, 1e-3, 1e-5)
+
+
+def test_attention_training_dropout_given_mask():
+    """reference attention in training mode (atten_dropout 0.1): the oracle's masked SDPA reproduces the output and
+    every gradient once it is handed the keep mask torch drew (replayed by make_goldens.attn_dropout_case)"""
+    meta, g = gio.load("attn_dropout")
+    sd = {k: t.clone().requires_grad_(True) for k, t in g["sd"].items()}
+    x = g["in"]["x"].clone().requires_grad_(True)
+    keep = g["in"]["keep"].bool()
+    assert 0.8 < keep.float().mean().item() < 0.97
+    out = orc.attention(sd, "", x, meta["h"], meta["hkv"], False, keep, meta["p"])
+    close(out, g["out"]["out"])
+    (out * g["in"]["w"]).sum().backward()
+    close(x.grad, g["grad"]["x"], 1e-3, 1e-6)
+    for k, gr in g["grad"].items():
+        if k != "x":
+            close(sd[k].grad, gr, 1e-3, 1e-6)
+
+
+def test_dropout_mask_function_statistics():
+    """the product's counter-based mask (restated in numpy): keep rate, per-row balance, seed sensitivity"""
+    p = 0.1
+    m1 = orc.dropout_keep_mask(0x0123456789ABCDEF, 1, 4, 512, p).float()
+    m2 = orc.dropout_keep_mask(0x0123456789ABCDF0, 1, 4, 512, p).float()
+    assert abs(m1.mean().item() - (1 - orc.dropout_threshold(p) / 65536)) < 2e-3
+    assert (m1.mean(dim=-1) - 0.9).abs().max().item() < 0.08          # every query row
+    assert (m1.mean(dim=-2) - 0.9).abs().max().item() < 0.08          # every key column
+    agree = (m1 == m2).float().mean().item()                            # independent masks agree w.p. 0.82
+    assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 5e-3
+    # neighbouring elements are uncorrelated (the two keys of a pair share one 32-bit word)
+    a, b2 = m1[..., 0::2].flatten(), m1[..., 1::2].flatten()
+    corr = ((a - a.mean()) * (b2 - b2.mean())).mean() / (a.std() * b2.std())
+    assert abs(corr.item()) < 5e-3

@@ -28,14 +28,16 @@ if what == "attn":
     freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
     d_o = torch.randn(b * s, h * 32, device=dev)
     att = 2 * s * s * 32 * h
+    pd = float(os.environ.get("MB_DROP", 0.0))     # attention dropout probability
+    sd = torch.tensor([12345], dtype=torch.int64, device=dev) if pd > 0 else None
     if ops.get_precision() == "bf16":
-        o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5)
-        timeit(lambda: ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5), "attn_fwd_bf16(+prep)", 2 * att)
-        timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5), "attn_bwd_bf16(all)", 4 * att)
+        o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd)
+        timeit(lambda: ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd), "attn_fwd_bf16(+prep)", 2 * att)
+        timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd), "attn_bwd_bf16(all)", 4 * att)
         ops.timing_reset(True)
         for _ in range(reps):
-            ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5)
-            ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5)
+            ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd)
+            ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd)
         torch.cuda.synchronize()
         for name, (calls, tot) in ops.timing_summary().items():
             print(f"  {name}: {tot / calls:.4f} ms")
