@@ -169,6 +169,27 @@ __device__ __forceinline__ void drop_select(f32x16& v, const f32x16& other, uint
     }
 }
 
+// zero the dropped elements of a P tile that is already packed to bf16 (dword j = rows 2j, 2j+1 = the two keys of
+// pair word j): per dword one xor, one packed saturating 16-bit subtract (sign = dropped), one packed arithmetic
+// shift (sign -> 0xFFFF) and one and-not -- 2 VALU ops per element instead of compare + select on fp32.
+// awf = row word ^ 0x80008000 (halfwords as signed), tpk = (thr - 32768) in both halves.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf, const uint32_t* bw_tile, int hf, s16x2 tpk) {
+    const uint4 w0 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8);
+    const uint4 w1 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8 + 4);
+    const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    uint4 a = __builtin_bit_cast(uint4, f0), b = __builtin_bit_cast(uint4, f1);
+    uint32_t pk[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, awf ^ wd[j]), tpk);
+        const s16x2 m = d >> (short)15;
+        pk[j] &= ~__builtin_bit_cast(uint32_t, m);
+    }
+    f0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    f1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
 // ------------------------------------------------------------------------------------------------
@@ -207,9 +228,11 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     if constexpr (DROP) {
         const unsigned long long seed = *a.drop.seed;
         const int bh = b * a.H + head;
-        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31));
+        aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31)) ^ 0x80008000u;
         ck = gdrop::col_key(seed, bh);
     }
+    const short ts = (short)((int)a.drop.thr - 32768);
+    const s16x2 tpk = {ts, ts};
 
     // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
@@ -264,9 +287,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                 ps1 += sc[r + 1];
             }
             l += ps0 + ps1;   // per-half partial; the halves are added once, after the key loop
-            if constexpr (DROP) drop_select<true>(sc, sc, aw, bw_s + 16 * t, hf, a.drop.thr);   // l stays undropped
             bf16x8 p0, p1;
             acc_to_frags(sc, p0, p1);
+            if constexpr (DROP) drop_packed(p0, p1, aw, bw_s + 16 * t, hf, tpk);   // l stays undropped
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
         };
