@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def model_config(latent, layers, k):
+def model_config(latent, layers, k, atten_dropout=0.1):
     from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
     from gaot_3d_amd.model.layers.magno import MAGNOConfig
     return types.SimpleNamespace(
@@ -35,7 +35,7 @@ def model_config(latent, layers, k):
         transformer=TransformerConfig(patch_size=2, hidden_size=256, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
                                       num_layers=layers, positional_embedding="rope", use_long_range_skip=True,
                                       attn_config=AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8,
-                                                                  atten_dropout=0.0),
+                                                                  atten_dropout=atten_dropout),
                                       ffn_config=FFNConfig(hidden_size=1024)),
         latent_tokens=tuple(latent))
 
@@ -54,7 +54,7 @@ def algorithmic_work(n_pts, m_lat, e_enc, e_dec, s_tok, layers, heads=8, dh=32, 
     }
 
 
-def cpu_baseline(layers, k, seed):
+def cpu_baseline(layers, k, seed, atten_dropout):
     """The oracle (CPU restatement of the reference, pure PyTorch fp32) timed on the host cores on a bounded sample
     of the same workload: 1/16 of the points and 1/8 of the latent grid, same widths and depth."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -69,17 +69,27 @@ def cpu_baseline(layers, k, seed):
     model = init_model(6, 1, "gaot_3d", cfg)
     sd = {kk: v.clone() for kk, v in model.state_dict().items()}
     batch, tokens = make_synthetic_sample(n, latent, k=k, seed=seed)
-    orc.train_step_grads(sd, cfg, batch, tokens)  # warm-up
+    s_tok = latent[0] * latent[1] * latent[2] // 8
+
+    def one_step():
+        drop = None
+        if atten_dropout > 0.0:   # the training path draws one Bernoulli keep mask per attention call, as SDPA does
+            masks = [torch.empty(1, 8, s_tok, s_tok).bernoulli_(1.0 - atten_dropout) for _ in range(layers)]
+            drop = (masks, atten_dropout)
+        orc.train_step_grads(sd, cfg, batch, tokens, drop=drop)
+
+    one_step()  # warm-up
     times = []
     t_begin = time.perf_counter()
     while len(times) < 3 and time.perf_counter() - t_begin < 25.0:
         t0 = time.perf_counter()
-        orc.train_step_grads(sd, cfg, batch, tokens)
+        one_step()
         times.append(time.perf_counter() - t0)
     t = sorted(times)[0]
     return dict(value=n / t, unit="points/s", cores=cores, kind="port",
                 sample=f"oracle fwd+MSE+bwd on N={n} points (1/8 of the sample), latent {latent[0]}x{latent[1]}x{latent[2]} "
-                       f"(1/8), k={k}, L={layers}, d=256, fp32, best of {len(times)} after 1 warm-up ({t:.2f} s/step)")
+                       f"(1/8), k={k}, L={layers}, d=256, attention dropout {atten_dropout}, fp32, best of {len(times)} "
+                       f"after 1 warm-up ({t:.2f} s/step)")
 
 
 def main():
@@ -96,6 +106,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph", action="store_true", help="also use the hipGraph replay for N>1 (default: N=1 only)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--atten-dropout", type=float, default=0.1,
+                    help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
+                         "attn.py:22; no shipped config overrides it)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra dropout-free timing at N=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +138,7 @@ def main():
     gaot_3d_amd.set_precision(args.precision)
 
     latent = tuple(int(v) for v in args.latent.split(","))
-    cfg = model_config(latent, args.layers, args.knn)
+    cfg = model_config(latent, args.layers, args.knn, args.atten_dropout)
     torch.manual_seed(args.seed)
     model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
     use_graph = (not args.no_graph) and (world == 1 or args.graph)
@@ -159,48 +173,65 @@ def main():
     # The step is ~600 short kernels; launched eagerly from Python the host becomes the bottleneck.  Capture ONE
     # whole step (CSR build, forward, loss, backward, gradient exchange, AdamW) into a hipGraph after the warm-up and
     # replay it: the timed region then measures the device work.  --no-graph times the eager launches instead.
-    graph = None
-    if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(args.warmup, 1)):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step()
-        except Exception as ex:  # capture is a launch optimisation only; fall back to eager launches
-            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
-            graph = None
+    def measure():
+        graph = None
+        loss = None
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(args.warmup, 1)):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-    if graph is None:
-        for _ in range(args.warmup):
-            step()
-    else:
-        for _ in range(args.warmup):
-            graph.replay()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loss = step()
+            except Exception as ex:  # capture is a launch optimisation only; fall back to eager launches
+                print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
         if graph is None:
-            loss = step()
+            for _ in range(args.warmup):
+                step()
         else:
-            graph.replay()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+            for _ in range(args.warmup):
+                graph.replay()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is None:
+                loss = step()
+            else:
+                graph.replay()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = tt.item()
+        return elapsed, graph, loss
+
+    elapsed, graph, loss = measure()
+    secondary = None
+    if world == 1 and args.atten_dropout > 0.0 and not args.no_secondary:
+        # the same step with the dropout switched off (what the kernels do in eval mode / atten_dropout = 0)
+        for mod in model.modules():
+            if hasattr(mod, "atten_dropout"):
+                mod.atten_dropout = 0.0
+        e2, g2, _ = measure()
+        secondary = dict(ms_per_step=e2 / args.steps * 1e3, value=n_total / (e2 / args.steps), atten_dropout=0.0)
+        del g2
+        for mod in model.modules():
+            if hasattr(mod, "atten_dropout"):
+                mod.atten_dropout = args.atten_dropout
     # per-kernel durations: HIP events around the instrumented launches of two more (eager) steps on the same stream
     ops.timing_reset(True)
     t_e = time.perf_counter()
@@ -267,10 +298,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] x ' + str(world) + ' points'}: one {n_total}-point car-like surface sample (pos+normals), latent "
                                    f"{latent[0]}x{latent[1]}x{latent[2]}, knn k={args.knn} encoder + flipped decoder, "
-                                   f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, MSE + AdamW step; CSR build and "
-                                   f"geoembed stats inside the step",
+                                   f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, attention dropout {args.atten_dropout} "
+                                   f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step",
                        "points": n_total, "latent_tokens": list(latent), "edges": e, "layers": args.layers,
-                       "precision": args.precision, "points_per_gpu": args.points,
+                       "precision": args.precision, "points_per_gpu": args.points, "atten_dropout": args.atten_dropout,
                        "sharding": f"point-shard x{world}, latent grid / Transformer replicated" if world > 1 else "none"},
             "loss": float(loss.detach()),
             "launch": "hipGraph replay of one captured step" if graph is not None else "eager",
@@ -278,12 +309,13 @@ def main():
             # capture the eager allocations go back to hipMalloc)
             "instrumented_eager_ms_per_step": round(t_eager * 1e3, 3) if graph is None else None,
             "instrumented_eager_host_ms_per_step": round(t_host * 1e3, 3) if graph is None else None,
+            "without_attention_dropout": secondary,
             "roofline": roof,
             "kernels": {kname: {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ent.items()}
                         for kname, ent in per_kernel.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.layers, args.knn, args.seed)
+            out["cpu_baseline"] = cpu_baseline(args.layers, args.knn, args.seed, args.atten_dropout)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
