@@ -86,6 +86,14 @@ SIGNATURES = {
     "gaot_mse_workspace_bytes": (_sz, []),
     "gaot_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "gaot_mse_bwd": (_i, [_p, _p, _i64, _p, _p, _p]),
+    "gaot_gather_rows": (_i, [_p, _i64, _p, _i64, _i, _p, _i64, _p]),
+    "gaot_segment_reduce": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p, _p, _p]),
+    "gaot_segment_reduce_bwd": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _i, _p, _p]),
+    "gaot_segment_softmax_fwd": (_i, [_p, _p, _i64, _p, _p]),
+    "gaot_segment_softmax_bwd": (_i, [_p, _p, _p, _i64, _p, _p]),
+    "gaot_edge_coords": (_i, [_p, _p, _p, _p, _i64, _i, _p, _i64, _p]),
+    "gaot_mul": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "gaot_mul_rowsum": (_i, [_p, _p, _i64, _i, _p, _p]),
     "gaot_scale_mix_fwd": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
     "gaot_scale_mix_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i64, _i, _p]),
 }

@@ -1,11 +1,14 @@
 """GeometricEmbedding with the reference's signature (src/model/layers/geoembed.py:24, 57-64).
 method='statistical' runs csrc/geoembed.hip (one neighbour-list sweep + in-register 3x3 eigen-solve)
-followed by the 9 -> 64 -> C MLP on the HIP GEMM.  'pointnet' raises NotImplementedError."""
+followed by the 9 -> 64 -> C MLP on the HIP GEMM.  method='pointnet' (geoembed.py:184-222) runs the general per-edge
+path: edge offsets, the 3 -> 32 -> 32 ReLU MLP on the GEMM kernels, segment max / mean and the output linear
+(csrc/edgeops.hip)."""
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
+from ... import edgeops as EO
 from ... import functional as GF
 from ... import ops
 from .integral_transform import graph_for
@@ -34,10 +37,12 @@ class GeometricEmbedding(nn.Module):
                 graph=None, shard_group=None):
         """``shard_group`` (extension, gaot_3d_amd/sharding.py): the edges of this sample are spread over the ranks of
         the group; the per-row statistics are assembled from additive fp64 moments with one SUM all-reduce."""
-        if self.method != "statistical":
-            raise NotImplementedError("GeometricEmbedding(method='pointnet') is not implemented on the HIP path")
         if graph is None:
             graph = graph_for(edge_index.to(query_pos.device), source_pos.shape[0], query_pos.shape[0])
+        if self.method == "pointnet":
+            if shard_group is not None:
+                raise NotImplementedError("point-sharded PointNet GeoEmbed is not implemented")
+            return self._forward_pointnet(source_pos, query_pos, graph)
         if shard_group is not None:
             import torch.distributed as dist
             mom = ops.geoembed_moments(source_pos, query_pos, graph)
@@ -47,3 +52,17 @@ class GeometricEmbedding(nn.Module):
             feats = ops.geoembed_stats(source_pos, query_pos, graph)  # geometry only: no autograd through it
         h = GF.linear(feats, self.mlp[0].weight, self.mlp[0].bias, act="relu", precision=0)
         return GF.linear(h, self.mlp[2].weight, self.mlp[2].bias, precision=0)
+
+    def _forward_pointnet(self, source_pos, query_pos, g):
+        """geoembed.py:184-222: MLP(nbr - query) per edge, segment max | mean, fc; rows without neighbours = 0"""
+        nq = query_pos.shape[0]
+        if g.by_dst.num_edges == 0:
+            return torch.zeros(nq, self.output_dim, dtype=query_pos.dtype, device=query_pos.device)
+        c = EO.edge_coords(source_pos, query_pos, g, 1)                                    # :196-198
+        h = GF.linear(c, self.pointnet_mlp[0].weight, self.pointnet_mlp[0].bias, act="relu", precision=0)
+        h = GF.linear(h, self.pointnet_mlp[2].weight, self.pointnet_mlp[2].bias, act="relu", precision=0)
+        pooled = EO.SegmentReduceFn.apply(h, g, EO.MAX if self.pooling == "max" else EO.MEAN)   # :211-216
+        po = GF.linear(pooled, self.fc[0].weight, self.fc[0].bias, precision=0)
+        rp = g.by_dst.rowptr
+        has = (rp[1:] > rp[:-1]).to(torch.float32)                                          # :219 masked assignment
+        return EO.RowScaleFn.apply(po, has)

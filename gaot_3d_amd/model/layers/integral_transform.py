@@ -1,13 +1,17 @@
 """IntegralTransform with the reference's constructor/forward signature
-(src/model/layers/integral_transform.py:31-40, 80-87) running the fused HIP kernel (csrc/gno.hip).
+(src/model/layers/integral_transform.py:31-40, 80-87).
 
-Supported on the HIP path: transform_type='linear', use_attn falsy, coord_dim 3, kernel MLP
-6 -> 64 (x1..4) -> 32.  Everything else raises NotImplementedError (no silent fallback)."""
+Default configuration -- transform_type='linear', no attention weights, kernel MLP 6 -> 64 (x1..4) -> 32 -- runs the
+fused HIP kernels (csrc/gno.hip, gno_bf16.hip: no per-edge tensor ever reaches HBM).  Every other variant the
+reference offers ('nonlinear', 'nonlinear_kernelonly', use_attn cosine / dot_product, other MLP shapes, f_y=None)
+runs the general path: per-edge tensors in dst-sorted order, the MLP on the GEMM kernels, gather / segment /
+element-wise glue and its autograd in csrc/edgeops.hip (gaot_3d_amd/edgeops.py).  HIP only, no CPU fallback."""
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
+from ... import edgeops as EO
 from ... import functional as GF
 from ... import ops
 from .mlp import LinearChannelMLP
@@ -55,16 +59,50 @@ class IntegralTransform(nn.Module):
                 batch_x=None, graph=None):
         """y_pos [N_y,3] source coords, x_pos [N_x,3] query coords, edge_index [2,E] (row 0 -> y, row 1 -> x),
         f_y [N_y,C].  ``graph`` (optional) = prebuilt neighbour lists for edge_index."""
-        if self.use_attn:
-            raise NotImplementedError("IntegralTransform(use_attn=True) is not implemented on the HIP path")
-        if self.transform_type != "linear":
-            raise NotImplementedError(f"transform_type='{self.transform_type}' is not implemented on the HIP path "
-                                      f"(only 'linear')")
-        if f_y is None:
-            raise NotImplementedError("IntegralTransform without f_y is not implemented on the HIP path")
+        if self.transform_type not in ("linear", "nonlinear", "nonlinear_kernelonly"):
+            raise ValueError(f"Invalid transform_type: {self.transform_type}")
+        fcs = list(self.channel_mlp.fcs)
+        if edge_index is not None and edge_index.shape[1] == 0 and graph is None:   # integral_transform.py:106-112
+            return torch.zeros(x_pos.shape[0], fcs[-1].weight.shape[0], dtype=x_pos.dtype, device=x_pos.device)
         if graph is None:
             graph = graph_for(edge_index.to(x_pos.device), y_pos.shape[0], x_pos.shape[0])
-        params = []
-        for fc in self.channel_mlp.fcs:
-            params += [fc.weight, fc.bias]
-        return GF.GnoFn.apply(f_y, y_pos, x_pos, graph, *params)
+        if self._fused_eligible(fcs, f_y):
+            params = []
+            for fc in fcs:
+                params += [fc.weight, fc.bias]
+            return GF.GnoFn.apply(f_y, y_pos, x_pos, graph, *params)
+        return self._forward_general(fcs, y_pos, x_pos, f_y, graph)
+
+    def _fused_eligible(self, fcs, f_y) -> bool:
+        if self.use_attn or self.transform_type != "linear" or f_y is None:
+            return False
+        if getattr(self.channel_mlp, "non_linearity", "gelu") != "gelu" or not (2 <= len(fcs) <= 5):
+            return False
+        dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
+        ok = dims[0] == (64, 6) and dims[-1] == (32, 64) and all(d == (64, 64) for d in dims[1:-1])
+        return ok and f_y.shape[1] == 32
+
+    def _forward_general(self, fcs, y_pos, x_pos, f_y, g):
+        """integral_transform.py:114-171 on per-edge tensors (dst-sorted order)"""
+        tt = self.transform_type
+        act = getattr(self.channel_mlp, "non_linearity", "gelu")
+        k = EO.EdgeInputFn.apply(y_pos, x_pos, f_y if (f_y is not None and tt != "linear") else None, g)   # :146-152
+        for i, fc in enumerate(fcs):                                                                        # :154
+            w = fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight
+            k = GF.linear(k, w, fc.bias, act=act if i < len(fcs) - 1 else None)
+        if f_y is not None and tt != "nonlinear_kernelonly":                                                # :156-157
+            k = EO.MulFn.apply(k, EO.GatherFn.apply(f_y, g, 0))
+        mode = EO.MEAN
+        if self.use_attn:                                                                                   # :126-142
+            cd = self.coord_dim
+            if cd != 3:
+                raise NotImplementedError("use_attn on the HIP path needs coord_dim = 3")
+            if self.attention_type == "dot_product":
+                qn = GF.linear(x_pos, self.query_proj.weight, self.query_proj.bias, precision=0)
+                kn = GF.linear(y_pos, self.key_proj.weight, self.key_proj.bias, precision=0)
+                sc = EO.RowDotFn.apply(EO.GatherFn.apply(qn, g, 1), EO.GatherFn.apply(kn, g, 0), self.scaling_factor)
+            else:
+                sc = EO.edge_coords(y_pos, x_pos, g, 2)          # cosine of the raw coordinates: no parameters
+            k = EO.RowScaleFn.apply(k, EO.SegmentSoftmaxFn.apply(sc, g))                                    # :159-160
+            mode = EO.SUM                                                                                   # :163
+        return EO.SegmentReduceFn.apply(k, g, mode)

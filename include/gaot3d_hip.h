@@ -279,6 +279,38 @@ int gaot_mlp2_bwd(const float* x, int64_t num_rows, int in_dim, int hidden, int 
                   const float* w2, const float* d_out, float* d_x, float* d_w1, float* d_b1, float* d_w2, void* workspace,
                   size_t workspace_bytes, gaot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * General (unfused) per-edge operators: the glue around the GEMM-run edge MLP for the GNO variants the
+ * fused kernels do not cover -- IntegralTransform transform_type "nonlinear" / "nonlinear_kernelonly" and
+ * the segment-softmax attention weights (reference integral_transform.py:68-78, 126-160), other kernel-MLP
+ * widths, PointNet GeometricEmbedding (geoembed.py:184-222) -- and their autograd.  Per-edge tensors
+ * are row-major fp32 in the dst-sorted edge order of gaot_csr_build (a segment = a contiguous row range);
+ * a reduction over the other endpoint walks that endpoint's CSR through `map` (position in its order ->
+ * position in the dst order).  Fixed-order reductions, no atomics.
+ *   gather_rows        out[e] = table[idx[e]]                       (backward: segment_reduce sum over idx's CSR)
+ *   segment_reduce     out[r] = sum | mean | max over the row's edges (mode 0 | 1 | 2; empty row -> 0, like
+ *                      scatter_native.py:4-54); max also returns the arg-max edge per (row, channel)
+ *   segment_reduce_bwd d_vals from d_out (sum / mean: broadcast [/ degree]; max: routed to the arg-max edge)
+ *   segment_softmax    w = exp(s - max_seg) / max(sum_seg, FLT_MIN)   and   ds = w * (dw - sum_seg(w dw))
+ *   edge_coords        mode 0: [y[src], x[dst]] (6)   1: y[src] - x[dst] (3)   2: cos(x[dst], y[src]) (1)
+ *   mul / mul_rowsum   a .* b with b per element or per row;  row-wise sum of a .* b
+ * ------------------------------------------------------------------------------------------- */
+int gaot_gather_rows(const float* table, int64_t ld, const int32_t* idx, int64_t num_edges, int channels, float* out,
+                     int64_t ld_out, gaot_stream_t stream);
+int gaot_segment_reduce(const float* vals, int64_t ld_vals, const int32_t* rowptr, const int32_t* map, int64_t num_rows,
+                        int channels, int mode, float* out, int32_t* argmax, gaot_stream_t stream);
+int gaot_segment_reduce_bwd(const float* d_out, const int32_t* key, const int32_t* rowptr, const int32_t* argmax,
+                            int64_t num_rows, int64_t num_edges, int channels, int mode, float* d_vals,
+                            gaot_stream_t stream);
+int gaot_segment_softmax_fwd(const float* scores, const int32_t* rowptr, int64_t num_rows, float* w, gaot_stream_t stream);
+int gaot_segment_softmax_bwd(const float* w, const float* dw, const int32_t* rowptr, int64_t num_rows, float* ds,
+                             gaot_stream_t stream);
+int gaot_edge_coords(const float* y_pos, const float* x_pos, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                     int mode, float* out, int64_t ld_out, gaot_stream_t stream);
+int gaot_mul(const float* a, const float* b, int64_t rows, int channels, int b_is_row_scalar, float* out,
+             gaot_stream_t stream);
+int gaot_mul_rowsum(const float* a, const float* b, int64_t rows, int channels, float* out, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
