@@ -76,6 +76,8 @@ SIGNATURES = {
     "gaot_exclusive_scan_i32": (_i, [_p, _i64, _p, _p, _sz, _p]),
     "gaot_segment_cap_flags": (_i, [_p, _p, _i64, _i, _p, _p]),
     "gaot_unique_pair_flags": (_i, [_p, _p, _i64, _p, _p]),
+    "gaot_random_keep_flags": (_i, [_p, _i64, _d, _p, _p]),
+    "gaot_segment_random_cap_flags": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "gaot_compact_pairs": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "gaot_cast_bf16": (_i, [_p, _p, _i64, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),

@@ -129,6 +129,42 @@ __global__ void k_segment_cap_flags(const int* __restrict__ rowptr, const int* _
     flags[i] = (i - rowptr[key_sorted[i]] < cap) ? 1 : 0;
 }
 
+// ---- neighbour sampling (reference magno.py:297-371, apply_neighbor_sampling) -------------------------------
+// The reference draws from torch's generator (randperm per over-full query; torch_geometric dropout_edge); here the
+// draw is a counter-based 32-bit hash of (seed, edge id), restated in the oracle, so a sample is reproducible from
+// its seed word and needs no generator state on the device.
+__device__ __forceinline__ uint32_t sample_hash(unsigned long long seed, uint32_t i) {
+    uint32_t x = (uint32_t)seed ^ (i * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += (uint32_t)(seed >> 32);
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15;
+    return x;
+}
+// 'ratio': keep edge i with probability thr / 2^32
+__global__ void k_random_keep_flags(const unsigned long long* __restrict__ seed, int64_t n, uint32_t thr, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = sample_hash(*seed, (uint32_t)i) < thr ? 1 : 0;
+}
+// 'max_neighbors': of every segment with more than cap entries keep the cap entries with the smallest (hash, index)
+// -- a uniformly random subset; smaller segments are kept whole
+__global__ void k_segment_random_cap_flags(const unsigned long long* __restrict__ seed, const int* __restrict__ rowptr,
+                                           const int* __restrict__ key_sorted, int64_t n, int cap, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = key_sorted[i];
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    if (hi - lo <= cap) { flags[i] = 1; return; }
+    const unsigned long long sd = *seed;
+    const uint32_t mine = sample_hash(sd, (uint32_t)i);
+    int rank = 0;
+    for (int j = lo; j < hi; ++j) {
+        const uint32_t h = sample_hash(sd, (uint32_t)j);
+        rank += (h < mine || (h == mine && j < i)) ? 1 : 0;
+    }
+    flags[i] = rank < cap ? 1 : 0;
+}
+
 // flags[i] = 1 when pair i differs from pair i-1 (lists sorted by (a, b))
 __global__ void k_unique_pair_flags(const int* __restrict__ a, const int* __restrict__ b, int64_t P, int* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,6 +289,31 @@ extern "C" int gaot_segment_cap_flags(const int32_t* rowptr, const int32_t* key_
     GAOT_CHECK_ARG(rowptr && key_sorted && flags, "null pointer");
     hipLaunchKernelGGL(k_segment_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, key_sorted,
                        n, cap, flags);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_random_keep_flags(const unsigned long long* seed, int64_t n, double keep_prob, int32_t* flags,
+                                      gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && keep_prob >= 0.0 && keep_prob <= 1.0, "bad argument");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(seed && flags, "null pointer");
+    double t = keep_prob * 4294967296.0 + 0.5;
+    const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    hipLaunchKernelGGL(k_random_keep_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, n, thr, flags);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_random_cap_flags(const unsigned long long* seed, const int32_t* rowptr, const int32_t* key_sorted,
+                                             int64_t n, int cap, int32_t* flags, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && cap >= 1, "bad argument");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(seed && rowptr && key_sorted && flags, "null pointer");
+    hipLaunchKernelGGL(k_segment_random_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       rowptr, key_sorted, n, cap, flags);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

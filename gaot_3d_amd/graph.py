@@ -135,6 +135,46 @@ def cap_per_key(key: Tensor, other: Tensor, num_keys: int, cap: int) -> Tuple[Te
     return _compact(s.key, s.other, flags)
 
 
+def apply_neighbor_sampling(edge_index: Tensor, num_query_nodes: int, device=None, sampling_strategy: Optional[str] = None,
+                            max_neighbors: Optional[int] = None, sample_ratio: Optional[float] = None,
+                            training: bool = True, seed: Optional[Tensor] = None) -> Tensor:
+    """reference magno.py:297-371, same arguments (+ ``seed``: one-element int64 device tensor; default = the next
+    word of the device seed stream, functional.next_dropout_seed).  'max_neighbors': every query keeps at most
+    ``max_neighbors`` uniformly random edges (applied in training and eval alike, as in the reference); 'ratio': every
+    edge is kept with probability ``sample_ratio`` in training mode.  The result is sorted by query (the reference keeps
+    the input order; the operators downstream do not depend on it)."""
+    if sampling_strategy is None:
+        return edge_index
+    if num_query_nodes == 0 or edge_index.shape[1] == 0:
+        return edge_index
+    if sampling_strategy == "max_neighbors":
+        if max_neighbors is None:
+            raise ValueError("max_neighbors must be provided when using 'max_neighbors' sampling strategy")
+    elif sampling_strategy == "ratio":
+        if sample_ratio is None:
+            raise ValueError("sample_ratio must be provided when using 'ratio' sampling strategy")
+        if sample_ratio >= 1.0 or not training:
+            return edge_index
+    else:
+        raise ValueError(f"Invalid sampling strategy: {sampling_strategy}")
+    _need_cuda(edge_index, "edge_index")
+    lib = _lib.load()
+    if seed is None:
+        from .functional import next_dropout_seed
+        seed = next_dropout_seed(edge_index.device)
+    e = edge_index.shape[1]
+    flags = torch.empty(e, dtype=torch.int32, device=edge_index.device)
+    s = ops.csr_build(edge_index, 1, num_query_nodes)          # key = query, other = source
+    if sampling_strategy == "max_neighbors":
+        check(lib.gaot_segment_random_cap_flags(ops._ptr(seed), ops._ptr(s.rowptr), ops._ptr(s.key), e, int(max_neighbors),
+                                                ops._ptr(flags), ops._stream()), "gaot_segment_random_cap_flags")
+    else:
+        check(lib.gaot_random_keep_flags(ops._ptr(seed), e, float(sample_ratio), ops._ptr(flags), ops._stream()),
+              "gaot_random_keep_flags")
+    q, src = _compact(s.key, s.other, flags)
+    return torch.stack([src, q]).to(edge_index.dtype)
+
+
 def coalesce(row0: Tensor, row1: Tensor, num_row0: int, num_row1: int) -> Tensor:
     """sort by (row0, row1) and drop duplicates -- torch_geometric.utils.coalesce as the reference uses it for
     'bidirectional' (magno.py:219-220): stable sort by row1, stable sort by row0, adjacent-unique, compact"""

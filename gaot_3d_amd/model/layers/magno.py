@@ -154,8 +154,17 @@ def _make_mlp(mlp_type, layers):
 
 
 def _check_unsupported(cfg: MAGNOConfig):
-    if cfg.sampling_strategy is not None:
-        raise NotImplementedError("neighbor sampling (sampling_strategy) is not implemented on the HIP path")
+    if cfg.sampling_strategy not in (None, "max_neighbors", "ratio"):
+        raise ValueError(f"Invalid sampling strategy: {cfg.sampling_strategy}")
+
+
+def _sample(module, edge_index, num_query):
+    """reference magno.py:529-538 / 739-748"""
+    if module.sampling_strategy is None:
+        return edge_index
+    from ...graph import apply_neighbor_sampling
+    return apply_neighbor_sampling(edge_index, num_query, edge_index.device, module.sampling_strategy, module.max_neighbors,
+                                   module.sample_ratio, module.training)
 
 
 def _sum_scales(outs):
@@ -185,6 +194,9 @@ class MAGNOEncoder(nn.Module):
     def __init__(self, in_channels, out_channels, gno_config: MAGNOConfig):
         super().__init__()
         _check_unsupported(gno_config)
+        self.sampling_strategy = gno_config.sampling_strategy
+        self.max_neighbors = gno_config.max_neighbors
+        self.sample_ratio = gno_config.sample_ratio
         self.gno_radius = gno_config.gno_radius
         self.scales = gno_config.scales
         self.lifting_channels = gno_config.lifting_channels
@@ -252,7 +264,9 @@ class MAGNOEncoder(nn.Module):
                 edge_index = get_neighbor_strategy(self.encoder_strategy, phys_pos, batch.batch, latent_tokens_pos,
                                                    latent_tokens_batch_idx, self.gno_radius * scale, self.k_neighbors,
                                                    False, latent_dims=getattr(self, "latent_dims", None)).to(device)
-            g = graph_for(edge_index, phys_pos.shape[0], latent_tokens_pos.shape[0], batch, ("enc", si))
+            edge_index = _sample(self, edge_index, latent_tokens_pos.shape[0])
+            g = graph_for(edge_index, phys_pos.shape[0], latent_tokens_pos.shape[0],
+                          batch if self.sampling_strategy is None else None, ("enc", si))
             enc = self.gno(y_pos=phys_pos, x_pos=latent_tokens_pos, edge_index=edge_index, f_y=lifted,
                            graph=g) if self.use_gno else None
             shard_group = getattr(self, "_shard_group", None)
@@ -279,6 +293,9 @@ class MAGNODecoder(nn.Module):
     def __init__(self, in_channels, out_channels, gno_config: MAGNOConfig):
         super().__init__()
         _check_unsupported(gno_config)
+        self.sampling_strategy = gno_config.sampling_strategy
+        self.max_neighbors = gno_config.max_neighbors
+        self.sample_ratio = gno_config.sample_ratio
         self.gno_radius = gno_config.gno_radius
         self.scales = gno_config.scales
         self.coord_dim = gno_config.gno_coord_dim
@@ -322,7 +339,9 @@ class MAGNODecoder(nn.Module):
                                                    latent_tokens_pos, latent_tokens_batch_idx, self.gno_radius * scale,
                                                    self.k_neighbors, True,
                                                    latent_dims=getattr(self, "latent_dims", None)).to(device)
-            g = graph_for(edge_index, latent_tokens_pos.shape[0], phys_pos_query.shape[0], batch, ("dec", si))
+            edge_index = _sample(self, edge_index, phys_pos_query.shape[0])
+            g = graph_for(edge_index, latent_tokens_pos.shape[0], phys_pos_query.shape[0],
+                          batch if self.sampling_strategy is None else None, ("dec", si))
             dec = self.gno(y_pos=latent_tokens_pos, x_pos=phys_pos_query, edge_index=edge_index, f_y=rndata_flat, graph=g)
             if self.use_geoembed:
                 if getattr(self, "_shard_group", None) is not None:

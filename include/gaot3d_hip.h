@@ -261,6 +261,14 @@ int gaot_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* wo
 int gaot_segment_cap_flags(const int32_t* rowptr, const int32_t* key_sorted, int64_t n, int cap, int32_t* flags,
                            gaot_stream_t stream);
 int gaot_unique_pair_flags(const int32_t* a, const int32_t* b, int64_t n, int32_t* flags, gaot_stream_t stream);
+/* neighbour sampling (reference magno.py:297-371, apply_neighbor_sampling): 'ratio' keeps every edge with probability
+ * keep_prob (torch_geometric dropout_edge); 'max_neighbors' keeps a uniformly random `cap` of the edges of every
+ * query that has more (randperm[:cap] in the reference).  The draws are a counter-based hash of (*seed, position),
+ * seed = DEVICE pointer to one 64-bit word; compact with gaot_exclusive_scan_i32 + gaot_compact_pairs. */
+int gaot_random_keep_flags(const unsigned long long* seed, int64_t n, double keep_prob, int32_t* flags,
+                           gaot_stream_t stream);
+int gaot_segment_random_cap_flags(const unsigned long long* seed, const int32_t* rowptr, const int32_t* key_sorted,
+                                  int64_t n, int cap, int32_t* flags, gaot_stream_t stream);
 int gaot_compact_pairs(const int32_t* a, const int32_t* b, const int32_t* flags, const int32_t* offsets, int64_t n,
                        int32_t* out_a, int32_t* out_b, gaot_stream_t stream);
 

@@ -200,6 +200,47 @@ def geoembed(sd: SD, prefix: str, source_pos: Tensor, query_pos: Tensor, edge_in
 
 
 # --------------------------------------------------------------------------------------
+# Neighbour sampling (src/model/layers/magno.py:297-371).  The reference draws from torch's generator (randperm /
+# dropout_edge: third-party torch_geometric, "parity unpinned"); the product draws from a counter-based hash of
+# (seed, position in the query-sorted edge list), restated here bit for bit (integer work).
+# --------------------------------------------------------------------------------------
+def _sample_hash(seed: int, idx):
+    import numpy as np
+    seed &= 0xFFFFFFFFFFFFFFFF
+    lo, hi = np.uint64(seed & _M32), np.uint64(seed >> 32)
+    x = (lo ^ ((idx.astype(np.uint64) * np.uint64(0x9E3779B1)) & _M32)) & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & _M32
+    x ^= x >> np.uint64(16)
+    x = (x + hi) & _M32
+    x ^= x >> np.uint64(17); x = (x * np.uint64(0xed5ad4bb)) & _M32
+    x ^= x >> np.uint64(11); x = (x * np.uint64(0xac4c1b51)) & _M32
+    x ^= x >> np.uint64(15)
+    return x
+
+
+def neighbor_sampling_keep(seed: int, dst_sorted: Tensor, num_query: int, strategy: str, max_neighbors=None,
+                           sample_ratio=None) -> Tensor:
+    """bool keep flag per edge of a QUERY-SORTED edge list (positions = the product's CSR order)"""
+    import numpy as np
+    n = dst_sorted.numel()
+    h = _sample_hash(seed, np.arange(n, dtype=np.uint64))
+    if strategy == "ratio":
+        thr = min(int(sample_ratio * 4294967296.0 + 0.5), 4294967295)
+        return torch.from_numpy(h < np.uint64(thr))
+    keep = np.ones(n, dtype=bool)
+    d = dst_sorted.numpy()
+    counts = np.bincount(d, minlength=num_query)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    for r in np.nonzero(counts > max_neighbors)[0]:
+        lo, hi = start[r], start[r + 1]
+        order = np.lexsort((np.arange(lo, hi), h[lo:hi]))      # by hash, ties by position
+        keep[lo:hi] = False
+        keep[lo + order[:max_neighbors]] = True
+    return torch.from_numpy(keep)
+
+
+# --------------------------------------------------------------------------------------
 # MAGNO encoder / decoder  (src/model/layers/magno.py:468-600, 691-798)
 # --------------------------------------------------------------------------------------
 def _pair(v, n=2):

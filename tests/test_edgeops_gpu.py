@@ -167,3 +167,58 @@ def test_model_with_nonlinear_attention_pointnet(precision):
         cos = num / (d1 ** 0.5 * d2 ** 0.5)
         print(f"[parity] variants bf16 grad cosine = {cos:.6f}")
         assert cos >= 0.999
+
+
+def test_model_with_neighbor_sampling():
+    """MAGNOConfig.sampling_strategy = 'max_neighbors' (reference magno.py:529-538, 739-748): the model's step equals
+    the oracle's step on the edge lists the sampler produces for the same seed words (encoder draw first, then the
+    decoder's; the sampler itself is checked bit for bit in test_graph_gpu.py)."""
+    import copy
+
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.graph import apply_neighbor_sampling
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from gaot_3d_amd.model.layers.magno import MAGNOConfig
+    cfg = types.SimpleNamespace(
+        magno=MAGNOConfig(gno_coord_dim=3, lifting_channels=32, encoder_feature_attr="pos", mlp_type="linear",
+                          use_geoembed=[True, False], neighbor_strategy="knn", k_neighbors=8, precompute_edges=True,
+                          sampling_strategy="max_neighbors", max_neighbors=5),
+        transformer=TransformerConfig(patch_size=2, hidden_size=256, num_layers=2, positional_embedding="rope",
+                                      attn_config=AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8,
+                                                                  atten_dropout=0.0),
+                                      ffn_config=FFNConfig(hidden_size=1024)),
+        latent_tokens=(8, 8, 8))
+    gaot_3d_amd.set_precision("fp32")
+    torch.manual_seed(0)
+    model = init_model(3, 1, "gaot_3d", cfg)
+    batch, tokens = make_synthetic_sample(3000, cfg.latent_tokens, k=8, in_normals=False, surface=False, seed=2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    seed0 = 424242
+    words = GF.dropout_seed_sequence(seed0, 2)
+
+    def dev_seed(v):
+        return torch.tensor([v - (1 << 64) if v >= (1 << 63) else v], dtype=torch.int64, device=DEV)
+
+    sampled = copy.copy(batch)
+    sampled.encoder_edge_index_s0 = apply_neighbor_sampling(batch.encoder_edge_index_s0.to(DEV), 512, DEV, "max_neighbors",
+                                                            max_neighbors=5, seed=dev_seed(words[0])).cpu()
+    sampled.decoder_edge_index_s0 = apply_neighbor_sampling(batch.decoder_edge_index_s0.to(DEV), 3000, DEV, "max_neighbors",
+                                                            max_neighbors=5, seed=dev_seed(words[1])).cpu()
+    assert sampled.decoder_edge_index_s0.shape[1] == 3000 * 5
+    ocfg = copy.deepcopy(cfg)
+    ocfg.magno.sampling_strategy = None
+    pred_r, loss_r, grads_r = orc.train_step_grads(sd, ocfg, sampled, tokens)
+    model = model.to(DEV).train()
+    bd = batch.to(DEV)
+    GF.set_dropout_seed(seed0, DEV)
+    pred = model(batch=bd, tokens_pos=tokens.to(DEV))
+    loss = GF.mse_loss(pred, bd.x)
+    loss.backward()
+    close("sampling/pred", pred, pred_r, 1e-4, 2e-5)
+    close("sampling/loss", loss, loss_r, 1e-5, 1e-7)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            close(f"sampling/grad/{k}", p.grad, grads_r[k], 1e-3, 1e-5)

@@ -7,6 +7,9 @@ import sys
 import pytest
 import torch
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import gaot_oracle as orc  # noqa: E402  (checker only)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
@@ -168,3 +171,50 @@ def test_model_builds_its_graphs_on_device(strategy):
     assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[True][0]), (res[True][0], res[False][0])
     for k, g in res[True][1].items():
         assert torch.allclose(res[False][1][k], g, rtol=1e-3, atol=1e-5 * max(1.0, float(g.abs().max()))), k
+
+
+@pytest.mark.parametrize("strategy", ["max_neighbors", "ratio"])
+def test_neighbor_sampling(strategy):
+    """apply_neighbor_sampling (reference magno.py:297-371): the kept set equals the oracle's restatement of the
+    counter-based draw bit for bit; 'max_neighbors' leaves min(deg, cap) edges per query and smaller rows untouched,
+    'ratio' keeps the configured fraction and is the identity in eval mode; different seeds give different samples and
+    every edge of an over-full row is kept equally often."""
+    from gaot_3d_amd import ops
+    from gaot_3d_amd.graph import apply_neighbor_sampling
+    g = torch.Generator().manual_seed(5)
+    nq, ns, e = 300, 2000, 20000
+    dst = torch.randint(0, nq, (e,), generator=g)
+    dst[:400] = 7                      # one heavy query
+    dst[dst == 11] = 12                # one empty query
+    src = torch.randint(0, ns, (e,), generator=g)
+    ei = torch.stack([src, dst]).to(DEV)
+    seed_val = 0x1234ABCD5678
+    seed = torch.tensor([seed_val], dtype=torch.int64, device=DEV)
+    kw = dict(max_neighbors=16) if strategy == "max_neighbors" else dict(sample_ratio=0.4)
+    out = apply_neighbor_sampling(ei, nq, DEV, strategy, training=True, seed=seed, **kw)
+    s = ops.csr_build(ei, 1, nq)
+    keep = orc.neighbor_sampling_keep(seed_val, s.key.cpu().long(), nq, strategy, kw.get("max_neighbors"), kw.get("sample_ratio"))
+    want = torch.stack([s.other.cpu()[keep], s.key.cpu()[keep]]).long()
+    assert torch.equal(out.cpu().long(), want)
+    deg0 = torch.bincount(dst, minlength=nq)
+    deg1 = torch.bincount(out[1].cpu().long(), minlength=nq)
+    if strategy == "max_neighbors":
+        assert torch.equal(deg1, deg0.clamp(max=16))
+        assert torch.equal(apply_neighbor_sampling(ei, nq, DEV, strategy, training=False, seed=seed, **kw).cpu(), out.cpu())
+        counts = torch.zeros(int(deg0[7]))
+        rows = (s.key.cpu() == 7).nonzero().flatten()
+        for t in range(200):
+            sd = torch.tensor([seed_val + 7919 * t], dtype=torch.int64, device=DEV)
+            o = apply_neighbor_sampling(ei, nq, DEV, strategy, seed=sd, **kw)
+            k2 = orc.neighbor_sampling_keep(seed_val + 7919 * t, s.key.cpu().long(), nq, strategy, 16, None)
+            assert int((o[1] == 7).sum()) == 16
+            counts += k2[rows].float()
+        expect = 200 * 16 / float(deg0[7])
+        assert (counts - expect).abs().max().item() < 6 * (expect ** 0.5) + 1
+    else:
+        assert abs(out.shape[1] / e - 0.4) < 0.02
+        assert apply_neighbor_sampling(ei, nq, DEV, strategy, training=False, seed=seed, **kw) is ei
+        assert apply_neighbor_sampling(ei, nq, DEV, strategy, sample_ratio=1.0) is ei
+    other = apply_neighbor_sampling(ei, nq, DEV, strategy, seed=torch.tensor([99], dtype=torch.int64, device=DEV), **kw)
+    assert other.shape != out.shape or not torch.equal(other, out)
+    assert apply_neighbor_sampling(ei, nq, DEV, None) is ei
