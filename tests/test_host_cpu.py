@@ -67,16 +67,33 @@ def test_init_model_rejects_unknown():
         init_model(3, 1, "gino", types.SimpleNamespace())
 
 
-def test_unsupported_variants_raise():
+def test_variants_have_no_cpu_fallback_and_bad_options_raise():
+    """every IntegralTransform / GeoEmbed variant runs on the HIP path only: CPU tensors fail loudly (no fallback);
+    invalid option strings raise ValueError like the reference"""
+    from gaot_3d_amd._lib import GaotError
+    from gaot_3d_amd.graph import apply_neighbor_sampling
     from gaot_3d_amd.model.layers.geoembed import GeometricEmbedding
     from gaot_3d_amd.model.layers.integral_transform import IntegralTransform
+    ei = torch.tensor([[0, 1, 2], [0, 1, 1]])
     it = IntegralTransform(channel_mlp_layers=[38, 64, 32], transform_type="nonlinear")
-    with pytest.raises(NotImplementedError):
-        it(torch.zeros(4, 3), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long), torch.zeros(4, 32))
-    with pytest.raises(NotImplementedError):
-        GeometricEmbedding(3, 32, method="pointnet")(torch.zeros(4, 3), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long))
+    with pytest.raises((GaotError, RuntimeError)):
+        it(torch.zeros(4, 3), torch.zeros(2, 3), ei, torch.zeros(4, 32))
+    with pytest.raises((GaotError, RuntimeError)):
+        GeometricEmbedding(3, 32, method="pointnet")(torch.zeros(4, 3), torch.zeros(2, 3), ei)
+    # empty edge list: zeros without touching the device (integral_transform.py:106-112)
+    out = it(torch.zeros(4, 3), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long), torch.zeros(4, 32))
+    assert out.shape == (2, 32) and not out.any()
     with pytest.raises(ValueError):
         GeometricEmbedding(3, 32, method="nope")
+    with pytest.raises(ValueError):
+        IntegralTransform(channel_mlp_layers=[6, 64, 32], transform_type="nope")(torch.zeros(4, 3), torch.zeros(2, 3), ei,
+                                                                               torch.zeros(4, 32))
+    with pytest.raises(ValueError):
+        apply_neighbor_sampling(ei, 2, None, "nope")
+    with pytest.raises(ValueError):
+        apply_neighbor_sampling(ei, 2, None, "max_neighbors")
+    assert apply_neighbor_sampling(ei, 2, None, None) is ei
+    assert apply_neighbor_sampling(ei, 2, None, "ratio", sample_ratio=0.5, training=False) is ei
 
 
 def test_no_cpu_fallback():
