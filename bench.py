@@ -302,7 +302,8 @@ def main():
                                    f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step",
                        "points": n_total, "latent_tokens": list(latent), "edges": e, "layers": args.layers,
                        "precision": args.precision, "points_per_gpu": args.points, "atten_dropout": args.atten_dropout,
-                       "sharding": f"point-shard x{world}, latent grid / Transformer replicated" if world > 1 else "none"},
+                       "sharding": f"point-shard x{world}; latent grid / Transformer replicated, attention heads split over the "
+                                   f"ranks (all-gather of head outputs)" if world > 1 else "none"},
             "loss": float(loss.detach()),
             "launch": "hipGraph replay of one captured step" if graph is not None else "eager",
             # wall time of the two instrumented eager steps (only meaningful without a captured graph: right after a

@@ -171,16 +171,44 @@ def dropout_seed_sequence(seed0: int, n: int):
     return [(int(seed0) + i * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
 
 
+def _all_gather_stack(t: Tensor, group, gsz: int) -> Tensor:
+    """[G, *t.shape]: one all-gather (RCCL: all_gather_into_tensor; gloo, used by the one-GPU tests: list form)"""
+    import torch.distributed as dist
+    t = t if t.is_contiguous() else t.contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((gsz,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out
+    parts = [torch.empty_like(t) for _ in range(gsz)]
+    dist.all_gather(parts, t, group=group)
+    return torch.stack(parts)
+
+
 class AttentionFn(Function):
     """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k, optional dropout
     on the attention weights (reference attn.py:122-127).
     precision fp32: exact-fp32 MFMA kernels (csrc/attn.hip); bf16: csrc/attn_bf16.hip."""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, dropout_p: float = 0.0):
+    def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, dropout_p: float = 0.0,
+                head_group=None):
+        """``head_group`` (extension, gaot_3d_amd/sharding.py): a process group whose ranks hold the SAME qkv (replicated
+        Transformer of a point-sharded sample); rank r computes heads [r*h/G, (r+1)*h/G) only and the outputs are
+        all-gathered, so the attention work -- 60 % of a 500 K-point step -- is divided by G instead of repeated G times."""
         scale = 1.0 / (32 ** 0.5)
         bf16 = ops.get_precision() == "bf16"
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        ctx.hp = None
+        if head_group is not None:
+            import torch.distributed as dist
+            gsz, grk = dist.get_world_size(head_group), dist.get_rank(head_group)
+            if gsz > 1 and h % gsz == 0 and hkv % gsz == 0:
+                hl, kl = h // gsz, hkv // gsz
+                ctx.hp = (head_group, gsz, grk, h, hkv)
+                qkv = torch.cat([qkv[:, grk * hl * 32:(grk + 1) * hl * 32],
+                                 qkv[:, (h + grk * kl) * 32:(h + (grk + 1) * kl) * 32],
+                                 qkv[:, (h + hkv + grk * kl) * 32:(h + hkv + (grk + 1) * kl) * 32]], dim=1)
+                h, hkv = hl, kl
         seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
         if bf16:
             o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed)
@@ -194,6 +222,10 @@ class AttentionFn(Function):
         empty = torch.empty(0, device=qkv.device)
         ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else empty, seed if seed is not None else empty)
         ctx.dims = (b, s, h, hkv, scale, freqs is not None, bf16, dropout_p)
+        if ctx.hp is not None:
+            group, gsz = ctx.hp[0], ctx.hp[1]
+            allo = _all_gather_stack(o, group, gsz)
+            return allo.permute(1, 0, 2).reshape(o.shape[0], gsz * o.shape[1])     # heads back in global order
         return o
 
     @staticmethod
@@ -201,6 +233,9 @@ class AttentionFn(Function):
         keep, o, lse, freqs, seed = ctx.saved_tensors
         b, s, h, hkv, scale, rope, bf16, dropout_p = ctx.dims
         seed = seed if dropout_p > 0.0 else None
+        if ctx.hp is not None:       # this rank's heads of the (replicated) output gradient
+            grk = ctx.hp[2]
+            d_o = d_o[:, grk * h * 32:(grk + 1) * h * 32]
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
         if bf16:
             dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
@@ -208,7 +243,14 @@ class AttentionFn(Function):
             dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
         if rope:
             ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
-        return dqkv, None, None, None, None, None, None
+        if ctx.hp is not None:
+            group, gsz, grk, hg, kg = ctx.hp
+            rows = dqkv.shape[0]
+            allg = _all_gather_stack(dqkv, group, gsz).permute(1, 0, 2)                                          # [rows, G, (hl + 2 kl) * 32]
+            dqkv = torch.cat([allg[:, :, :h * 32].reshape(rows, hg * 32),
+                              allg[:, :, h * 32:(h + hkv) * 32].reshape(rows, kg * 32),
+                              allg[:, :, (h + hkv) * 32:].reshape(rows, kg * 32)], dim=1)
+        return dqkv, None, None, None, None, None, None, None
 
 
 class SwiGLUFn(Function):

@@ -92,7 +92,7 @@ class GroupQueryFlashAttention(nn.Module):
         GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
-        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp)
+        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp, getattr(self, "_head_group", None))
         y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
 

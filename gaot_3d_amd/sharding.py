@@ -12,6 +12,12 @@ Exchange steps (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gl
   after backward: gradients of the per-point / per-edge parameters (encoder.lifting, encoder.gno, decoder.*)
             are partial sums -> one flat all_reduce (~125 KB).  Per-token parameters (encoder.geoembed,
             encoder.recovery, patch_linear, processor.*) see identical full gradients on every rank.
+Head-parallel attention (on by default in ShardedStep): rank r runs the attention kernels for heads [r*H/G, (r+1)*H/G)
+of the replicated Transformer -- forward all_gather of the head outputs [S, d/G] (16.8 MB total at configs[1]),
+backward all_gather of d(q|k|v) [S, 3d/G] (50 MB total) per layer; everything else of the Transformer stays
+replicated, so no weight-gradient exchange is needed.  With attention dropout every head's mask is drawn by the one
+rank that owns it (same seed stream on all ranks; the masks differ from the unsharded run's, which keys them by the
+global head index).
 The geometry-only GeoEmbed statistics of the encoder are sums over each token's edges, which are spread over the
 ranks: every rank reduces its own edges to additive fp64 moments [M,12] (count, sum d, sum d^2, sum u, sum u u^T),
 one SUM all_reduce (12.6 MB) combines them and every rank finishes the features (csrc/geoembed.hip) -- no rank holds
@@ -130,7 +136,7 @@ def allreduce_partial_grads(params: List[torch.nn.Parameter], group):
 class ShardedStep:
     """forward + MSE + backward of the drop-in model on a rank-local shard (see module docstring)."""
 
-    def __init__(self, model, group, n_total: int):
+    def __init__(self, model, group, n_total: int, head_parallel: bool = True):
         self.model = model
         self.group = group
         self.n_total = n_total
@@ -138,6 +144,11 @@ class ShardedStep:
         model.encoder._shard_group = group
         model.decoder._shard_group = group
         model._shard_group = group
+        # head-parallel attention: the Transformer is replicated, so every rank holds the same q|k|v; each
+        # computes its share of the heads and the outputs / gradients are all-gathered (functional.AttentionFn)
+        for mod in model.modules():
+            if hasattr(mod, "num_kv_heads") and hasattr(mod, "o_proj"):
+                mod._head_group = group if head_parallel else None
 
     def forward_backward(self, batch: MeshBatch, tokens_pos: Optional[Tensor]):
         from . import functional as GF

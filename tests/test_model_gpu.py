@@ -165,10 +165,16 @@ def test_point_shard_plumbing_on_gpu_world1():
         for k, p in model.named_parameters():
             if p.grad is not None:
                 close(f"shard1/grad/{k}", p.grad, ref[k], 1e-5, 1e-7)
+        # the RCCL form of the head-parallel exchange (all_gather_into_tensor) on the 1-rank group
+        t = torch.randn(37, 96, device=DEV)
+        assert torch.equal(GF._all_gather_stack(t, dist.group.WORLD, 1), t[None])
     finally:
         model.encoder._shard_group = None
         model.decoder._shard_group = None
         model._shard_group = None
+        for mod in model.modules():
+            if hasattr(mod, "_head_group"):
+                mod._head_group = None
         if created:
             dist.destroy_process_group()
 
@@ -242,6 +248,7 @@ def test_point_shard_two_ranks_one_gpu(tmp_path):
                         "127.0.0.1", "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))
+    loss = loss.detach()
     print(f"[parity] shard2/loss: {got['loss']:.8f} vs {float(loss):.8f}")
     assert abs(got["loss"] - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-8
     n = 0
