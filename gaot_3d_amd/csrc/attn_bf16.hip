@@ -930,9 +930,15 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups
         const dim3 gkb((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * HKV), 1, (unsigned)B);
+        // one key block per wave: 2 workgroups per CU (256 registers) when the grid is small or the dropout words are
+        // live (at 4 per CU the dropout variant spills: 0.83 -> 0.49 ms at S = 16384, H = 4)
+        const bool occ2 = drop || (int64_t)g1.x * B <= 512;
         if ((int64_t)ceil_div(S, 256) * HKV * B >= 512) {
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+        } else if (occ2) {
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<2, true>), g1, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<2, false>), g1, dim3(256), 0, st, a);
         } else {
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, true>), g1, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, false>), g1, dim3(256), 0, st, a);
@@ -940,9 +946,13 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     }
     if (phase_mask & 4) {
         const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
+        const bool occ2 = drop || (int64_t)g1.x * B <= 512;
         if ((int64_t)ceil_div(S, 256) * H * B >= 512) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+        } else if (occ2) {
+            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<2, true>), g1, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<2, false>), g1, dim3(256), 0, st, a);
         } else {
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, true>), g1, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, false>), g1, dim3(256), 0, st, a);

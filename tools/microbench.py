@@ -23,7 +23,7 @@ def timeit(fn, name, flops=None):
 
 
 if what == "attn":
-    b, s, h = 1, int(os.environ.get('MB_S', 16384)), 8
+    b, s, h = 1, int(os.environ.get('MB_S', 16384)), int(os.environ.get('MB_H', 8))
     qkv = torch.randn(b * s, 3 * h * 32, device=dev)
     freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
     d_o = torch.randn(b * s, h * 32, device=dev)
