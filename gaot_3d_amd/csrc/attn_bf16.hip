@@ -142,6 +142,10 @@ struct FwdArgs {
     int64_t ld;
     int B, S, H, HKV;
     gdrop::Drop drop;
+    // key-range split (few heads: one head is only S/128 workgroups): blockIdx.y = part, keys [part*chunk, +chunk);
+    // part p writes its own normalised O / lse at o + p*o_part, lse + p*lse_part (combined by k_attn_combine)
+    int chunk;
+    int64_t o_part, lse_part;
 };
 
 // dropout words of one 32-key tile for the lanes that hold ONE query and runs of 4 consecutive keys (rows
@@ -238,20 +242,21 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
     // scale (acc, l) is rescaled exactly once.
     uint4 regs[TPM];
-    stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, 0, a.S);
-    for (int64_t k0 = 0; k0 < a.S; k0 += 32 * TPM) {
+    const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
+    stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, lo, a.S);
+    for (int64_t k0 = lo; k0 < hi; k0 += 32 * TPM) {
         __syncthreads();
         stage_storeN<TPM>(regs, lds);
         if constexpr (DROP) stage_col_words<TPM>(bw_s, ck, k0);
         __syncthreads();
-        if (k0 + 32 * TPM < a.S) stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, k0 + 32 * TPM, a.S);
+        if (k0 + 32 * TPM < hi) stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, k0 + 32 * TPM, a.S);
         // one 32-key tile at a time.  Fast path (no running max grows): p = exp2(S - m) needs no subtraction and
         // the O accumulator is not rescaled; otherwise everything at the old scale (acc, l, this tile) is rescaled
         // exactly once, in place.
         auto do_tile = [&](int t, int64_t kb) {
             const char* kt = lds + t * TILE_BYTES;
             const char* vt = lds + (TPM + t) * TILE_BYTES;
-            const bool first = (kb == 0);
+            const bool first = (kb == lo);
             f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
             if (kb + 32 > a.S) {   // wave-uniform: only the last tile of the sequence
@@ -297,14 +302,14 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
 #pragma unroll 1
             for (int t = 0; t < TPM; ++t) {
                 const int64_t kb = k0 + 32 * t;
-                if (kb >= a.S) break;
+                if (kb >= hi) break;
                 do_tile(t, kb);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < TPM; ++t) {
                 const int64_t kb = k0 + 32 * t;
-                if (kb >= a.S) break;
+                if (kb >= hi) break;
                 do_tile(t, kb);
             }
         }
@@ -313,13 +318,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     l += xhalf(l);
     if (qi < a.S) {
         const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
-        float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
+        float* op = a.o + blockIdx.y * a.o_part + (rowbase + qi) * (a.H * D) + head * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 t = make_float4(acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
             *reinterpret_cast<float4*>(op + 8 * g + 4 * hf) = t;
         }
-        if (hf == 0) a.lse[((int64_t)b * a.H + head) * a.S + qi] = m * LN2 + logf(l);
+        if (hf == 0) a.lse[blockIdx.y * a.lse_part + ((int64_t)b * a.H + head) * a.S + qi] = m * LN2 + logf(l);
     }
 }
 
@@ -333,6 +338,10 @@ struct BwdArgs {
     int B, S, H, HKV;
     float scale;
     gdrop::Drop drop;
+    // range split of the streamed side (queries for dK/dV, keys for dQ) over blockIdx.y; part p accumulates into
+    // dqkv + p*dqkv_part, the parts are summed in a fixed order by k_sum_parts
+    int chunk;
+    int64_t dqkv_part;
 };
 
 // dropout words for the lanes that hold ONE key and runs of queries (dK/dV): the row words of the staged queries,
@@ -399,11 +408,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         const float* lsep = a.lse + ((int64_t)b * a.H + head) * a.S;
         const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
         uint4 regs[2];
-        stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, 0, a.S);
+        const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
+        stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, lo, a.S);
         float lt = 0.f, et = 0.f;
         if (threadIdx.x < 64) {
-            lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;   // staged NEGATED: they are the
-            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;         // initial accumulator values
+            const int64_t qq = lo + threadIdx.x;
+            lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;   // staged NEGATED: they are the
+            et = (qq < a.S) ? -delp[qq] * dscale : 0.f;         // initial accumulator values
         }
         uint32_t rk = 0, bsel = 0;
         if constexpr (DROP) {
@@ -412,13 +423,13 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
             const uint32_t bw = gdrop::col_word(gdrop::col_key(seed, bh), (uint32_t)(ki >> 1));
             bsel = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
         }
-        for (int64_t q0 = 0; q0 < a.S; q0 += 64) {
+        for (int64_t q0 = lo; q0 < hi; q0 += 64) {
             __syncthreads();
             stage_store<4>(regs, lds);
             if (threadIdx.x < 64) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
             if constexpr (DROP) stage_row_words<64>(aw_s, rk, q0);
             __syncthreads();
-            if (q0 + 64 < a.S) {
+            if (q0 + 64 < hi) {
                 stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + 64, a.S);
                 if (threadIdx.x < 64) {
                     const int64_t qq = q0 + 64 + threadIdx.x;
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
             }
 #pragma unroll 1
             for (int t = 0; t < 2; ++t) {
-                if (q0 + 32 * t >= a.S) break;
+                if (q0 + 32 * t >= hi) break;
                 const char* qt = lds + t * TILE_BYTES;
                 const char* dt = lds + (2 + t) * TILE_BYTES;
                 // accumulators start at -lse[q] / -delta[q] (rows of this lane: 4 runs of 4 consecutive q)
@@ -481,8 +492,8 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         __syncthreads();
     }
     if (ki < a.S) {
-        float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
-        float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+        float* dkp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+        float* dvp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
         const float vsc = DROP ? a.drop.inv_keep : 1.f;
         const float ksc = vsc / LOG2E;  // Q image carries scale*log2e: dK = dS^T (Q*scale) = dS^T Qimg / log2e
 #pragma unroll
@@ -717,17 +728,18 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     }
 
     uint4 regs[2];
-    stage_load4(regs, kp, a.ld, vp, a.ld, 0, a.S);
-    for (int64_t k0 = 0; k0 < a.S; k0 += 64) {
+    const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
+    stage_load4(regs, kp, a.ld, vp, a.ld, lo, a.S);
+    for (int64_t k0 = lo; k0 < hi; k0 += 64) {
         __syncthreads();
         stage_store<4>(regs, lds);
         if constexpr (DROP) stage_col_words<2>(bw_s, ck, k0);
         __syncthreads();
-        if (k0 + 64 < a.S) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
+        if (k0 + 64 < hi) stage_load4(regs, kp, a.ld, vp, a.ld, k0 + 64, a.S);
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) {
             const int64_t kb = k0 + 32 * t;
-            if (kb >= a.S) break;
+            if (kb >= hi) break;
             const char* kt = lds + t * TILE_BYTES;
             const char* vt = lds + (2 + t) * TILE_BYTES;
             f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negl, 0, 0, 0);
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
         }
     }
     if (qi < a.S) {
-        float* dqp = a.dqkv + (rowbase + qi) * a.ld + head * D;
+        float* dqp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + qi) * a.ld + head * D;
         const float qsc = DROP ? a.scale * a.drop.inv_keep : a.scale;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -867,11 +879,69 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
     }
 }
 
+// combine the key-range parts of the forward: lse = log sum_p exp(lse_p), O = sum_p exp(lse_p - lse) O_p
+__global__ void k_attn_combine(const float* __restrict__ o_parts, const float* __restrict__ lse_parts, int P, int64_t o_part,
+                               int64_t lse_part, int B, int S, int H, float* __restrict__ o, float* __restrict__ lse) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (row, head, 4-column group)
+    const int64_t n = (int64_t)B * S * H * 8;
+    if (i >= n) return;
+    const int g = (int)(i & 7);
+    const int head = (int)((i >> 3) % H);
+    const int64_t row = (i >> 3) / H;
+    const int64_t li = ((row / S) * H + head) * S + (row % S);
+    float mx = -INFINITY;
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, lse_parts[p * lse_part + li]);
+    float den = 0.f;
+    for (int p = 0; p < P; ++p) den += __expf(lse_parts[p * lse_part + li] - mx);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t oi = row * (H * D) + head * D + 4 * g;
+    for (int p = 0; p < P; ++p) {
+        const float w = __expf(lse_parts[p * lse_part + li] - mx) / den;
+        const float4 v = *reinterpret_cast<const float4*>(o_parts + p * o_part + oi);
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+    *reinterpret_cast<float4*>(o + oi) = acc;
+    if (g == 0) lse[li] = mx + logf(den);
+}
+
+// out = sum_p parts[p]  (fixed order)
+__global__ void k_sum_parts(const float* __restrict__ parts, int P, int64_t part, int64_t n4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = reinterpret_cast<const float4*>(parts)[i];
+    for (int p = 1; p < P; ++p) {
+        const float4 v = reinterpret_cast<const float4*>(parts + p * part)[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+}
+
+// number of range parts for a launch whose unsplit grid has `wgs` workgroups: aim at eight workgroups per CU,
+// keep at least 1024 streamed rows per part
+int split_parts(int64_t wgs, int S) {
+    constexpr int tgt = 2048;   // measured at S = 16384 with 1 / 2 / 4 heads: 2048 workgroups beat 512 and 1024
+    if (wgs >= tgt) return 1;
+    int p = (int)std::min<int64_t>(8, ceil_div(tgt, wgs));
+    p = std::min(p, std::max(1, S / 1024));
+    return std::max(p, 1);
+}
+int split_chunk(int S, int P) { return (int)(ceil_div(ceil_div(S, P), 128) * 128); }
+
 }  // namespace
 
 // fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t image_only_bytes(int B, int S, int H, int HKV) { return align256(sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64); }
+
 extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
-    return sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64;
+    const int P = split_parts(ceil_div(S, 128) * H * B, S);
+    size_t parts = P > 1 ? (size_t)P * ((size_t)B * S * H * D + (size_t)B * H * S) * sizeof(float) : 0;
+    return image_only_bytes(B, S, H, HKV) + parts;
+}
+extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV) {
+    const int P = split_parts(ceil_div(S, 128) * H * B, S);
+    size_t parts = P > 1 ? (size_t)P * (size_t)B * S * (H + 2 * HKV) * D * sizeof(float) : 0;
+    return align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64) + parts;
 }
 
 extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse,
@@ -892,8 +962,15 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     const int64_t n = rows * (ld / 2);
     hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
-    FwdArgs a{(const bf16_t*)qkv_image, o, lse, ld, B, S, H, HKV, gdrop::make_drop(dropout_seed, dropout_p)};
-    const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
+    // few heads (head-parallel ranks): split the key range over blockIdx.y so that the launch still fills the chip;
+    // every part writes a normalised O / lse of its keys into the scratch behind the image, combined below
+    const int P = split_parts(ceil_div(S, 128) * H * B, S);
+    float* o_parts = reinterpret_cast<float*>(reinterpret_cast<char*>(qkv_image) + image_only_bytes(B, S, H, HKV));
+    const int64_t o_part = rows * H * D, lse_part = (int64_t)B * H * S;
+    float* lse_parts = o_parts + (size_t)P * o_part;
+    FwdArgs a{(const bf16_t*)qkv_image, P > 1 ? o_parts : o, P > 1 ? lse_parts : lse, ld, B, S, H, HKV,
+              gdrop::make_drop(dropout_seed, dropout_p), P > 1 ? split_chunk(S, P) : S, o_part, lse_part};
+    const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), (unsigned)(P > 1 ? ceil_div(S, a.chunk) : 1), (unsigned)B);
     // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
@@ -901,6 +978,9 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
         hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, true>), fgrid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
+    if (P > 1)
+        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)ceil_div(rows * H * 8, 256)), dim3(256), 0, st, o_parts, lse_parts,
+                           (int)fgrid.y, o_part, lse_part, B, S, H, o, lse);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -919,8 +999,17 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
-    BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, dqkv, ld, B, S, H, HKV, scale,
-              gdrop::make_drop(dropout_seed, dropout_p)};
+    // range split for small grids (see gaot_attn_fwd_bf16): part p of dK/dV covers queries, of dQ keys
+    // [p*chunk, (p+1)*chunk) and accumulates into its own copy of dqkv behind the dO image; summed after phase 4
+    const int P0 = split_parts(ceil_div(S, 128) * H * B, S);
+    const bool kb_dkv = (int64_t)ceil_div(S, 256) * HKV * B >= 512, kb_dq = (int64_t)ceil_div(S, 256) * H * B >= 512;
+    const int P = (kb_dkv || kb_dq) ? 1 : P0;
+    const int chunk = P > 1 ? split_chunk(S, P) : S;
+    const unsigned ny = (unsigned)(P > 1 ? ceil_div(S, chunk) : 1);
+    const int64_t dqkv_part = (int64_t)B * S * ld;
+    float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(do_image) + align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64));
+    BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, P > 1 ? parts : dqkv, ld, B, S, H, HKV, scale,
+              gdrop::make_drop(dropout_seed, dropout_p), chunk, dqkv_part};
     const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 1)
@@ -929,11 +1018,11 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 2) {
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups
-        const dim3 gkb((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * HKV), 1, (unsigned)B);
+        const dim3 gkb((unsigned)(ceil_div(S, 256) * HKV), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * HKV), ny, (unsigned)B);
         // one key block per wave: 2 workgroups per CU (256 registers) when the grid is small or the dropout words are
         // live (at 4 per CU the dropout variant spills: 0.83 -> 0.49 ms at S = 16384, H = 4)
-        const bool occ2 = drop || (int64_t)g1.x * B <= 512;
-        if ((int64_t)ceil_div(S, 256) * HKV * B >= 512) {
+        const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
+        if (kb_dkv) {
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
@@ -945,9 +1034,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         }
     }
     if (phase_mask & 4) {
-        const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), 1, (unsigned)B);
-        const bool occ2 = drop || (int64_t)g1.x * B <= 512;
-        if ((int64_t)ceil_div(S, 256) * H * B >= 512) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
+        const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), ny, (unsigned)B);
+        const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
+        if (kb_dq) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
@@ -957,6 +1046,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, true>), g1, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, false>), g1, dim3(256), 0, st, a);
         }
+        if (P > 1)   // dK/dV (phase 2) and dQ parts are complete: fixed-order sum into dqkv
+            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)ceil_div(dqkv_part / 4, 256)), dim3(256), 0, st, parts, (int)ny, dqkv_part,
+                               dqkv_part / 4, dqkv);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

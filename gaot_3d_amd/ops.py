@@ -366,7 +366,7 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: i
     dev = o.device
     dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
-    doimg = _ws(2 * b * s * h * 32 + 64, dev)
+    doimg = _ws(lib.gaot_attn_bwd_bf16_scratch_bytes(b, s, h, hkv), dev)
     for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),

@@ -156,8 +156,12 @@ int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
  * rope_freqs != NULL, q pre-scaled) into qkv_image (gaot_attn_bf16_image_bytes), which the backward re-uses;
  * backward writes the fp32 gradient w.r.t. the ROTATED q|k|v into dqkv (apply gaot_rope(inverse=1) after it).
- * do_image: scratch of B*S*H*32 bf16. */
+ * do_image: scratch of gaot_attn_bwd_bf16_scratch_bytes (bf16 dO image; for launches with few heads also the
+ * per-range partial gradients).  When (S/128)*H*B is below two workgroups per CU the streamed range (keys for forward
+ * and dQ, queries for dK/dV) is split over blockIdx.y and the parts are combined in a fixed order (forward: by their
+ * log-sum-exp; backward: summed at the end of phase 4, so phases 2 and 4 must both be issued). */
 size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
+size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
                        int H, int HKV, int head_dim, float scale, float dropout_p,
                        const unsigned long long* dropout_seed, gaot_stream_t stream);

@@ -150,7 +150,9 @@ def test_attention_bf16(b, s, h, hkv, rope):
     assert (g - gr).abs().max().item() <= 5e-2 * gr.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("b,s,h,hkv", [(1, 16384, 8, 8), (4, 4000, 8, 8), (2, 8200, 8, 4)])
+@pytest.mark.parametrize("b,s,h,hkv", [(1, 16384, 8, 8), (4, 4000, 8, 8), (2, 8200, 8, 4),
+                                       # few heads (what a head-parallel rank runs): range-split launches
+                                       (1, 16384, 1, 1), (1, 8200, 2, 2), (1, 16384, 2, 1), (1, 3000, 1, 1), (1, 16384, 4, 4)])
 def test_attention_bf16_large_grid(b, s, h, hkv):
     """Sizes at which the two-key-blocks-per-wave dK/dV kernel is dispatched (grid >= 2 workgroups per CU), full
     BASELINE sequence length included, ragged tails included.  The CPU oracle cannot hold S x S at this size, so the
