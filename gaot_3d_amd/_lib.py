@@ -47,6 +47,8 @@ SIGNATURES = {
     "gaot_geoembed_stats": (_i, [_p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "gaot_geoembed_moments": (_i, [_p, _p, _p, _p, _i64, _p, _p]),
     "gaot_geoembed_from_moments": (_i, [_p, _i64, _p, _p, _sz, _p]),
+    "gaot_geoembed_raw": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "gaot_geoembed_finalize": (_i, [_p, _i64, _p, _i64, _p, _sz, _p]),
     "gaot_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
     "gaot_gemm_ex": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p, _i, _p,

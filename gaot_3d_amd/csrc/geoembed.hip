@@ -207,6 +207,27 @@ __global__ void k_geo_colfinal(const double* __restrict__ part, int nparts, int6
     stats[NF + i] = sd;
 }
 
+// the same in two steps, for rows that are spread over several ranks: column sums of the local rows, then (after the
+// caller's SUM all-reduce) mean / std over all Q_total rows
+__global__ void k_geo_colsums(const double* __restrict__ part, int nparts, double* __restrict__ sums) {
+    const int i = threadIdx.x;
+    if (i >= 2 * NF) return;
+    double s = 0;
+    for (int p = 0; p < nparts; ++p) s += part[p * 2 * NF + i];
+    sums[i] = s;
+}
+__global__ void k_geo_stats_from_sums(const double* __restrict__ sums, int64_t Q, float* __restrict__ stats) {
+    const int i = threadIdx.x;
+    if (i >= NF) return;
+    const double mean = sums[i] / (double)Q;
+    double var = (Q > 1) ? (sums[NF + i] - (double)Q * mean * mean) / (double)(Q - 1) : NAN;
+    if (var < 0) var = 0;
+    float sd = (float)sqrt(var);
+    if (sd < 1e-6f) sd = 1.f;
+    stats[i] = (float)mean;
+    stats[NF + i] = sd;
+}
+
 __global__ void k_geo_normalize(float* __restrict__ feat, int64_t Q, const float* __restrict__ stats) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q * NF) return;
@@ -267,6 +288,49 @@ extern "C" int gaot_geoembed_from_moments(const double* moments, int64_t num_que
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
     hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
     hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);
+    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+                       num_queries, stats);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// Split form of gaot_geoembed_stats for queries that are spread over several ranks (decoder side of a point-sharded
+// sample: every rank owns all edges of ITS queries, only the column z-score runs over all queries):
+//   raw      : un-normalised features of the local queries + their column sums / sums of squares (18 doubles)
+//   finalize : z-score with the (all-reduced) sums over num_queries_total rows
+extern "C" int gaot_geoembed_raw(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
+                                 const int32_t* src_sorted, int64_t num_queries, float* features, double* colsums,
+                                 void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_queries >= 0, "negative size");
+    GAOT_CHECK_ARG(colsums && workspace, "null pointer");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    if (num_queries == 0) {
+        if (hipMemsetAsync(colsums, 0, sizeof(double) * 2 * NF, st) != hipSuccess) return GAOT_ERR_LAUNCH;
+        return GAOT_OK;
+    }
+    GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && features, "null pointer");
+    hipLaunchKernelGGL(k_geo_raw, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, st, source_pos, query_pos,
+                       rowptr_dst, src_sorted, num_queries, features);
+    const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
+    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    hipLaunchKernelGGL(k_geo_colsums, dim3(1), dim3(64), 0, st, part, nb, colsums);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_geoembed_finalize(float* features, int64_t num_queries, const double* colsums, int64_t num_queries_total,
+                                      void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_queries >= 0 && num_queries_total >= num_queries, "bad sizes");
+    if (num_queries == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(features && colsums && workspace, "null pointer");
+    GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* stats = (float*)((double*)workspace + 256 * 2 * NF);
+    hipLaunchKernelGGL(k_geo_stats_from_sums, dim3(1), dim3(64), 0, st, colsums, num_queries_total, stats);
     hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();

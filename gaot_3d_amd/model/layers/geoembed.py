@@ -34,16 +34,20 @@ class GeometricEmbedding(nn.Module):
 
     def forward(self, source_pos, query_pos, edge_index, batch_source: Optional[torch.Tensor] = None,
                 batch_query: Optional[torch.Tensor] = None, neighbors_counts: Optional[torch.Tensor] = None,
-                graph=None, shard_group=None):
+                graph=None, shard_group=None, sharded_queries_total: Optional[int] = None):
         """``shard_group`` (extension, gaot_3d_amd/sharding.py): the edges of this sample are spread over the ranks of
         the group; the per-row statistics are assembled from additive fp64 moments with one SUM all-reduce."""
         if graph is None:
             graph = graph_for(edge_index.to(query_pos.device), source_pos.shape[0], query_pos.shape[0])
         if self.method == "pointnet":
-            if shard_group is not None:
-                raise NotImplementedError("point-sharded PointNet GeoEmbed is not implemented")
-            return self._forward_pointnet(source_pos, query_pos, graph)
-        if shard_group is not None:
+            if shard_group is not None and sharded_queries_total is None:
+                raise NotImplementedError("point-sharded PointNet GeoEmbed on the encoder side (edges of a token spread "
+                                          "over the ranks) is not implemented")
+            return self._forward_pointnet(source_pos, query_pos, graph)   # decoder side: every query's edges are local
+        if shard_group is not None and sharded_queries_total is not None:
+            # decoder side of a point-sharded sample: the query rows are spread over the ranks, only the z-score is global
+            feats = ops.geoembed_stats_sharded_queries(source_pos, query_pos, graph, shard_group, sharded_queries_total)
+        elif shard_group is not None:
             import torch.distributed as dist
             mom = ops.geoembed_moments(source_pos, query_pos, graph)
             dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group)

@@ -344,11 +344,13 @@ class MAGNODecoder(nn.Module):
                           batch if self.sampling_strategy is None else None, ("dec", si))
             dec = self.gno(y_pos=latent_tokens_pos, x_pos=phys_pos_query, edge_index=edge_index, f_y=rndata_flat, graph=g)
             if self.use_geoembed:
-                if getattr(self, "_shard_group", None) is not None:
-                    raise NotImplementedError("decoder GeoEmbed under point sharding: its z-score runs over ALL query points "
-                                              "(geoembed.py:168-175); the sharded step supports use_geoembed=[*, False] "
-                                              "(the reference's drivaernet config)")
-                geo = self.geoembed(latent_tokens_pos, phys_pos_query, edge_index, graph=g)
+                sg = getattr(self, "_shard_group", None)
+                if sg is not None:   # point-sharded sample: the z-score (geoembed.py:177-180) runs over ALL query points
+                    total = getattr(batch, "shard", (0, 0, 0, 0, phys_pos_query.shape[0]))[4]
+                    geo = self.geoembed(latent_tokens_pos, phys_pos_query, edge_index, graph=g, shard_group=sg,
+                                        sharded_queries_total=total)
+                else:
+                    geo = self.geoembed(latent_tokens_pos, phys_pos_query, edge_index, graph=g)
                 dec = GF.cat_linear([dec, geo], self.recovery.fcs[0].weight, self.recovery.fcs[0].bias, precision=0)
             outs.append(dec)
         return self.projection(_mix_scales(self, outs, phys_pos_query))

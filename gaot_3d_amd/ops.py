@@ -449,6 +449,27 @@ def geoembed_stats(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> 
     return feat
 
 
+def geoembed_stats_sharded_queries(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph, group, num_queries_total: int) -> Tensor:
+    """statistical features when the QUERY rows are spread over the ranks of ``group`` (each rank holds all edges of its
+    queries): local raw features, one fp64 SUM all-reduce of the 18 column sums, z-score over all rows"""
+    import torch.distributed as dist
+    lib = _lib.load()
+    source_pos = _req(source_pos, torch.float32, "source_pos")
+    query_pos = _req(query_pos, torch.float32, "query_pos")
+    if source_pos.shape[1] != 3:
+        raise GaotError("geoembed statistical features: coord_dim must be 3 on the HIP path")
+    q = g.num_dst
+    feat = torch.empty(q, 9, dtype=torch.float32, device=query_pos.device)
+    sums = torch.empty(18, dtype=torch.float64, device=query_pos.device)
+    ws = _ws(lib.gaot_geoembed_stats_workspace_bytes(), query_pos.device)
+    check(lib.gaot_geoembed_raw(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), q, _ptr(feat),
+                                _ptr(sums), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_raw")
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    check(lib.gaot_geoembed_finalize(_ptr(feat), q, _ptr(sums), int(num_queries_total), _ptr(ws), ws.numel(), _stream()),
+          "gaot_geoembed_finalize")
+    return feat
+
+
 def geoembed_moments(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> Tensor:
     """fp64 [Q, 12] additive moments of every query row's neighbourhood (include/gaot3d_hip.h: gaot_geoembed_moments)"""
     lib = _lib.load()

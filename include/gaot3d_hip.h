@@ -104,6 +104,15 @@ int gaot_geoembed_moments(const float* source_pos, const float* query_pos, const
                           const int32_t* src_sorted, int64_t num_queries, double* moments, gaot_stream_t stream);
 int gaot_geoembed_from_moments(const double* moments, int64_t num_queries, float* features, void* workspace,
                                size_t workspace_bytes, gaot_stream_t stream);
+/* the same features when the QUERIES are spread over several ranks (decoder side of a point-sharded sample: a rank
+ * owns every edge of its queries, only the column z-score of geoembed.py:177-180 runs over all queries):
+ * raw = un-normalised local features + their 18 column sums / sums of squares (fp64); after the caller's SUM
+ * all-reduce of colsums, finalize applies the z-score over num_queries_total rows. */
+int gaot_geoembed_raw(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst, const int32_t* src_sorted,
+                      int64_t num_queries, float* features, double* colsums, void* workspace, size_t workspace_bytes,
+                      gaot_stream_t stream);
+int gaot_geoembed_finalize(float* features, int64_t num_queries, const double* colsums, int64_t num_queries_total,
+                           void* workspace, size_t workspace_bytes, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM  C[m][n] = act(sum_k A(m,k) B(k,n) + bias[n]) + residual[m][n]   (row-major, fp32 I/O)

@@ -208,13 +208,15 @@ dist.destroy_process_group()
 """
 
 
-def small_config():
+def small_config(dec_geo=None):
+    if dec_geo is None:
+        dec_geo = os.environ.get("GAOT_TEST_DEC_GEO", "0") == "1"
     from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
     from gaot_3d_amd.model.layers.magno import MAGNOConfig
     return types.SimpleNamespace(
         magno=MAGNOConfig(use_gno=True, gno_coord_dim=3, neighbor_strategy="knn", k_neighbors=4, projection_channels=64,
                           in_gno_channel_mlp_hidden_layers=[64, 64], out_gno_channel_mlp_hidden_layers=[64, 64],
-                          lifting_channels=32, gno_radius=0.1, use_geoembed=[True, False], embedding_method="statistical",
+                          lifting_channels=32, gno_radius=0.1, use_geoembed=[True, bool(dec_geo)], embedding_method="statistical",
                           encoder_feature_attr=["pos", "c"], mlp_type="linear", precompute_edges=True),
         transformer=TransformerConfig(patch_size=2, hidden_size=64, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
                                       num_layers=2, positional_embedding="rope", use_long_range_skip=True,
@@ -224,9 +226,12 @@ def small_config():
         latent_tokens=(8, 8, 4))
 
 
-def test_point_shard_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("dec_geo", [False, True])
+def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo):
     """The N>1 path end to end on the real kernels: two processes (both on cuda:0, gloo) each take half of the points
-    of one sample; loss and every parameter gradient must equal the unsharded step on the same model and sample."""
+    of one sample; loss and every parameter gradient must equal the unsharded step on the same model and sample.
+    Head-parallel attention is on (one of the two heads per rank); dec_geo adds the decoder-side GeoEmbed, whose
+    z-score runs over the points of both ranks."""
     import json, subprocess
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
@@ -234,7 +239,7 @@ def test_point_shard_two_ranks_one_gpu(tmp_path):
     from gaot_3d_amd.model import init_model
     gaot_3d_amd.set_precision("fp32")
     torch.manual_seed(0)
-    model = init_model(6, 1, "gaot_3d", small_config()).to(DEV).train()
+    model = init_model(6, 1, "gaot_3d", small_config(dec_geo)).to(DEV).train()
     batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device=str(DEV))
     pred = model(batch=batch, tokens_pos=tokens.to(DEV))
     loss = GF.mse_loss(pred, batch.x)
@@ -243,9 +248,9 @@ def test_point_shard_two_ranks_one_gpu(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     out = tmp_path / "out.json"
-    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", GAOT_TEST_DEC_GEO="1" if dec_geo else "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
+                        "127.0.0.1", "--master-port", "29534" if dec_geo else "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))
     loss = loss.detach()
