@@ -296,6 +296,30 @@ def attn_dropout_case():
     save("attn_dropout", dict(name="attn_dropout", b=b, s=s, d=d, h=h, hkv=hkv, p=p), arrays)
 
 
+def lr_schedule_case():
+    """the trainer's 'mix' learning-rate schedule (src/trainer/optimizers.py:40-67, 226-246): per-epoch values of the
+    reference's own CustomLRScheduler driven through AdamWOptimizer's phase split, for a few epoch counts"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_optimizers", os.path.join(REF, "src", "trainer", "optimizers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    except Exception as ex:   # relative imports of the trainer package: fall back to the class source only
+        raise RuntimeError(f"cannot import the reference scheduler: {ex}")
+    arrays, cases = {}, []
+    for total in (1, 2, 7, 50, 100, 333):
+        cfg = mod.OptimizerargsConfig(epoch=total, lr=3e-4, scheduler="mix", max_lr=1e-2, min_lr=1e-5, final_lr=2e-6)
+        opt = mod.AdamWOptimizer([torch.nn.Parameter(torch.zeros(1))], cfg)
+        lrs = []
+        for _ in range(total + 2):
+            lrs.append(opt.optimizer.param_groups[0]["lr"])
+            opt.optimizer.step()
+            opt.scheduler.step()
+        arrays[f"out/lr_{total}"] = np.asarray(lrs, dtype=np.float64)
+        cases.append(total)
+    save("lr_mix", dict(name="lr_mix", totals=cases, lr=3e-4, max_lr=1e-2, min_lr=1e-5, final_lr=2e-6), arrays)
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not present: goldens can only be regenerated in the authoring container"
     install_stubs()
@@ -304,8 +328,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "attn_dropout":   # regenerate just this file
         attn_dropout_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "lr_mix":
+        lr_schedule_case()
+        return
     ops_case()
     attn_dropout_case()
+    lr_schedule_case()
     model_case("model_knn_abs", seed=1, n_per_graph=[200], latent_tokens=(4, 4, 4),
                magno_kw=dict(use_geoembed=[True, False], mlp_type="linear", neighbor_strategy="knn", k_neighbors=4),
                tr_kw=dict(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="absolute"),

@@ -218,3 +218,56 @@ def test_neighbor_sampling(strategy):
     other = apply_neighbor_sampling(ei, nq, DEV, strategy, seed=torch.tensor([99], dtype=torch.int64, device=DEV), **kw)
     assert other.shape != out.shape or not torch.equal(other, out)
     assert apply_neighbor_sampling(ei, nq, DEV, None) is ei
+
+
+def test_neural_field_training_step():
+    """the reference's neural-field strategy (stat.py:520-541): a random subset of the points is the encoder input,
+    another subset the decoder queries (query_coord_pos / query_coord_batch_idx), graphs built inside forward
+    (precompute_edges = False -> device kernels).  Loss and every gradient equal the oracle's step on edge lists built
+    by the brute-force restatement for the same subsets."""
+    import copy
+    import types
+
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from gaot_3d_amd.model.layers.magno import MAGNOConfig, get_neighbor_strategy
+    from gaot_3d_amd.schedule import sample_nodes_neural_field
+    gaot_3d_amd.set_precision("fp32")
+    cfg = types.SimpleNamespace(
+        magno=MAGNOConfig(gno_coord_dim=3, lifting_channels=32, encoder_feature_attr=["pos", "c"], mlp_type="linear",
+                          use_geoembed=[True, False], neighbor_strategy="knn", k_neighbors=4, precompute_edges=False),
+        transformer=TransformerConfig(patch_size=2, hidden_size=256, num_layers=2, positional_embedding="rope",
+                                      attn_config=AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8,
+                                                                  atten_dropout=0.0),
+                                      ffn_config=FFNConfig(hidden_size=1024)),
+        latent_tokens=(8, 8, 4))
+    torch.manual_seed(0)
+    model = init_model(6, 1, "gaot_3d", cfg)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch, tokens = make_synthetic_sample(5000, cfg.latent_tokens, k=4, seed=3)
+    sb, qpos, qb, target = sample_nodes_neural_field(batch, 1500, 2200, generator=torch.Generator().manual_seed(4))
+    assert sb.pos.shape[0] == 1500 and qpos.shape[0] == 2200
+    # oracle: same subsets, edges from the brute-force helpers (CPU tensors)
+    ob = copy.copy(sb)
+    zb, zl = torch.zeros(1500, dtype=torch.long), torch.zeros(tokens.shape[0], dtype=torch.long)
+    ob.encoder_edge_index_s0 = get_neighbor_strategy("knn", sb.pos, zb, tokens, zl, 0.1, 4, False)
+    ob.decoder_edge_index_s0 = get_neighbor_strategy("knn", qpos, torch.zeros(2200, dtype=torch.long), tokens, zl, 0.1, 4, True)
+    ocfg = copy.deepcopy(cfg)
+    ocfg.magno.precompute_edges = True
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k != "latent_tokens" and not k.endswith("freqs") else v)
+            for k, v in sd.items()}
+    pred_r = orc.gaot3d_forward(leaf, ocfg, ob, tokens, query_coord_pos=qpos)
+    loss_r = orc.mse_loss(pred_r, target)
+    loss_r.backward()
+    model = model.to(DEV).train()
+    pred = model(batch=sb.to(DEV), tokens_pos=tokens.to(DEV), query_coord_pos=qpos.to(DEV), query_coord_batch_idx=qb.to(DEV))
+    loss = GF.mse_loss(pred, target.to(DEV))
+    loss.backward()
+    assert torch.allclose(pred.cpu(), pred_r.detach(), rtol=1e-4, atol=2e-5), (pred.cpu() - pred_r).abs().max().item()
+    assert torch.allclose(loss.detach().cpu(), loss_r.detach(), rtol=1e-5, atol=1e-7)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p.grad.cpu(), leaf[k].grad, rtol=1e-3, atol=1e-5), (k, (p.grad.cpu() - leaf[k].grad).abs().max().item())

@@ -176,3 +176,37 @@ def test_colocate_keeps_parameters_and_values():
     # neighbours in memory that are NOT slices of one buffer must not be taken for one matrix
     a, b = torch.zeros(4, 4), torch.zeros(4, 4)
     assert not GF._adjacent([a, b])
+
+
+def test_mix_lr_schedule_matches_reference_golden():
+    """gaot_3d_amd.schedule.MixLRScheduler against the per-epoch learning rates of the reference's CustomLRScheduler +
+    AdamWOptimizer phase split (golden lr_mix.npz, oracle/make_goldens.py: lr_schedule_case)"""
+    from gaot_3d_amd.schedule import MixLRScheduler
+    meta, g = gio.load("lr_mix")
+    for total in meta["totals"]:
+        want = g["out"][f"lr_{total}"].double()
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=meta["lr"])
+        sch = MixLRScheduler(opt, total, meta["lr"], meta["max_lr"], meta["min_lr"], meta["final_lr"])
+        got = []
+        for _ in range(total + 2):
+            got.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        assert torch.allclose(torch.tensor(got, dtype=torch.float64), want, rtol=1e-12, atol=0), total
+
+
+def test_neural_field_sampling_shapes_and_semantics():
+    from gaot_3d_amd.data import MeshBatch
+    from gaot_3d_amd.schedule import sample_nodes_neural_field
+    g = torch.Generator().manual_seed(0)
+    s1 = MeshBatch(pos=torch.rand(50, 3, generator=g), x=torch.arange(50.0)[:, None], c=torch.rand(50, 2, generator=g))
+    s2 = MeshBatch(pos=torch.rand(20, 3, generator=g), x=100 + torch.arange(20.0)[:, None], c=torch.rand(20, 2, generator=g))
+    b = MeshBatch.from_data_list([s1, s2], num_latent_nodes=8)
+    sb, qp, qb, tgt = sample_nodes_neural_field(b, 30, 30, generator=torch.Generator().manual_seed(1))
+    assert sb.pos.shape == (50, 3) and sb.num_graphs == 2                 # 30 of 50, all 20 of 20
+    assert torch.equal(sb.batch, torch.tensor([0] * 30 + [1] * 20)) and torch.equal(sb.ptr, torch.tensor([0, 30, 50]))
+    assert torch.equal(qp, sb.pos) and torch.equal(tgt, sb.x)             # same counts -> same subset
+    assert len(set(sb.x[:30, 0].tolist())) == 30 and sb.x[:30].max() < 50 and sb.x[30:].min() >= 100
+    sb, qp, qb, tgt = sample_nodes_neural_field(b, 10, 25, generator=torch.Generator().manual_seed(2))
+    assert sb.pos.shape[0] == 20 and qp.shape[0] == 45 and torch.equal(qb, torch.tensor([0] * 25 + [1] * 20))
+    assert tgt.shape == (45, 1) and tgt[:25].max() < 50 and tgt[25:].min() >= 100
