@@ -210,6 +210,10 @@ class AttentionFn(Function):
                                  qkv[:, (h + hkv + grk * kl) * 32:(h + hkv + (grk + 1) * kl) * 32]], dim=1)
                 h, hkv = hl, kl
         seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
+        if seed is not None and ctx.hp is not None:
+            # the kernels key a head's mask by its LOCAL index: give every rank its own seed word so that the heads
+            # of different ranks do not share masks
+            seed = seed + ctx.hp[2] * 0x632BE59BD9B4E019 % (1 << 63)
         if bf16:
             o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed)
             keep = img
