@@ -92,20 +92,22 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
         dw_part[(int64_t)blockIdx.x * d + i] = sm[i] + sm[d + i] + sm[2 * d + i] + sm[3 * d + i];
 }
 
-// out[n] = sum_{p<parts} part[p][n]; 32 columns x 8 part-lanes per block, fixed summation order
+// out[n] = sum_{p<parts} part[p][n]; 8 columns x 32 part-lanes per block (the partial tables are a few hundred rows of a
+// few hundred columns: many short blocks instead of 8 long serial ones -- 13 -> 4 us), fixed summation order
+constexpr int RP_COLS = 8, RP_LANES = 32;
 __global__ void k_reduce_parts(const float* __restrict__ part, int64_t parts, int64_t n, float* __restrict__ out) {
-    __shared__ float sm[8][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + cx;
+    __shared__ float sm[RP_LANES][RP_COLS + 1];
+    const int cx = threadIdx.x % RP_COLS, ry = threadIdx.x / RP_COLS;
+    const int64_t i = (int64_t)blockIdx.x * RP_COLS + cx;
     float s = 0.f;
     if (i < n)
-        for (int64_t p = ry; p < parts; p += 8) s += part[p * n + i];
+        for (int64_t p = ry; p < parts; p += RP_LANES) s += part[p * n + i];
     sm[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && i < n) {
         float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t += sm[j][cx];
+        for (int j = 0; j < RP_LANES; ++j) t += sm[j][cx];
         out[i] = t;
     }
 }
@@ -426,7 +428,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
                        dx, part, rows, dim);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim, 32)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -453,7 +455,7 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
                        rpc, part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N, 32)), dim3(256), 0, st, part, chunks, N, out);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
