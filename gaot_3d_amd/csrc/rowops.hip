@@ -135,6 +135,30 @@ __global__ void k_colsum_part(const float* __restrict__ x, int64_t M, int64_t N,
     }
 }
 
+// the same with 16-byte loads: 32 float4 column groups x 8 row lanes per block (N, ld multiples of 4, 16-byte aligned x)
+__global__ void k_colsum_part4(const float* __restrict__ x, int64_t M, int64_t N, int64_t ld, int64_t rows_per_chunk,
+                               float* __restrict__ part) {
+    __shared__ float4 sm[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int64_t n = ((int64_t)blockIdx.x * 32 + cx) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = (r0 + rows_per_chunk < M) ? r0 + rows_per_chunk : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N)
+        for (int64_t r = r0 + ry; r < r1; r += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ld + n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    sm[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t.x += sm[j][cx].x; t.y += sm[j][cx].y; t.z += sm[j][cx].z; t.w += sm[j][cx].w; }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + n) = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // RoPE, in place: rows of width ld; nheads heads of 32 starting at column col0.  pos = row % S.
 // ---------------------------------------------------------------------------------------------
@@ -434,7 +458,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
 }
 
 extern "C" size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N) {
-    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 256)));
+    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 64)));
     return sizeof(float) * (size_t)(chunks * N) + 64;
 }
 
@@ -450,11 +474,15 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
         return GAOT_OK;
     }
     GAOT_CHECK_ARG(x && workspace && workspace_bytes >= gaot_colsum_workspace_bytes(M, N), "workspace too small");
-    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 256)));
+    const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 64)));
     const int64_t rpc = ceil_div(M, chunks);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
-                       rpc, part);
+    if (N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(k_colsum_part4, dim3((unsigned)ceil_div(N, 128), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
+                           rpc, part);
+    else
+        hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
+                           rpc, part);
     hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
