@@ -1,0 +1,134 @@
+"""On-disk samples of the reference's data layer without torch_geometric.
+
+The reference stores one ``torch_geometric.data.Data`` / ``EnrichedData`` per ``<name>.pt`` (src/data/pyg_datasets.py:
+125-137, written by src/trainer/stat.py:163-214) with ``pos [N,3]``, ``x [N,out]``, optional ``c``, ``filename``,
+``num_latent_nodes`` and -- when the edges are precomputed -- ``encoder_edge_index_s{i}`` / ``decoder_edge_index_s{i}``
+(int32 ``[2,E]``) and ``{encoder,decoder}_query_counts_s{i}`` (int32).  PyG is a third-party dependency that is absent
+here ("third-party, unpinned": no sample file or fixture of the reference is available to pin the pickle layout), so the
+reader makes no assumption beyond "every torch_geometric class is an attribute bag": classes of ``torch_geometric.*`` and
+the reference's own ``EnrichedData`` are unpickled as inert stand-ins and the tensors / scalars are collected from the
+object's storage mapping.  ``enrich_sample`` is the device version of the trainer's edge pre-computation pass."""
+from __future__ import annotations
+
+import pickle
+from typing import Any, Dict, Optional, Sequence
+
+import torch
+
+from .data import MeshBatch, rescale
+
+Tensor = torch.Tensor
+
+
+class _Bag:
+    """inert stand-in for any torch_geometric / reference data class met in a pickle"""
+
+    def __init__(self, *args, **kwargs):
+        self._args, self._kwargs = args, kwargs
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple):      # (dict, slots-dict)
+            for part in state:
+                if isinstance(part, dict):
+                    self.__dict__.update(part)
+        else:
+            self.__dict__["_state"] = state
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module: str, name: str):
+        if module.split(".")[0] == "torch_geometric" or name in ("EnrichedData",):
+            return type(name, (_Bag,), {"__module__": module})
+        return super().find_class(module, name)
+
+
+class _PickleModule:
+    """what torch.load expects of ``pickle_module``"""
+    __name__ = "gaot_3d_amd.io"
+    Unpickler = _Unpickler
+    load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump = staticmethod(pickle.dump)
+    dumps = staticmethod(pickle.dumps)
+    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+    PickleError, UnpicklingError, PicklingError = pickle.PickleError, pickle.UnpicklingError, pickle.PicklingError
+
+
+def _collect(obj: Any, out: Dict[str, Any], depth: int = 0) -> None:
+    """tensors and plain values reachable through the attribute bags' dicts (Data -> _store -> _mapping)"""
+    if depth > 4:
+        return
+    items = obj.items() if isinstance(obj, dict) else (obj.__dict__.items() if isinstance(obj, _Bag) else ())
+    for k, v in items:
+        if isinstance(v, (_Bag, dict)) and (k.startswith("_") or isinstance(v, _Bag)):
+            if k != "_parent":
+                _collect(v, out, depth + 1)
+        elif isinstance(k, str) and not k.startswith("_") and k not in out:
+            if torch.is_tensor(v) or isinstance(v, (int, float, str, list, tuple)):
+                out[k] = v
+
+
+def load_sample(path: str, active_variables: Optional[Sequence[int]] = None, map_location="cpu") -> MeshBatch:
+    """one reference ``.pt`` sample as a single-graph MeshBatch (dataset ``get``: pyg_datasets.py:125-137, including
+    the ``active_variables`` column selection and the squeeze of a trailing singleton axis of ``x``)"""
+    obj = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_PickleModule)
+    fields: Dict[str, Any] = {}
+    if isinstance(obj, MeshBatch):
+        fields = dict(obj.__dict__)
+    elif isinstance(obj, dict):
+        fields = {k: v for k, v in obj.items() if isinstance(k, str)}
+    else:
+        _collect(obj, fields)
+    if "pos" not in fields:
+        raise ValueError(f"{path}: no 'pos' attribute found")
+    x = fields.get("x")
+    if torch.is_tensor(x):
+        if active_variables is not None:
+            x = x[:, list(active_variables)]
+        if x.dim() == 3:
+            x = x.squeeze(-1)
+        fields["x"] = x
+    b = MeshBatch(**fields)
+    n = b.pos.shape[0]
+    b.num_graphs = 1
+    b.batch = torch.zeros(n, dtype=torch.long, device=b.pos.device)
+    b.ptr = torch.tensor([0, n], dtype=torch.long, device=b.pos.device)
+    return b
+
+
+def save_sample(sample: MeshBatch, path: str) -> None:
+    """plain-dict form of a sample (tensors on the CPU); ``load_sample`` reads it back"""
+    d = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sample.__dict__.items()
+         if not k.startswith("_") and k not in ("batch", "ptr", "num_graphs")}
+    torch.save(d, path)
+
+
+def enrich_sample(sample: MeshBatch, latent_tokens_pos: Tensor, gno_config, latent_dims=None, device=None,
+                  rescale_pos: bool = True) -> MeshBatch:
+    """the trainer's pre-computation pass (stat.py:163-214): rescale the coordinates to [-1, 1], build the encoder /
+    decoder edge lists of every scale with ``get_neighbor_strategy`` -- on ``device`` through the graph kernels when the
+    tokens are a regular grid (``latent_dims``) -- and store them as int32 together with the per-query counts and
+    ``num_latent_nodes``.  Returns a new sample on the CPU (what the reference writes back to the .pt file)."""
+    from .model.layers.magno import get_neighbor_strategy, parse_neighbor_strategy
+    dev = torch.device(device) if device is not None else sample.pos.device
+    out = MeshBatch(**{k: v for k, v in sample.__dict__.items() if not k.startswith("_")})
+    pos = sample.pos.to(torch.float32)
+    pos = rescale(pos, (-1, 1)) if rescale_pos else pos
+    lat = latent_tokens_pos.to(dev, torch.float32)
+    p = pos.to(dev)
+    n, m = p.shape[0], lat.shape[0]
+    bp = torch.zeros(n, dtype=torch.long, device=dev)
+    bl = torch.zeros(m, dtype=torch.long, device=dev)
+    enc_s, dec_s = parse_neighbor_strategy(gno_config.neighbor_strategy)
+    for si, scale in enumerate(gno_config.scales):
+        r = gno_config.gno_radius * scale
+        for name, strat, is_dec, nq in (("encoder", enc_s, False, m), ("decoder", dec_s, True, n)):
+            ei = get_neighbor_strategy(strat, p, bp, lat, bl, r, gno_config.k_neighbors, is_dec, latent_dims=latent_dims)
+            ei = ei.to(torch.int32)
+            cnt = torch.bincount(ei[1].long(), minlength=nq).to(torch.int32) if ei.numel() else torch.zeros(nq, dtype=torch.int32, device=dev)
+            setattr(out, f"{name}_edge_index_s{si}", ei.cpu())
+            setattr(out, f"{name}_query_counts_s{si}", cnt.cpu())
+    out.num_latent_nodes = m
+    return out

@@ -210,3 +210,51 @@ def test_neural_field_sampling_shapes_and_semantics():
     sb, qp, qb, tgt = sample_nodes_neural_field(b, 10, 25, generator=torch.Generator().manual_seed(2))
     assert sb.pos.shape[0] == 20 and qp.shape[0] == 45 and torch.equal(qb, torch.tensor([0] * 25 + [1] * 20))
     assert tgt.shape == (45, 1) and tgt[:25].max() < 50 and tgt[25:].min() >= 100
+
+
+def test_sample_reader_without_pyg(tmp_path):
+    """gaot_3d_amd.io.load_sample on a pickle shaped like torch_geometric's Data (attribute bags: Data -> _store ->
+    _mapping), written through stand-in modules that are removed again before reading -- the reader must not need
+    torch_geometric -- plus the plain-dict round trip and the CPU path of the edge pre-computation pass"""
+    import sys
+    import types as _t
+    from gaot_3d_amd import io as gio2
+    from gaot_3d_amd.data import latent_grid
+    mods = {}
+    for name in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage"):
+        mods[name] = _t.ModuleType(name)
+    GlobalStorage = type("GlobalStorage", (), {"__module__": "torch_geometric.data.storage"})
+    Data = type("Data", (), {"__module__": "torch_geometric.data.data"})
+    mods["torch_geometric.data.storage"].GlobalStorage = GlobalStorage
+    mods["torch_geometric.data.data"].Data = Data
+    sys.modules.update(mods)
+    try:
+        g = torch.Generator().manual_seed(0)
+        st = GlobalStorage()
+        d = Data()
+        st._mapping = {"pos": torch.rand(40, 3, generator=g), "x": torch.rand(40, 3, 1, generator=g), "c": torch.rand(40, 2, generator=g),
+                       "filename": "run_7", "num_latent_nodes": 27,
+                       "encoder_edge_index_s0": torch.randint(0, 27, (2, 90), generator=g).to(torch.int32)}
+        st._parent = d
+        d._store = st
+        d._edge_attr_cls, d._tensor_attr_cls = None, None
+        path = tmp_path / "run_7.pt"
+        torch.save(d, path)
+    finally:
+        for name in mods:
+            sys.modules.pop(name, None)
+    assert "torch_geometric" not in sys.modules
+    s = gio2.load_sample(str(path), active_variables=[0, 2])
+    assert s.pos.shape == (40, 3) and s.x.shape == (40, 2) and s.c.shape == (40, 2)
+    assert s.filename == "run_7" and s.num_latent_nodes == 27 and s.encoder_edge_index_s0.dtype == torch.int32
+    assert torch.equal(s.x, st._mapping["x"][:, [0, 2], 0]) and torch.equal(s.ptr, torch.tensor([0, 40]))
+    p2 = tmp_path / "plain.pt"
+    gio2.save_sample(s, str(p2))
+    s2 = gio2.load_sample(str(p2))
+    assert torch.equal(s2.pos, s.pos) and torch.equal(s2.encoder_edge_index_s0, s.encoder_edge_index_s0)
+    cfg = types.SimpleNamespace(neighbor_strategy=["knn", "knn"], scales=[1.0], gno_radius=0.3, k_neighbors=2)
+    e = gio2.enrich_sample(s, latent_grid((3, 3, 3)), cfg)
+    assert e.num_latent_nodes == 27 and e.encoder_edge_index_s0.dtype == torch.int32 and e.encoder_edge_index_s0.shape == (2, 80)
+    assert e.decoder_edge_index_s0.shape == (2, 80) and int(e.decoder_query_counts_s0.sum()) == 80
+    assert torch.equal(e.encoder_query_counts_s0.long(), torch.bincount(e.encoder_edge_index_s0[1].long(), minlength=27))
+    assert float(e.pos.min()) == float(s.pos.min())          # coordinates stay as stored; edges use the rescaled copy
