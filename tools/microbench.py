@@ -58,6 +58,8 @@ elif what == "gemm":
         timeit(lambda: ops.gemm(x, wb, m, n, k, k, k, False, True), f"fwd  (bf16 W)", fl)
         timeit(lambda: ops.gemm(dy, wb, m, k, n, n, k, False, False), f"dx   (bf16 W)", fl)
         timeit(lambda: ops.gemm(x, wb, m, n, k, k, k, False, True, out_dtype=torch.bfloat16), f"fwd  (bf16 W, bf16 C)", fl)
+        xb = x.bfloat16()
+        timeit(lambda: ops.gemm(xb, wb, m, n, k, k, k, False, True), f"fwd  (bf16 x, bf16 W)", fl)
         mb = (m * k + m * n + n * k) * 4 / 1e6
         print(f"     (operand + result bytes {mb:.0f} MB -> {mb / 5e3 * 1e3:.1f} us at 5 TB/s)")
 elif what == "graph":
