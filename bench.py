@@ -110,6 +110,9 @@ def main():
                     help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
                          "attn.py:22; no shipped config overrides it)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra dropout-free timing at N=1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = every GPU owns --points points of one N x --points sample (default); strong = one "
+                         "--points sample split over the N GPUs (BASELINE configs[2])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +151,7 @@ def main():
     # Weak scaling (the path shards by mesh points): every GPU owns --points points of ONE sample of
     # world x --points points (N = 1: configs[1], 500 K points; N = 8: a 4 M-point sample, between configs[1] and the
     # 8-10 M-point configs[4]); latent grid, Transformer and parameters are replicated, as the north star prescribes.
-    n_total = args.points * world
+    n_total = args.points * world if args.scaling == "weak" else args.points
     batch, tokens = make_synthetic_sample(n_total, latent, k=args.knn, seed=args.seed, device=str(dev))
     tokens = tokens.to(dev)
     if world > 1:
@@ -292,16 +295,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if world == 1 else 'configs[1] x ' + str(world) + ' points'}: one {n_total}-point car-like surface sample (pos+normals), latent "
+            "config": {"workload": f"{'configs[1]' if world == 1 else ('configs[1] x ' + str(world) + ' points' if args.scaling == 'weak' else 'configs[2] (one sample split over ' + str(world) + ' GPUs)')}: one {n_total}-point car-like surface sample (pos+normals), latent "
                                    f"{latent[0]}x{latent[1]}x{latent[2]}, knn k={args.knn} encoder + flipped decoder, "
                                    f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, attention dropout {args.atten_dropout} "
                                    f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step",
                        "points": n_total, "latent_tokens": list(latent), "edges": e, "layers": args.layers,
-                       "precision": args.precision, "points_per_gpu": args.points, "atten_dropout": args.atten_dropout,
+                       "precision": args.precision, "points_per_gpu": n_total // world, "atten_dropout": args.atten_dropout,
                        "sharding": f"point-shard x{world}; latent grid / Transformer replicated, attention heads split over the "
                                    f"ranks (all-gather of head outputs)" if world > 1 else "none"},
             "loss": float(loss.detach()),
