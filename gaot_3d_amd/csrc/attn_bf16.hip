@@ -975,7 +975,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
     if (a.drop.thr)
-        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, true>), fgrid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);   // 128-key stages: -2 % with the mask work
     else
         hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
     if (P > 1)
