@@ -272,7 +272,7 @@ def test_configs3_radius_encoder_bidirectional_decoder_geoembed_both_sides(sampl
     print(f"[parity] configs[3]-shaped step: loss fp32={l32:.6f} bf16={l16:.6f} (other seed {l16c:.6f})")
     assert torch.isfinite(g32).all() and torch.isfinite(g16).all()
     assert l16 == l16b and torch.equal(g16, g16b)
-    assert l16 != l16c
+    assert not torch.equal(g16, g16c)          # another seed, other masks (the loss itself may agree to the last bit)
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
     cos = float(g16 @ g32 / (g16.norm() * g32.norm()))
     print(f"[parity] configs[3]-shaped gradient cosine bf16 vs fp32: {cos:.6f}")
