@@ -267,3 +267,66 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo):
         assert torch.allclose(head, ref.flatten()[:64], rtol=1e-3, atol=1e-5 * max(1.0, float(ref.abs().max()))), k
         n += 1
     assert n > 20
+
+
+_DDP_WORKER = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["GAOT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GAOT_ROOT"], "tests"))
+import gaot_3d_amd
+from gaot_3d_amd import functional as GF
+from gaot_3d_amd.data import make_synthetic_sample
+from gaot_3d_amd.model import init_model
+from torch.nn.parallel import DistributedDataParallel as DDP
+import test_model_gpu as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://")
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = init_model(6, 1, "gaot_3d", T.small_config(False)).to(dev).train()
+ddp = DDP(model)                                   # the reference's own multi-GPU mode (stat.py:431-436)
+batch, tokens = make_synthetic_sample(2000 + 300 * rank, (8, 8, 4), k=4, seed=10 + rank, device="cuda:0")
+pred = ddp(batch=batch, tokens_pos=tokens.to(dev))
+loss = GF.mse_loss(pred, batch.x)
+loss.backward()
+torch.cuda.synchronize()
+if rank == 0:
+    out = {"norms": {k: float(p.grad.detach().double().norm()) for k, p in model.named_parameters() if p.grad is not None},
+           "grads": {k: p.grad.detach().cpu().double().flatten()[:64].tolist() for k, p in model.named_parameters() if p.grad is not None}}
+    json.dump(out, open(os.environ["GAOT_OUT"], "w"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_sample_level_ddp_two_ranks_one_gpu(tmp_path):
+    """the reference's own parallelism -- DistributedDataParallel over samples (stat.py:431-436) -- wraps the drop-in
+    module unchanged: two processes (both on cuda:0, gloo), one sample each; the all-reduced gradients equal the mean of
+    the two single-process gradients (every trainable parameter gets a gradient, so no find_unused_parameters)."""
+    import json, subprocess
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    gaot_3d_amd.set_precision("fp32")
+    ref = {}
+    for rank in range(2):
+        torch.manual_seed(0)
+        model = init_model(6, 1, "gaot_3d", small_config(False)).to(DEV).train()
+        batch, tokens = make_synthetic_sample(2000 + 300 * rank, (8, 8, 4), k=4, seed=10 + rank, device=str(DEV))
+        GF.mse_loss(model(batch=batch, tokens_pos=tokens.to(DEV)), batch.x).backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                ref[k] = ref.get(k, 0) + 0.5 * p.grad.detach().cpu().double()
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    out = tmp_path / "ddp_out.json"
+    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29535", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.load(open(out))
+    assert set(got["norms"]) == set(ref)
+    for k, g in ref.items():
+        assert abs(got["norms"][k] - float(g.norm())) <= 1e-3 * float(g.norm()) + 1e-6, (k, got["norms"][k], float(g.norm()))
+        assert torch.allclose(torch.tensor(got["grads"][k], dtype=torch.float64), g.flatten()[:64], rtol=1e-3,
+                              atol=1e-5 * max(1.0, float(g.abs().max()))), k
