@@ -330,3 +330,40 @@ def test_sample_level_ddp_two_ranks_one_gpu(tmp_path):
         assert abs(got["norms"][k] - float(g.norm())) <= 1e-3 * float(g.norm()) + 1e-6, (k, got["norms"][k], float(g.norm()))
         assert torch.allclose(torch.tensor(got["grads"][k], dtype=torch.float64), g.flatten()[:64], rtol=1e-3,
                               atol=1e-5 * max(1.0, float(g.abs().max()))), k
+
+
+def test_training_loop_loss_decreases():
+    """thirty training steps (zero_grad -> forward -> MSE -> backward -> fused AdamW under the 'mix' schedule) of the
+    drop-in model in bf16 mode with the reference's training-mode attention dropout, on a learnable target (a smooth
+    function of the coordinates): the loss falls by more than 40 % and every parameter stays finite"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.optim import AdamW
+    from gaot_3d_amd.schedule import MixLRScheduler
+    cfg = _cfg0()
+    cfg.transformer.attn_config.atten_dropout = 0.1
+    torch.manual_seed(0)
+    model = init_model(3, 1, "gaot_3d", cfg).to(DEV).train()
+    batch, tokens = make_synthetic_sample(8192, cfg.latent_tokens, k=8, in_normals=False, surface=False, seed=0, device=str(DEV))
+    tokens = tokens.to(DEV)
+    p = batch.pos
+    batch.x = (torch.sin(3.0 * p[:, :1]) * torch.cos(2.0 * p[:, 1:2]) + 0.5 * p[:, 2:3]).contiguous()
+    opt = AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    sch = MixLRScheduler(opt, 30, 1e-3, 3e-3, 1e-4, 5e-5)
+    gaot_3d_amd.set_precision("bf16")
+    losses = []
+    try:
+        for _ in range(30):
+            opt.zero_grad(set_to_none=True)
+            loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens), batch.x)
+            loss.backward()
+            opt.step()
+            sch.step()
+            losses.append(float(loss.detach()))
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    print("[train] losses:", " ".join(f"{v:.4f}" for v in losses[::3]))
+    assert all(torch.isfinite(q).all() for q in model.parameters())
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
