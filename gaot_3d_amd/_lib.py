@@ -99,6 +99,7 @@ SIGNATURES = {
     "gaot_edge_coords": (_i, [_p, _p, _p, _p, _i64, _i, _p, _i64, _p]),
     "gaot_mul": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gaot_mul_rowsum": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "gaot_affine_cols": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "gaot_scale_mix_fwd": (_i, [_p, _i, _p, _p, _p, _i64, _i, _p]),
     "gaot_scale_mix_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i64, _i, _p]),
 }

@@ -147,7 +147,28 @@ __global__ void k_mul_rowsum(const float* __restrict__ a, const float* __restric
     if (lane == 0) out[r] = s;
 }
 
+// out[r][c] = x[r][c] * (1 + scale_m1[c]) + bias[c]   (time-conditioned norm, reference mlp.py:112-128; bias may be NULL)
+__global__ void k_affine_cols(const float* __restrict__ x, const float* __restrict__ sm1, const float* __restrict__ bias,
+                              int64_t n, int C, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    out[i] = fmaf(x[i], 1.0f + sm1[c], bias ? bias[c] : 0.f);
+}
+
 }  // namespace
+
+extern "C" int gaot_affine_cols(const float* x, const float* scale_minus_one, const float* bias, int64_t rows, int C,
+                                float* out, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && C > 0, "bad shape");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(x && scale_minus_one && out, "null pointer");
+    hipLaunchKernelGGL(k_affine_cols, dim3((unsigned)ceil_div(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x,
+                       scale_minus_one, bias, rows * C, C, out);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
 
 extern "C" int gaot_gather_rows(const float* table, int64_t ld, const int* idx, int64_t E, int C, float* out, int64_t ldo,
                                 gaot_stream_t stream) {

@@ -235,3 +235,33 @@ class RowDotFn(Function):
         a, b = ctx.saved_tensors
         d = (d * ctx.scale).contiguous()
         return mul(b, d, row_scalar=True), mul(a, d, row_scalar=True), None
+
+
+def affine_cols(x: Tensor, scale_m1: Tensor, bias: Optional[Tensor]) -> Tensor:
+    lib = _lib.load()
+    x = _req(x, torch.float32, "x")
+    scale_m1 = _req(scale_m1, torch.float32, "scale")
+    bias = None if bias is None else _req(bias, torch.float32, "bias")
+    out = torch.empty_like(x)
+    check(lib.gaot_affine_cols(_ptr(x), _ptr(scale_m1), _ptr(bias), x.shape[0], x.shape[1], _ptr(out), _stream()), "gaot_affine_cols")
+    return out
+
+
+class AffineColsFn(Function):
+    """x[rows, C] * (1 + s[C]) + b[C]  -- ConditionedNorm.forward for one batch element (reference mlp.py:112-128)"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, s: Tensor, b: Tensor):
+        ctx.save_for_backward(x, s)
+        return affine_cols(x, s, b)
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        from . import ops
+        x, s = ctx.saved_tensors
+        d = d if d.is_contiguous() else d.contiguous()
+        dx = affine_cols(d, s, None)
+        rows, c = x.shape
+        ds = ops.colsum(mul(d, x), rows, c, c)
+        db = ops.colsum(d, rows, c, c)
+        return dx, ds, db

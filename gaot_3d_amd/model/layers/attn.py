@@ -2,7 +2,8 @@
 (src/model/layers/attn.py: configs :15-44, GroupQueryFlashAttention :51-135, FFN :137-165, RMSNorm
 :167-178, TransformerBlock :180-244, Transformer :246-325), computing through the HIP kernels:
 RMSNorm row kernel, MFMA GEMMs (q|k|v and w1|w3 written into one fused buffer each), RoPE, flash
-attention fwd/bwd, SwiGLU.  Time-conditional norm (use_conditional_norm) is outside the hot path."""
+attention fwd/bwd, SwiGLU.  Time-conditional norm (use_conditional_norm, reference mlp.py:74-128) rescales the input
+of attention / FFN per batch element (needs ``condition`` as a [batch, 1] tensor)."""
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -11,6 +12,7 @@ import torch.nn as nn
 
 from ... import functional as GF
 from ...utils.dataclass import shallow_asdict
+from .mlp import ConditionedNorm
 
 
 @dataclass
@@ -66,8 +68,6 @@ class GroupQueryFlashAttention(nn.Module):
         super().__init__()
         assert hidden_size % num_heads == 0, f"hidden_size {hidden_size} must be divisible by num_heads {num_heads}"
         assert num_heads % num_kv_heads == 0, f"num_heads {num_heads} must be divisible by num_kv_heads {num_kv_heads}"
-        if use_conditional_norm:
-            raise NotImplementedError("use_conditional_norm is not implemented on the HIP path")
         self.num_heads = num_heads
         self.num_kv_heads = num_kv_heads
         self.num_repeat = num_heads // num_kv_heads
@@ -80,7 +80,7 @@ class GroupQueryFlashAttention(nn.Module):
         self.k_proj = nn.Linear(input_size, kv_hidden, bias=False)
         self.v_proj = nn.Linear(input_size, kv_hidden, bias=False)
         self.o_proj = nn.Linear(hidden_size, output_size, bias=False)
-        self.correction = None
+        self.correction = ConditionedNorm(1, output_size, cond_norm_hidden_size) if use_conditional_norm else None
         if positional_embedding == "rope":
             self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
 
@@ -88,6 +88,8 @@ class GroupQueryFlashAttention(nn.Module):
                 residual: Optional[torch.Tensor] = None):
         """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`)."""
         dp = float(self.atten_dropout) if self.training else 0.0     # reference attn.py:122-126
+        if self.correction is not None:                               # attn.py:101-102
+            x = self.correction(c=condition, x=x)
         b, s, _ = x.shape
         GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
@@ -105,16 +107,20 @@ class FFN(nn.Module):
     def __init__(self, input_size: int, output_size: int, hidden_size: int = 256, use_conditional_norm: bool = False,
                  cond_norm_hidden_size: int = 4):
         super().__init__()
-        if use_conditional_norm:
-            raise NotImplementedError("use_conditional_norm is not implemented on the HIP path")
         self.w1 = nn.Linear(input_size, hidden_size, bias=False)
         self.w2 = nn.Linear(hidden_size, output_size, bias=False)
         self.w3 = nn.Linear(input_size, hidden_size, bias=False)
-        self.correction = None
+        self.correction = ConditionedNorm(1, output_size, cond_norm_hidden_size) if use_conditional_norm else None
         self.hidden = hidden_size
 
     def forward(self, x, condition: Optional[float] = None, residual: Optional[torch.Tensor] = None):
         """``residual`` (extension): added inside the w2 GEMM epilogue (the block's `h + ffn(h)`)."""
+        if self.correction is not None:     # attn.py:155-159: the correction acts on the FFN's OUTPUT, before the residual
+            y = self.correction(c=condition, x=self._forward_ffn(x, None))
+            return y if residual is None else GF.add(y, residual.view_as(y))
+        return self._forward_ffn(x, residual)
+
+    def _forward_ffn(self, x, residual):
         shp = x.shape
         GF.colocate([self.w1.weight, self.w3.weight])
         if GF.FFNFn.eligible(x, self.w1.weight, self.w3.weight, self.w2.weight):   # bf16 path: bf16 intermediates

@@ -60,3 +60,54 @@ class ChannelMLP(nn.Module):
             x = GF.linear(x, fc.weight, fc.bias, act=self.non_linearity if i < self.n_layers - 1 else None,
                           precision=_FP32)
         return x
+
+
+class MLP(nn.Module):
+    """reference src/model/layers/mlp.py:44-72 (the small MLP of the time-conditioned norm): ``layers`` ModuleList of
+    nn.Linear, activation between them, none after the last; num_layers <= 2 collapses to ONE Linear(input, output)"""
+
+    def __init__(self, input_size: int, output_size: int, hidden_size: int, num_layers: int = 3, activation: str = "swish"):
+        super().__init__()
+        if num_layers <= 2:
+            self.layers = nn.ModuleList([nn.Linear(input_size, output_size)])
+        else:
+            self.layers = nn.ModuleList([nn.Linear(input_size, hidden_size)])
+            for _ in range(num_layers - 2):
+                self.layers.append(nn.Linear(hidden_size, hidden_size))
+            self.layers.append(nn.Linear(hidden_size, output_size))
+        if activation not in ("none", "swish", "silu", "gelu", "relu"):
+            raise ValueError(f"Activation function {activation} not found")
+        self.activation = {"swish": "silu"}.get(activation, activation)
+
+    def forward(self, x):
+        act = None if self.activation == "none" else self.activation
+        for layer in self.layers[:-1]:
+            x = GF.linear(x, layer.weight, layer.bias, act=act, precision=_FP32)
+        return GF.linear(x, self.layers[-1].weight, self.layers[-1].bias, precision=_FP32)
+
+
+class ConditionedNorm(nn.Module):
+    """time-conditioned normalisation (reference mlp.py:74-128): scale = 1 + c * mlp_scale(c), bias = c * mlp_bias(c),
+    out = x * scale[:, None, :] + bias[:, None, :] with c [B, 1] and x [B, S, C]"""
+
+    def __init__(self, input_size: int, output_size: int, hidden_size: int):
+        super().__init__()
+        self.mlp_scale = MLP(input_size, output_size, hidden_size, num_layers=2, activation="none")
+        self.mlp_bias = MLP(input_size, output_size, hidden_size, num_layers=2, activation="none")
+        for layer in list(self.mlp_scale.layers) + list(self.mlp_bias.layers):
+            nn.init.normal_(layer.weight, std=0.01)
+
+    def forward(self, c, x):
+        from ... import edgeops as EO
+        if c is None or not torch.is_tensor(c):
+            raise TypeError("ConditionedNorm needs the condition as a [batch, 1] tensor (reference mlp.py:112-126)")
+        b = x.shape[0]
+        c = c.to(x.device, torch.float32).reshape(b, -1)
+        if c.shape[1] != 1:
+            raise ValueError("ConditionedNorm on the HIP path takes one conditioning scalar per batch element")
+        cs = c.reshape(b).contiguous()
+        sm1 = EO.RowScaleFn.apply(self.mlp_scale(c), cs)      # c * mlp_scale(c)   (scale - 1)
+        bias = EO.RowScaleFn.apply(self.mlp_bias(c), cs)      # c * mlp_bias(c)
+        outs = [EO.AffineColsFn.apply(x[i].reshape(-1, x.shape[-1]), sm1[i], bias[i]) for i in range(b)]
+        y = outs[0].unsqueeze(0) if b == 1 else torch.stack(outs)
+        return y.view_as(x)

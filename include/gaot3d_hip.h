@@ -331,6 +331,10 @@ int gaot_edge_coords(const float* y_pos, const float* x_pos, const int32_t* src,
 int gaot_mul(const float* a, const float* b, int64_t rows, int channels, int b_is_row_scalar, float* out,
              gaot_stream_t stream);
 int gaot_mul_rowsum(const float* a, const float* b, int64_t rows, int channels, float* out, gaot_stream_t stream);
+/* time-conditioned norm (reference ConditionedNorm.forward, src/model/layers/mlp.py:112-128):
+ * out[r][c] = x[r][c] * (1 + scale_minus_one[c]) + bias[c]  for the rows of one batch element; bias may be NULL */
+int gaot_affine_cols(const float* x, const float* scale_minus_one, const float* bias, int64_t rows, int channels,
+                     float* out, gaot_stream_t stream);
 
 #ifdef __cplusplus
 }

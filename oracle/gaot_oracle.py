@@ -403,10 +403,19 @@ def dropout_keep_mask(seed: int, b: int, h: int, s: int, p: float) -> Tensor:
     return torch.from_numpy((half >= thr).reshape(b, h, s, s))
 
 
+def conditioned_norm(sd: SD, prefix: str, c: Tensor, x: Tensor) -> Tensor:
+    """mlp.py:74-128 (ConditionedNorm; its MLPs have num_layers=2 -> one Linear each, activation "none")"""
+    sc = 1 + c * F.linear(c, sd[prefix + "mlp_scale.layers.0.weight"], sd[prefix + "mlp_scale.layers.0.bias"])
+    bi = c * F.linear(c, sd[prefix + "mlp_bias.layers.0.weight"], sd[prefix + "mlp_bias.layers.0.bias"])
+    return x * sc[:, None, :] + bi[:, None, :]
+
+
 def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int, rope: bool,
-              keep: Optional[Tensor] = None, p_drop: float = 0.0) -> Tensor:
+              keep: Optional[Tensor] = None, p_drop: float = 0.0, condition: Optional[Tensor] = None) -> Tensor:
     """attn.py:89-131; ``keep`` [B,H,S,S] = the dropout mask of the training path (None: eval / atten_dropout=0),
     ``p_drop`` the probability it was drawn with."""
+    if (prefix + "correction.mlp_scale.layers.0.weight") in sd:  # attn.py:101-102
+        x = conditioned_norm(sd, prefix + "correction.", condition, x)
     q = F.linear(x, sd[prefix + "q_proj.weight"])
     k = F.linear(x, sd[prefix + "k_proj.weight"])
     v = F.linear(x, sd[prefix + "v_proj.weight"])
@@ -430,11 +439,14 @@ def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int,
     return F.linear(o, sd[prefix + "o_proj.weight"])
 
 
-def ffn(sd: SD, prefix: str, x: Tensor) -> Tensor:
-    """attn.py:155-156"""
+def ffn(sd: SD, prefix: str, x: Tensor, condition: Optional[Tensor] = None) -> Tensor:
+    """attn.py:155-161"""
     a = F.linear(x, sd[prefix + "w1.weight"])
     g = F.linear(x, sd[prefix + "w3.weight"])
-    return F.linear(F.silu(a) * g, sd[prefix + "w2.weight"])
+    y = F.linear(F.silu(a) * g, sd[prefix + "w2.weight"])
+    if (prefix + "correction.mlp_scale.layers.0.weight") in sd:  # :158-159: on the OUTPUT of the FFN
+        y = conditioned_norm(sd, prefix + "correction.", condition, y)
+    return y
 
 
 def transformer_block(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, skip: Optional[Tensor],

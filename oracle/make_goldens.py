@@ -296,6 +296,38 @@ def attn_dropout_case():
     save("attn_dropout", dict(name="attn_dropout", b=b, s=s, d=d, h=h, hkv=hkv, p=p), arrays)
 
 
+def cond_norm_case():
+    """time-conditioned norm (mlp.py:74-128) inside GroupQueryFlashAttention and FFN (use_conditional_norm=True,
+    attn.py:81-84, 101-102, 150-159) in eval mode, condition = one scalar per batch element"""
+    from src.model.layers.attn import FFN, GroupQueryFlashAttention
+
+    b, s, d = 2, 20, 64
+    torch.manual_seed(9)
+    att = GroupQueryFlashAttention(d, d, hidden_size=d, num_heads=2, num_kv_heads=2, use_conditional_norm=True,
+                                   cond_norm_hidden_size=4, atten_dropout=0.0, positional_embedding="absolute").eval()
+    ffn = FFN(d, d, hidden_size=96, use_conditional_norm=True, cond_norm_hidden_size=4).eval()
+    with torch.no_grad():   # the reference initialises these weights with std 0.01: make the correction visible
+        for m in (att.correction, ffn.correction):
+            for p in m.parameters():
+                p.mul_(10.0).add_(0.05 * torch.randn(p.shape))
+    x = 0.5 * torch.randn(b, s, d)
+    c = torch.tensor([[0.3], [-1.2]])
+    arrays = {"in/x": x, "in/c": c}
+    for tag, mod in (("attn", att), ("ffn", ffn)):
+        xin = x.clone().requires_grad_(True)
+        out = mod(xin, condition=c)
+        w = torch.randn(out.shape)
+        (out * w).sum().backward()
+        arrays[f"in/{tag}/w"] = w
+        arrays[f"out/{tag}/out"] = out
+        arrays[f"grad/{tag}/x"] = xin.grad
+        for k, v in mod.state_dict().items():
+            arrays[f"sd/{tag}/{k}"] = v
+        for k, g in grads_of(mod).items():
+            arrays[f"grad/{tag}/{k}"] = g
+    save("cond_norm", dict(name="cond_norm", b=b, s=s, d=d, heads=2, ffn_hidden=96), arrays)
+
+
 def lr_schedule_case():
     """the trainer's 'mix' learning-rate schedule (src/trainer/optimizers.py:40-67, 226-246): per-epoch values of the
     reference's own CustomLRScheduler driven through AdamWOptimizer's phase split, for a few epoch counts"""
@@ -328,12 +360,16 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "attn_dropout":   # regenerate just this file
         attn_dropout_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "cond_norm":
+        cond_norm_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "lr_mix":
         lr_schedule_case()
         return
     ops_case()
     attn_dropout_case()
     lr_schedule_case()
+    cond_norm_case()
     model_case("model_knn_abs", seed=1, n_per_graph=[200], latent_tokens=(4, 4, 4),
                magno_kw=dict(use_geoembed=[True, False], mlp_type="linear", neighbor_strategy="knn", k_neighbors=4),
                tr_kw=dict(patch_size=2, hidden_size=64, num_layers=2, positional_embedding="absolute"),

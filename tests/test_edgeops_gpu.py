@@ -222,3 +222,41 @@ def test_model_with_neighbor_sampling():
     for k, p in model.named_parameters():
         if p.requires_grad:
             close(f"sampling/grad/{k}", p.grad, grads_r[k], 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conditioned_norm_attention_and_ffn_golden(precision):
+    """use_conditional_norm=True (reference mlp.py:74-128; attention input attn.py:101-102, FFN output :158-159) with
+    one conditioning scalar per batch element, against the golden captured from the reference's modules"""
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers.attn import FFN, GroupQueryFlashAttention
+    meta, g = gio.load("cond_norm")
+    d = meta["d"]
+    c = g["in"]["c"].to(DEV)
+    att = GroupQueryFlashAttention(d, d, hidden_size=d, num_heads=meta["heads"], num_kv_heads=meta["heads"],
+                                   use_conditional_norm=True, cond_norm_hidden_size=4, atten_dropout=0.0,
+                                   positional_embedding="absolute")
+    ffn = FFN(d, d, hidden_size=meta["ffn_hidden"], use_conditional_norm=True, cond_norm_hidden_size=4)
+    gaot_3d_amd.set_precision(precision)
+    try:
+        for tag, mod in (("attn", att), ("ffn", ffn)):
+            sd = gio.sub(g["sd"], tag)
+            assert list(mod.state_dict().keys()) == list(sd.keys())
+            mod.load_state_dict(sd, strict=True)
+            mod = mod.to(DEV).eval()
+            x = g["in"]["x"].to(DEV).requires_grad_(True)
+            out = mod(x, condition=c)
+            (out * g["in"][f"{tag}/w"].to(DEV)).sum().backward()
+            ref_o, ref_dx = g["out"][f"{tag}/out"], g["grad"][f"{tag}/x"]
+            if precision == "fp32":
+                close(f"cond/{tag}/out", out, ref_o, 1e-4, 1e-5 * ref_o.abs().max().item())
+                close(f"cond/{tag}/dx", x.grad, ref_dx, 1e-3, 1e-5 * ref_dx.abs().max().item())
+                for k, gr in gio.sub(g["grad"], tag).items():
+                    if k != "x":
+                        close(f"cond/{tag}/grad/{k}", dict(mod.named_parameters())[k].grad, gr, 1e-3, 1e-5 * gr.abs().max().item())
+            else:
+                close(f"cond_bf16/{tag}/out", out, ref_o, 2e-2, 2e-2 * ref_o.abs().max().item())
+                a, b = x.grad.cpu().double().flatten(), ref_dx.double().flatten()
+                assert float(a @ b / (a.norm() * b.norm())) >= 0.999
+    finally:
+        gaot_3d_amd.set_precision("fp32")

@@ -113,3 +113,21 @@ def test_dropout_mask_function_statistics():
     a, b2 = m1[..., 0::2].flatten(), m1[..., 1::2].flatten()
     corr = ((a - a.mean()) * (b2 - b2.mean())).mean() / (a.std() * b2.std())
     assert abs(corr.item()) < 5e-3
+
+
+def test_conditioned_norm_in_attention_and_ffn():
+    """use_conditional_norm (reference mlp.py:74-128, attn.py:101-102, 158-159) against the golden captured from the
+    reference's attention and FFN modules"""
+    meta, g = gio.load("cond_norm")
+    c = g["in"]["c"]
+    for tag in ("attn", "ffn"):
+        sd = {k: t.clone().requires_grad_(True) for k, t in gio.sub(g["sd"], tag).items()}
+        x = g["in"]["x"].clone().requires_grad_(True)
+        out = orc.attention(sd, "", x, meta["heads"], meta["heads"], False, condition=c) if tag == "attn" \
+            else orc.ffn(sd, "", x, condition=c)
+        close(out, g["out"][f"{tag}/out"])
+        (out * g["in"][f"{tag}/w"]).sum().backward()
+        close(x.grad, g["grad"][f"{tag}/x"], 1e-3, 1e-5 * g["grad"][f"{tag}/x"].abs().max().item())
+        for k, gr in gio.sub(g["grad"], tag).items():
+            if k != "x":
+                close(sd[k].grad, gr, 1e-3, 1e-5 * gr.abs().max().item())   # sums of 40 rows of O(10) terms
