@@ -172,16 +172,8 @@ def dropout_seed_sequence(seed0: int, n: int):
 
 
 def _all_gather_stack(t: Tensor, group, gsz: int) -> Tensor:
-    """[G, *t.shape]: one all-gather (RCCL: all_gather_into_tensor; gloo, used by the one-GPU tests: list form)"""
-    import torch.distributed as dist
-    t = t if t.is_contiguous() else t.contiguous()
-    if dist.get_backend(group) == "nccl":
-        out = torch.empty((gsz,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=group)
-        return out
-    parts = [torch.empty_like(t) for _ in range(gsz)]
-    dist.all_gather(parts, t, group=group)
-    return torch.stack(parts)
+    from .sharding import all_gather_stack
+    return all_gather_stack(t, group, gsz)
 
 
 class AttentionFn(Function):
@@ -203,12 +195,10 @@ class AttentionFn(Function):
             import torch.distributed as dist
             gsz, grk = dist.get_world_size(head_group), dist.get_rank(head_group)
             if gsz > 1 and h % gsz == 0 and hkv % gsz == 0:
-                hl, kl = h // gsz, hkv // gsz
+                from .sharding import local_qkv
                 ctx.hp = (head_group, gsz, grk, h, hkv)
-                qkv = torch.cat([qkv[:, grk * hl * 32:(grk + 1) * hl * 32],
-                                 qkv[:, (h + grk * kl) * 32:(h + (grk + 1) * kl) * 32],
-                                 qkv[:, (h + hkv + grk * kl) * 32:(h + hkv + (grk + 1) * kl) * 32]], dim=1)
-                h, hkv = hl, kl
+                qkv = local_qkv(qkv, grk, gsz, h, hkv)
+                h, hkv = h // gsz, hkv // gsz
         seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
         if seed is not None and ctx.hp is not None:
             # the kernels key a head's mask by its LOCAL index: give every rank its own seed word so that the heads
@@ -227,9 +217,8 @@ class AttentionFn(Function):
         ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else empty, seed if seed is not None else empty)
         ctx.dims = (b, s, h, hkv, scale, freqs is not None, bf16, dropout_p)
         if ctx.hp is not None:
-            group, gsz = ctx.hp[0], ctx.hp[1]
-            allo = _all_gather_stack(o, group, gsz)
-            return allo.permute(1, 0, 2).reshape(o.shape[0], gsz * o.shape[1])     # heads back in global order
+            from .sharding import gather_head_outputs
+            return gather_head_outputs(o, ctx.hp[0], ctx.hp[1])                    # heads back in global order
         return o
 
     @staticmethod
@@ -248,12 +237,9 @@ class AttentionFn(Function):
         if rope:
             ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
         if ctx.hp is not None:
+            from .sharding import gather_qkv_grads
             group, gsz, grk, hg, kg = ctx.hp
-            rows = dqkv.shape[0]
-            allg = _all_gather_stack(dqkv, group, gsz).permute(1, 0, 2)                                          # [rows, G, (hl + 2 kl) * 32]
-            dqkv = torch.cat([allg[:, :, :h * 32].reshape(rows, hg * 32),
-                              allg[:, :, h * 32:(h + hkv) * 32].reshape(rows, kg * 32),
-                              allg[:, :, (h + hkv) * 32:].reshape(rows, kg * 32)], dim=1)
+            dqkv = gather_qkv_grads(dqkv, group, gsz, hg, kg)
         return dqkv, None, None, None, None, None, None, None
 
 

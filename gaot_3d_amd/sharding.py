@@ -112,6 +112,47 @@ class AllReduceGradFn(torch.autograd.Function):
         return g, None
 
 
+# ---- head-parallel attention: the index arithmetic of the exchange (device independent; kernels live in functional.py)
+def head_slices(rank: int, world: int, h: int, hkv: int):
+    """column ranges of rank's q / k / v heads inside a fused [rows, (h + 2 hkv) * 32] projection"""
+    hl, kl = h // world, hkv // world
+    return ((rank * hl * 32, (rank + 1) * hl * 32), ((h + rank * kl) * 32, (h + (rank + 1) * kl) * 32),
+            ((h + hkv + rank * kl) * 32, (h + hkv + (rank + 1) * kl) * 32))
+
+
+def local_qkv(qkv: Tensor, rank: int, world: int, h: int, hkv: int) -> Tensor:
+    (q0, q1), (k0, k1), (v0, v1) = head_slices(rank, world, h, hkv)
+    return torch.cat([qkv[:, q0:q1], qkv[:, k0:k1], qkv[:, v0:v1]], dim=1)
+
+
+def all_gather_stack(t: Tensor, group, world: int) -> Tensor:
+    """[world, *t.shape]: one all-gather (RCCL: all_gather_into_tensor; gloo, used by the tests: list form)"""
+    t = t if t.is_contiguous() else t.contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    return torch.stack(parts)
+
+
+def gather_head_outputs(o_local: Tensor, group, world: int) -> Tensor:
+    """[rows, (h/world)*32] per rank -> [rows, h*32] with the heads back in global order"""
+    allo = all_gather_stack(o_local, group, world)
+    return allo.permute(1, 0, 2).reshape(o_local.shape[0], world * o_local.shape[1])
+
+
+def gather_qkv_grads(dqkv_local: Tensor, group, world: int, h: int, hkv: int) -> Tensor:
+    """[rows, (hl + 2 kl)*32] per rank (q | k | v of the rank's heads) -> [rows, (h + 2 hkv)*32] in the fused layout"""
+    hl, kl = h // world, hkv // world
+    rows = dqkv_local.shape[0]
+    allg = all_gather_stack(dqkv_local, group, world).permute(1, 0, 2)           # [rows, world, (hl + 2 kl) * 32]
+    return torch.cat([allg[:, :, :hl * 32].reshape(rows, h * 32),
+                      allg[:, :, hl * 32:(hl + kl) * 32].reshape(rows, hkv * 32),
+                      allg[:, :, (hl + kl) * 32:].reshape(rows, hkv * 32)], dim=1)
+
+
 PARTIAL_GRAD_PREFIXES = ("encoder.lifting.", "encoder.gno.", "decoder.")
 
 

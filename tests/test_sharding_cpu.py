@@ -118,3 +118,74 @@ def test_shard_batch_partition():
             seen_dec += d.shape[1]
         assert cover[0][0] == 0 and cover[-1][1] == n and all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
         assert seen_enc == batch.encoder_edge_index_s0.shape[1] and seen_dec == batch.decoder_edge_index_s0.shape[1]
+
+
+# ---- head-parallel attention exchange (gaot_3d_amd/sharding.py helpers used by functional.AttentionFn) ------------
+def _attn_math(qkv, s, h, hkv):
+    """plain softmax attention on a fused [rows, (h + 2 hkv) * 32] projection (stands in for the HIP kernels on CPU)"""
+    rows = qkv.shape[0]
+    b = rows // s
+    q, k, v = qkv.split([h * 32, hkv * 32, hkv * 32], dim=1)
+    q = q.view(b, s, h, 32).transpose(1, 2)
+    k = k.view(b, s, hkv, 32).transpose(1, 2).repeat_interleave(h // hkv, dim=1)
+    v = v.view(b, s, hkv, 32).transpose(1, 2).repeat_interleave(h // hkv, dim=1)
+    att = torch.softmax(q @ k.transpose(-1, -2) / 32 ** 0.5, dim=-1)
+    return (att @ v).transpose(1, 2).reshape(rows, h * 32)
+
+
+class _HeadParallelAttn(torch.autograd.Function):
+    """the exchange of functional.AttentionFn(head_group=...) around a stand-in attention"""
+
+    @staticmethod
+    def forward(ctx, qkv, s, h, hkv, group, rank, world):
+        from gaot_3d_amd import sharding as sh
+        local = sh.local_qkv(qkv, rank, world, h, hkv).detach().requires_grad_(True)
+        with torch.enable_grad():
+            o_local = _attn_math(local, s, h // world, hkv // world)
+        ctx.local, ctx.o_local, ctx.meta = local, o_local, (h, hkv, group, rank, world)
+        return sh.gather_head_outputs(o_local.detach(), group, world)
+
+    @staticmethod
+    def backward(ctx, d_o):
+        from gaot_3d_amd import sharding as sh
+        h, hkv, group, rank, world = ctx.meta
+        hl = h // world
+        (dl,) = torch.autograd.grad(ctx.o_local, ctx.local, d_o[:, rank * hl * 32:(rank + 1) * hl * 32])
+        return sh.gather_qkv_grads(dl, group, world, h, hkv), None, None, None, None, None, None
+
+
+def _hp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(3)
+        s, h, hkv = 24, 4, 2
+        qkv = torch.randn(2 * s, (h + 2 * hkv) * 32, generator=g).requires_grad_(True)
+        w = torch.randn(2 * s, h * 32, generator=g)
+        out = _HeadParallelAttn.apply(qkv, s, h, hkv, dist.group.WORLD, rank, world)
+        (out * w).sum().backward()
+        ret[rank] = (out.detach(), qkv.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_parallel_exchange_two_ranks_matches_full_attention():
+    """world 2 over gloo: every rank computes half of the (grouped-query) heads; gathered outputs and gathered
+    q|k|v gradients equal full attention on every rank"""
+    from gaot_3d_amd.sharding import head_slices
+    assert head_slices(1, 2, 4, 2) == ((64, 128), (160, 192), (224, 256))
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_hp_worker, args=(world, port, ret), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(3)
+    s, h, hkv = 24, 4, 2
+    qkv = torch.randn(2 * s, (h + 2 * hkv) * 32, generator=g).requires_grad_(True)
+    w = torch.randn(2 * s, h * 32, generator=g)
+    ref = _attn_math(qkv, s, h, hkv)
+    (ref * w).sum().backward()
+    for r in range(world):
+        out, grad = ret[r]
+        assert torch.allclose(out, ref.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(grad, qkv.grad, rtol=1e-4, atol=1e-6)
