@@ -62,7 +62,7 @@ SIGNATURES = {
     "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
-    "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
+    "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gaot_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "gaot_colsum": (_i, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gaot_rope": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _p, _i, _p]),

@@ -40,8 +40,8 @@ __global__ void k_rmsnorm_fwd(const float* __restrict__ x, const float* __restri
 // dx = r*w*dy - x*r^3*mean(x*w*dy);  dw partial per block = sum_rows dy*x*r
 constexpr int RN_ROWS_PER_WAVE = 8;
 __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                              const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dw_part,
-                              int64_t rows, int d) {
+                              const float* __restrict__ rstd, const float* __restrict__ dx_add, float* __restrict__ dx,
+                              float* __restrict__ dw_part, int64_t rows, int d) {
     extern __shared__ float sm[];  // [4][d]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = d / 4;
@@ -73,8 +73,10 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
             const int i = lane + 64 * j;
             if (i < nv) {
                 const float4 v = xr[i], g = gr[i], ww = wr[i];
-                dxr[i] = make_float4(r * ww.x * g.x - v.x * c, r * ww.y * g.y - v.y * c, r * ww.z * g.z - v.z * c,
-                                     r * ww.w * g.w - v.w * c);
+                // dx_add: the gradient that reaches x through its other consumer (the block's residual), added here
+                const float4 e = dx_add ? reinterpret_cast<const float4*>(dx_add + row * d)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                dxr[i] = make_float4(r * ww.x * g.x - v.x * c + e.x, r * ww.y * g.y - v.y * c + e.y,
+                                     r * ww.z * g.z - v.z * c + e.z, r * ww.w * g.w - v.w * c + e.w);
                 dwacc[j].x += g.x * v.x * r;
                 dwacc[j].y += g.y * v.y * r;
                 dwacc[j].z += g.z * v.z * r;
@@ -436,9 +438,9 @@ extern "C" size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim) {
     return sizeof(float) * (size_t)(ceil_div(rows, 4 * RN_ROWS_PER_WAVE) * dim) + 64;
 }
 
-extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, float* dx,
-                                float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
-                                gaot_stream_t stream) {
+extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd,
+                                const float* dx_add, float* dx, float* dweight, int64_t rows, int dim, void* workspace,
+                                size_t workspace_bytes, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 1024, "dim must be a multiple of 4, <= 1024");
     GAOT_CHECK_ARG(workspace_bytes >= gaot_rmsnorm_bwd_workspace_bytes(rows, dim), "workspace too small");
@@ -451,7 +453,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
-                       dx, part, rows, dim);
+                       dx_add, dx, part, rows, dim);
     hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -176,6 +176,28 @@ def _all_gather_stack(t: Tensor, group, gsz: int) -> Tensor:
     return all_gather_stack(t, group, gsz)
 
 
+class RMSNormResFn(Function):
+    """RMSNorm that also hands x back for the block's residual ``x + attn(norm(x))`` (reference attn.py:226): x then has
+    ONE consumer in the autograd graph, and the gradient arriving through the residual is added into dx by the RMSNorm
+    backward kernel itself instead of a separate accumulation pass over [B*S, d]."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, eps: float):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, rstd = ops.rmsnorm_fwd(xc, weight, eps)
+        ctx.save_for_backward(xc, weight, rstd)
+        return y, xc.detach()
+
+    @staticmethod
+    def backward(ctx, dy: Tensor, dres: Optional[Tensor]):
+        x, w, rstd = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(x)
+        d = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, None if dres is None else dres.reshape(x.shape))
+        return dx, dw, None
+
+
 class AttentionFn(Function):
     """softmax(QK^T/sqrt(d))V on a fused [B*S, (h+2*hkv)*32] projection, optional 1-D RoPE on q,k, optional dropout
     on the attention weights (reference attn.py:122-127).
@@ -272,7 +294,9 @@ class FFNFn(Function):
                 and all(t.requires_grad for t in (w1, w3, w2)))
 
     @staticmethod
-    def forward(ctx, x: Tensor, w1: Tensor, w3: Tensor, w2: Tensor, residual: Optional[Tensor]):
+    def forward(ctx, x: Tensor, w1: Tensor, w3: Tensor, w2: Tensor, residual: Optional[Tensor], res_is_x: bool = False):
+        """``res_is_x``: the residual IS the input (the block's ``h + ffn(h)``, attn.py:229): its gradient is folded into the
+        dx GEMM's epilogue instead of meeting dx in a separate accumulation pass"""
         f, d = w1.shape
         x2 = x.reshape(-1, d)
         if not x2.is_contiguous():
@@ -283,13 +307,16 @@ class FFNFn(Function):
         ag = ops.gemm(x2, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
         u = ops.swiglu_fwd_bf16(ag, f)
         res = None
-        if residual is not None:
+        if res_is_x:
+            res = x2
+        elif residual is not None:
             res = residual.reshape(m, d)
             if not res.is_contiguous():
                 res = res.contiguous()
         y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
         ctx.save_for_backward(x2, wcat, w2c, ag, u)
-        ctx.meta = (f, d, x.shape, residual.shape if residual is not None else None, w1.shape, w2.shape)
+        ctx.res_is_x = res_is_x
+        ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
         return y.view(*x.shape[:-1], d)
 
     @staticmethod
@@ -303,10 +330,13 @@ class FFNFn(Function):
         du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
         dw2 = ops.gemm(dy2, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
         dag = ops.swiglu_bwd_bf16(ag, du, f)
-        dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, precision=1).view(xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,
+                          precision=1).view(xshape)
         dwcat = ops.gemm(dag, x2, 2 * f, d, m, 2 * f, d, True, False, precision=1)
         dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
-        return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres
+        return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None
 
 
 class Mlp2Fn(Function):

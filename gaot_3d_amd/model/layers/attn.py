@@ -124,7 +124,8 @@ class FFN(nn.Module):
         shp = x.shape
         GF.colocate([self.w1.weight, self.w3.weight])
         if GF.FFNFn.eligible(x, self.w1.weight, self.w3.weight, self.w2.weight):   # bf16 path: bf16 intermediates
-            return GF.FFNFn.apply(x, self.w1.weight, self.w3.weight, self.w2.weight, residual)
+            same = residual is x
+            return GF.FFNFn.apply(x, self.w1.weight, self.w3.weight, self.w2.weight, None if same else residual, same)
         ag = GF.multi_linear(x, [self.w1.weight, self.w3.weight])   # [rows, 2F] = [w1 x | w3 x]
         u = GF.SwiGLUFn.apply(ag, self.hidden)
         res = None if residual is None else residual.reshape(-1, residual.shape[-1])
@@ -143,6 +144,10 @@ class RMSNorm(nn.Module):
 
     def forward(self, x):
         return GF.RMSNormFn.apply(x, self.weight, self.eps)
+
+    def forward_with_residual(self, x):
+        """(norm(x), x) with x routed through the same autograd node: see functional.RMSNormResFn"""
+        return GF.RMSNormResFn.apply(x, self.weight, self.eps)
 
 
 class TransformerBlock(nn.Module):
@@ -166,8 +171,11 @@ class TransformerBlock(nn.Module):
             b, s, d = x.shape
             x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
                               self.skip_proj.bias).view(b, s, -1)
-        h = x if self.attn_norm is None else self.attn_norm(x)
-        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(norm(x))
+        if self.attn_norm is None:
+            h, xres = x, x
+        else:
+            h, xres = self.attn_norm.forward_with_residual(x)
+        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
         h = h if self.ffn_norm is None else self.ffn_norm(h)
         # NB: the second residual adds the *normalised* h (reference attn.py:226-229)
         return self.ffn(h, condition=condition, residual=h)                                          # h + ffn(h)

@@ -274,14 +274,16 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float):
     return y, rstd
 
 
-def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor):
+def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None):
     lib = _lib.load()
     d = x.shape[-1]
     rows = x.numel() // d
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     ws = _ws(lib.gaot_rmsnorm_bwd_workspace_bytes(rows, d), x.device)
-    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx), _ptr(dw), rows, d, _ptr(ws),
+    if dx_add is not None:
+        dx_add = _req(dx_add, torch.float32, "dx_add")
+    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx), _ptr(dw), rows, d, _ptr(ws),
                                ws.numel(), _stream()), "gaot_rmsnorm_bwd")
     return dx, dw
 

@@ -193,8 +193,11 @@ int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, 
 int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, int64_t rows, int dim, float eps,
                      gaot_stream_t stream);
 size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim);
-int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, float* dx, float* dweight,
-                     int64_t rows, int dim, void* workspace, size_t workspace_bytes, gaot_stream_t stream);
+/* dx_add (may be NULL): a gradient that reaches x through another consumer -- the block's residual
+ * `x + attn(norm(x))` (attn.py:226) -- added into dx by the same pass instead of a separate accumulation kernel */
+int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, const float* dx_add,
+                     float* dx, float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
+                     gaot_stream_t stream);
 size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N);
 int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, float* out, void* workspace, size_t workspace_bytes,
                 gaot_stream_t stream);
