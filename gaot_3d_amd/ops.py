@@ -362,7 +362,8 @@ def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, 
 
 
 def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
-                  dropout_p: float = 0.0, seed: Optional[Tensor] = None) -> Tensor:
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None) -> Tensor:
+    """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection"""
     lib = _lib.load()
     dp, sp = _drop_args(dropout_p, seed)
     dev = o.device
@@ -372,7 +373,8 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: i
     for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
-                                         b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()), "gaot_attn_bwd_bf16")
+                                         _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()),
+                  "gaot_attn_bwd_bf16")
     return dqkv
 
 

@@ -164,7 +164,8 @@ int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout
 /* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
  * rope_freqs != NULL, q pre-scaled) into qkv_image (gaot_attn_bf16_image_bytes), which the backward re-uses;
- * backward writes the fp32 gradient w.r.t. the ROTATED q|k|v into dqkv (apply gaot_rope(inverse=1) after it).
+ * backward writes the fp32 gradient w.r.t. the projection output into dqkv: with rope_freqs (the forward's) the dq / dk
+ * tiles are rotated back in the kernels' epilogues; with NULL the gradient is w.r.t. the ROTATED q|k|v.
  * do_image: scratch of gaot_attn_bwd_bf16_scratch_bytes (bf16 dO image; for launches with few heads also the
  * per-range partial gradients).  When (S/128)*H*B is below two workgroups per CU the streamed range (keys for forward
  * and dQ, queries for dK/dV) is split over blockIdx.y and the parts are combined in a fixed order (forward: by their
@@ -175,8 +176,9 @@ int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_imag
                        int H, int HKV, int head_dim, float scale, float dropout_p,
                        const unsigned long long* dropout_seed, gaot_stream_t stream);
 int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse, void* do_image,
-                       float* delta, float* dqkv, int B, int S, int H, int HKV, int head_dim, float scale,
-                       float dropout_p, const unsigned long long* dropout_seed, int phase_mask, gaot_stream_t stream);
+                       float* delta, float* dqkv, const float* rope_freqs, int B, int S, int H, int HKV, int head_dim,
+                       float scale, float dropout_p, const unsigned long long* dropout_seed, int phase_mask,
+                       gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row / element kernels (HBM-bound).

@@ -165,6 +165,11 @@ def test_attention_bf16_large_grid(b, s, h, hkv):
     scale = 32 ** -0.5
     o16, lse16, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale)
     g16 = ops.attn_bwd_bf16(img, o16, d_o, lse16, b, s, h, hkv, scale)
+    # with the frequencies the kernels rotate dq / dk back in their epilogues: same as k_rope(inverse) afterwards
+    g16u = ops.attn_bwd_bf16(img, o16, d_o, lse16, b, s, h, hkv, scale, freqs=freqs)
+    expect = g16.clone()
+    ops.rope_(expect, b * s, expect.shape[1], 0, h + hkv, s, freqs, True)
+    assert torch.allclose(g16u, expect, rtol=1e-5, atol=1e-6 * float(expect.abs().max())), (g16u - expect).abs().max().item()
     # the fp32 kernels take q|k already rotated; both gradient sets are compared in the rotated basis
     q32 = qkv.clone()
     ops.rope_(q32, b * s, q32.shape[1], 0, h + hkv, s, freqs, False)
