@@ -83,6 +83,7 @@ SIGNATURES = {
     "gaot_segment_random_cap_flags": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "gaot_compact_pairs": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "gaot_cast_bf16": (_i, [_p, _p, _i64, _p]),
+    "gaot_cast_bf16_multi": (_i, [_p, _i, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),

@@ -252,6 +252,32 @@ __global__ void k_cast_bf16(const float* __restrict__ src, unsigned short* __res
     }
 }
 
+// the same for up to 64 tensors in one launch (the Transformer's weights, once per forward): a workgroup finds its
+// tensor in the table of first-block prefix sums
+constexpr int CM_MAX = 64;
+struct CastTable {
+    const float* src[CM_MAX];
+    unsigned short* dst[CM_MAX];
+    int64_t n[CM_MAX];
+    int first_block[CM_MAX + 1];
+    int count;
+};
+__global__ void k_cast_bf16_multi(CastTable t) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+    const int64_t i = (int64_t)((int)blockIdx.x - t.first_block[ti]) * blockDim.x + threadIdx.x;
+    const int64_t n = t.n[ti], n8 = n / 8;
+    const float* src = t.src[ti];
+    unsigned short* dst = t.dst[ti];
+    if (i < n8) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reinterpret_cast<uint4*>(dst)[i] = pack8(f);
+    } else if (i == n8) {
+        for (int64_t j = 8 * n8; j < n; ++j) dst[j] = __builtin_bit_cast(unsigned short, (__bf16)src[j]);
+    }
+}
+
 __global__ void k_swiglu_fwd_bf16(const unsigned short* __restrict__ ag, unsigned short* __restrict__ u, int64_t rows, int F) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte chunk index
     const int fv = F / 8;
@@ -536,6 +562,33 @@ extern "C" int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_strea
     GAOT_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "buffers must be 16-byte aligned");
     const int64_t n8 = n / 8;
     hipLaunchKernelGGL(k_cast_bf16, dim3(blocks_for(n8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n8, n);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_tensors, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_tensors >= 0, "negative tensor count");
+    GAOT_CHECK_ARG(num_tensors == 0 || tensors, "null tensor table");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < num_tensors; base += CM_MAX) {
+        CastTable tb;
+        tb.count = 0;
+        int blocks = 0;
+        for (int i = base; i < num_tensors && i < base + CM_MAX; ++i) {
+            const gaot_cast_tensor_t& e = tensors[i];
+            GAOT_CHECK_ARG(e.numel >= 0, "negative tensor size");
+            if (e.numel == 0) continue;
+            GAOT_CHECK_ARG(e.src && e.dst, "null pointer in tensor table");
+            GAOT_CHECK_ARG((((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0, "buffers must be 16-byte aligned");
+            const int c = tb.count++;
+            tb.src[c] = e.src; tb.dst[c] = (unsigned short*)e.dst; tb.n[c] = e.numel;
+            tb.first_block[c] = blocks;
+            blocks += (int)ceil_div(e.numel / 8 + 1, 256);
+        }
+        tb.first_block[tb.count] = blocks;
+        if (tb.count) hipLaunchKernelGGL(k_cast_bf16_multi, dim3(blocks), dim3(256), 0, st, tb);
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -21,14 +21,44 @@ def _w2d(w: Tensor) -> Tensor:
     return w if w.is_contiguous() else w.contiguous()
 
 
+# bf16 weight copies made ahead of their use by ONE multi-tensor launch (precast_weights, called by Transformer.forward
+# for all of its matrices) and valid only until release_precast(): keyed by (address, shape) of the fp32 matrix
+_WB_CACHE: dict = {}
+
+
+def _wb_eligible(w: Tensor, prec: int) -> bool:
+    n, k = w.shape
+    return bool(prec == 1 and w.is_cuda and n > 64 and k > 64 and n % 8 == 0 and k % 8 == 0 and w.data_ptr() % 16 == 0)
+
+
+def fused_view(ws) -> Tensor:
+    """the [sum(out_i), in] matrix formed by co-located weights (see colocate)"""
+    w0 = _w2d(ws[0])
+    return w0.new_empty(0).set_(w0.untyped_storage(), w0.storage_offset(), (sum(_w2d(w).shape[0] for w in ws), w0.shape[1]),
+                                (w0.shape[1], 1))
+
+
+def precast_weights(mats) -> None:
+    _WB_CACHE.clear()
+    if ops.get_precision() != "bf16":
+        return
+    todo = [m for m in (_w2d(m) for m in mats) if _wb_eligible(m, 1)]
+    for m, c in zip(todo, ops.cast_bf16_multi(todo)):
+        _WB_CACHE[(m.data_ptr(), tuple(m.shape))] = c
+
+
+def release_precast() -> None:
+    _WB_CACHE.clear()
+
+
 def _wb(w: Tensor, precision: Optional[int]) -> Tensor:
     """the weight as the bf16 GEMMs' B operand: in bf16 mode a wide weight ([out > 64, in > 64], 16-byte rows) is rounded
     to bf16 ONCE per use instead of once per workgroup that streams it (a 64-row tile re-reads the whole matrix: at
     M = 16 384 that is 256 x); everything else stays fp32"""
     prec = (1 if ops.get_precision() == "bf16" else 0) if precision is None else precision
-    n, k = w.shape
-    if prec == 1 and w.is_cuda and n > 64 and k > 64 and n % 8 == 0 and k % 8 == 0 and w.data_ptr() % 16 == 0:
-        return ops.cast_bf16(w)
+    if _wb_eligible(w, prec):
+        c = _WB_CACHE.get((w.data_ptr(), tuple(w.shape)))
+        return c if c is not None else ops.cast_bf16(w)
     return w
 
 

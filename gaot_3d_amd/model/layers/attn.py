@@ -206,7 +206,32 @@ class Transformer(nn.Module):
         self.decoder_layers = nn.ModuleList([TransformerBlock.from_config(hidden, hidden, True, config)
                                              for _ in range(n // 2)])
 
+    def _matrices(self):
+        """every weight matrix a block hands to a bf16 GEMM, in the fused form the operators use"""
+        mats = []
+        blocks = list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
+        for blk in blocks:
+            a, f = blk.attn, blk.ffn
+            GF.colocate([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight])
+            GF.colocate([f.w1.weight, f.w3.weight])
+            mats += [GF.fused_view([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]), a.o_proj.weight,
+                     GF.fused_view([f.w1.weight, f.w3.weight]), f.w2.weight]
+            if getattr(blk, "skip_proj", None) is not None:
+                mats.append(blk.skip_proj.weight)
+        for proj in (self.input_proj, self.output_proj):
+            if isinstance(proj, nn.Linear):
+                mats.append(proj.weight)
+        return mats
+
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
+        if x.is_cuda:    # bf16 mode: ONE launch rounds all weight matrices of the blocks (46 separate casts otherwise)
+            GF.precast_weights(self._matrices())
+        try:
+            return self._forward(x, condition, relative_positions)
+        finally:
+            GF.release_precast()
+
+    def _forward(self, x, condition, relative_positions):
         if isinstance(self.input_proj, nn.Linear):
             x = GF.linear(x, self.input_proj.weight, self.input_proj.bias)
         skips = []

@@ -401,6 +401,29 @@ def cast_bf16(x: Tensor) -> Tensor:
     return out
 
 
+class _CastEntry(C.Structure):   # gaot_cast_tensor_t
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("numel", C.c_int64)]
+
+
+def cast_bf16_multi(xs: Sequence[Tensor]) -> List[Tensor]:
+    """bf16 copies of many contiguous fp32 tensors in ONE launch; the copies are slices of one buffer (16-byte aligned)"""
+    lib = _lib.load()
+    if not xs:
+        return []
+    offs, total = [], 0
+    for x in xs:
+        offs.append(total)
+        total += (x.numel() + 7) // 8 * 8
+    buf = torch.empty(total, dtype=torch.bfloat16, device=xs[0].device)
+    outs = [buf[o:o + x.numel()].view(x.shape) for o, x in zip(offs, xs)]
+    entries = (_CastEntry * len(xs))()
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        x = _req(x, torch.float32, "x")
+        entries[i] = _CastEntry(x.data_ptr(), o.data_ptr(), x.numel())
+    check(lib.gaot_cast_bf16_multi(entries, len(xs), _stream()), "gaot_cast_bf16_multi")
+    return outs
+
+
 def swiglu_fwd_bf16(ag: Tensor, f: int) -> Tensor:
     """bf16 [rows, 2F] -> bf16 [rows, F]"""
     lib = _lib.load()

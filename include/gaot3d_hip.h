@@ -210,6 +210,13 @@ int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int64_t rows, 
 /* fp32 -> bf16 (round to nearest even) copy of a weight matrix: the B operand of the bf16 GEMMs of one step is
  * rounded once instead of once per workgroup that streams it (gaot_gemm_ex, b_bf16) */
 int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_stream_t stream);
+/* the same for many tensors in one launch (all bf16 weight copies of the Transformer, once per forward) */
+typedef struct {
+    const float* src;
+    void* dst;        /* numel bf16 */
+    int64_t numel;
+} gaot_cast_tensor_t;
+int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_tensors, gaot_stream_t stream);
 /* the same with every buffer bf16 in memory (fp32 arithmetic); F % 8 == 0, 16-byte aligned buffers */
 int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
