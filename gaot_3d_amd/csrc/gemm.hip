@@ -309,9 +309,18 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
     if (tiles < 128 && K >= 4096) {
         // weight gradients of the per-point MLPs reduce over 500 K rows into ONE tile: a split walks its rows in
         // sequential 16-row steps (each a memory round trip), so such shapes get ~4 workgroups per CU
-        const int64_t cap = K >= 131072 ? 1024 : 64;
-        s = std::min<int64_t>(cap, std::max<int64_t>(1, (K >= 131072 ? 2048 : 1024) / tiles));
-        s = std::min<int64_t>(s, ceil_div(K, K >= 131072 ? 256 : 1024));
+        if (K >= 131072) {
+            s = std::min<int64_t>(1024, std::max<int64_t>(1, 2048 / tiles));
+            s = std::min<int64_t>(s, ceil_div(K, 256));
+        } else {
+            // Transformer weight gradients (K = tokens): aim at ~512 workgroups of 64 x 128 -- measured at K = 16384:
+            // 2048 x 256 outputs 65 -> 56 us with 8 splits, 256 x 256 outputs 24 -> 21 us with 32, the others best at 16
+            const int64_t tiles64 = ceil_div(M, 64) * ceil_div(N, 128);
+            int64_t want = std::max<int64_t>(1, 512 / tiles64);
+            s = 4;
+            while (s * 2 <= want && s < 32) s *= 2;
+            s = std::min<int64_t>(s, std::max<int64_t>(1, K / 512));
+        }
     }
     p.kps = ceil_div(ceil_div(K, s), bk) * bk;
     p.splits = (int)std::max<int64_t>(1, ceil_div(K, std::max<int64_t>(p.kps, 1)));
