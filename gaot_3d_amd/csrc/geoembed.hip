@@ -75,7 +75,7 @@ __global__ void k_geo_raw(const float* __restrict__ src_pos, const float* __rest
         double a00 = cxx * inv + 1e-6, a11 = cyy * inv + 1e-6, a22 = czz * inv + 1e-6;
         double a01 = cxy * inv, a02 = cxz * inv, a12 = cyz * inv;
 #pragma unroll 1
-        for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int sweep = 0; sweep < 5; ++sweep) {   // cyclic Jacobi on 3x3 converges quadratically: 5 sweeps reach fp64 round-off
             jacobi_rot(a00, a11, a01, a02, a12);
             jacobi_rot(a00, a22, a02, a01, a12);
             jacobi_rot(a11, a22, a12, a01, a02);
@@ -146,7 +146,7 @@ __global__ void k_geo_from_moments(const double* __restrict__ mom, int64_t Q, fl
         double a00 = m[6] * inv - ux * ux + 1e-6, a11 = m[9] * inv - uy * uy + 1e-6, a22 = m[11] * inv - uz * uz + 1e-6;
         double a01 = m[7] * inv - ux * uy, a02 = m[8] * inv - ux * uz, a12 = m[10] * inv - uy * uz;
 #pragma unroll 1
-        for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int sweep = 0; sweep < 5; ++sweep) {   // cyclic Jacobi on 3x3 converges quadratically: 5 sweeps reach fp64 round-off
             jacobi_rot(a00, a11, a01, a02, a12);
             jacobi_rot(a00, a22, a02, a01, a12);
             jacobi_rot(a11, a22, a12, a01, a02);
@@ -192,12 +192,21 @@ __global__ void k_geo_colpart(const float* __restrict__ feat, int64_t Q, double*
             sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-// stats[0..8] = mean, stats[9..17] = 1/std (1 if std < 1e-6)
+// stats[0..8] = mean, stats[9..17] = std (1 if std < 1e-6).  One block: 32 column lanes (18 used) x 8 part lanes, the
+// eight partial sums of a column combined in a fixed order (was one thread per column walking all parts: 63 us)
 __global__ void k_geo_colfinal(const double* __restrict__ part, int nparts, int64_t Q, float* __restrict__ stats) {
+    __shared__ double sm[8][2 * NF];
+    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    if (c < 2 * NF) {
+        double s = 0;
+        for (int p = ry; p < nparts; p += 8) s += part[p * 2 * NF + c];
+        sm[ry][c] = s;
+    }
+    __syncthreads();
     const int i = threadIdx.x;
     if (i >= NF) return;
     double s = 0, s2 = 0;
-    for (int p = 0; p < nparts; ++p) { s += part[p * 2 * NF + i]; s2 += part[p * 2 * NF + NF + i]; }
+    for (int j = 0; j < 8; ++j) { s += sm[j][i]; s2 += sm[j][NF + i]; }
     const double mean = s / (double)Q;
     double var = (Q > 1) ? (s2 - (double)Q * mean * mean) / (double)(Q - 1) : NAN;  // torch.std of one row = nan
     if (var < 0) var = 0;
@@ -210,11 +219,19 @@ __global__ void k_geo_colfinal(const double* __restrict__ part, int nparts, int6
 // the same in two steps, for rows that are spread over several ranks: column sums of the local rows, then (after the
 // caller's SUM all-reduce) mean / std over all Q_total rows
 __global__ void k_geo_colsums(const double* __restrict__ part, int nparts, double* __restrict__ sums) {
-    const int i = threadIdx.x;
-    if (i >= 2 * NF) return;
-    double s = 0;
-    for (int p = 0; p < nparts; ++p) s += part[p * 2 * NF + i];
-    sums[i] = s;
+    __shared__ double sm[8][2 * NF];
+    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    if (c < 2 * NF) {
+        double s = 0;
+        for (int p = ry; p < nparts; p += 8) s += part[p * 2 * NF + c];
+        sm[ry][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NF) {
+        double s = 0;
+        for (int j = 0; j < 8; ++j) s += sm[j][threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
 }
 __global__ void k_geo_stats_from_sums(const double* __restrict__ sums, int64_t Q, float* __restrict__ stats) {
     const int i = threadIdx.x;
@@ -255,7 +272,7 @@ extern "C" int gaot_geoembed_stats(const float* source_pos, const float* query_p
                        rowptr_dst, src_sorted, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
     hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);
+    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
     hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();
@@ -287,7 +304,7 @@ extern "C" int gaot_geoembed_from_moments(const double* moments, int64_t num_que
     hipLaunchKernelGGL(k_geo_from_moments, dim3((unsigned)ceil_div(num_queries, 256)), dim3(256), 0, st, moments, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
     hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(64), 0, st, part, nb, num_queries, stats);
+    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
     hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();
@@ -316,7 +333,7 @@ extern "C" int gaot_geoembed_raw(const float* source_pos, const float* query_pos
                        rowptr_dst, src_sorted, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
     hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colsums, dim3(1), dim3(64), 0, st, part, nb, colsums);
+    hipLaunchKernelGGL(k_geo_colsums, dim3(1), dim3(256), 0, st, part, nb, colsums);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

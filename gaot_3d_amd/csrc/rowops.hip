@@ -376,12 +376,12 @@ __global__ void k_mse_part(const float* __restrict__ p, const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// one wave: lane l sums parts l, l+64, ... in order, then a fixed butterfly (was one thread walking all parts: 60 us)
 __global__ void k_mse_final(const double* __restrict__ part, int nparts, double inv_n, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nparts; ++i) s += part[i];
-        *loss = (float)(s * inv_n);
-    }
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) *loss = (float)(s * inv_n);
 }
 __global__ void k_mse_bwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
                           const float* __restrict__ gscalar, float coef, float* __restrict__ dp) {
