@@ -247,18 +247,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int a_vec, int b_ve
 // Fixed-order reduction of the split-K partials [split][M*N]: a workgroup owns 64 consecutive outputs; its 4 waves
 // each sum every 4th split (coalesced 256-byte rows), then the 4 partial sums are added in wave order -- the order
 // never depends on timing, so the result is bit-reproducible.
+// OUT outputs x (256 / OUT) split lanes per workgroup: 64 x 4 for the Transformer-sized outputs, 16 x 16 for the small
+// per-point weight gradients whose 500 K-row reduction is cut into up to 1024 splits (64 x 4 walked 256 splits serially
+// per lane there: 62 us for a 32 x 64 output)
+template <int OUT>
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, int splits, GemmArgs g) {
-    __shared__ float red[4][64];
-    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    constexpr int LANES = 256 / OUT;
+    __shared__ float red[LANES][OUT];
+    const int o = threadIdx.x % OUT, sl = threadIdx.x / OUT;
     const int64_t mn = g.M * g.N;
-    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    const int64_t i = (int64_t)blockIdx.x * OUT + o;
     float v = 0.f;
     if (i < mn)
-        for (int s = sl; s < splits; s += 4) v += part[(int64_t)s * mn + i];
+        for (int s = sl; s < splits; s += LANES) v += part[(int64_t)s * mn + i];
     red[sl][o] = v;
     __syncthreads();
     if (sl != 0 || i >= mn) return;
-    v = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    v = red[0][o];
+#pragma unroll
+    for (int j = 1; j < LANES; ++j) v += red[j][o];
     const int64_t m = i / g.N, n = i % g.N;
     if (g.bias) v += g.bias[n];
     if (g.preact) g.preact[m * g.ldc + n] = v;
@@ -373,7 +380,10 @@ static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N
     else if (p.cfg == 1) launch_cfg<4, 1, 1, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else launch_cfg<2, 2, 2, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     if (gk.splits > 1) {
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)ceil_div(M * N, 64)), dim3(256), 0, st, part, gk.splits, g);
+        if (gk.splits >= 64 && M * N <= 32768)
+            hipLaunchKernelGGL(k_splitk_reduce<16>, dim3((unsigned)ceil_div(M * N, 16)), dim3(256), 0, st, part, gk.splits, g);
+        else
+            hipLaunchKernelGGL(k_splitk_reduce<64>, dim3((unsigned)ceil_div(M * N, 64)), dim3(256), 0, st, part, gk.splits, g);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
