@@ -411,6 +411,15 @@ __global__ void k_dropout_mask(gdrop::Drop d, int H, int S, int64_t n, unsigned 
     keep[i] = gdrop::keep_elem(gdrop::row_key(seed, bh), gdrop::col_key(seed, bh), (uint32_t)q, (uint32_t)k, d.thr) ? 1 : 0;
 }
 
+// out = state; state += stride  (one launch per dropout call: the word a forward uses and the advance of the stream)
+__global__ void k_seed_next(unsigned long long* __restrict__ state, unsigned long long stride, unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long v = *state;
+        *out = v;
+        *state = v + stride;
+    }
+}
+
 bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
 
 }  // namespace
@@ -470,6 +479,15 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
         if (drop) hipLaunchKernelGGL(k_attn_bwd_dq_f32<true>, g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_attn_bwd_dq_f32<false>, g, dim3(256), 0, st, a);
     }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride, unsigned long long* out,
+                                      gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(state && out, "null pointer");
+    hipLaunchKernelGGL(k_seed_next, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -191,9 +191,7 @@ def next_dropout_seed(device) -> Tensor:
     if st is None or st[1] != torch.initial_seed():
         set_dropout_seed(torch.initial_seed() * 0x2545F4914F6CDD1D + 0x632BE59BD9B4E019, dev)
         st = _DROP_STATE[dev]
-    used = st[0].clone()
-    st[0].add_(_DROP_STRIDE)
-    return used
+    return ops.dropout_seed_next(st[0], _DROP_STRIDE)
 
 
 def dropout_seed_sequence(seed0: int, n: int):

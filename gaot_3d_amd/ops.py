@@ -302,6 +302,14 @@ def _drop_args(p: float, seed: Optional[Tensor]):
     return float(p), _ptr(seed)
 
 
+def dropout_seed_next(state: Tensor, stride: int) -> Tensor:
+    """-> a fresh one-element int64 tensor holding the current seed word; ``state`` advances by ``stride`` (one launch)"""
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.int64, device=state.device)
+    check(lib.gaot_dropout_seed_next(_ptr(state), stride & 0xFFFFFFFFFFFFFFFF, _ptr(out), _stream()), "gaot_dropout_seed_next")
+    return out
+
+
 def attn_dropout_mask(seed: Tensor, p: float, b: int, h: int, s: int) -> Tensor:
     """keep[b, h, q, k] (uint8) of the attention dropout mask the kernels regenerate from ``seed`` (checks only)"""
     lib = _lib.load()

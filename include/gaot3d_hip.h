@@ -160,6 +160,9 @@ int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o
                   int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */, gaot_stream_t stream);
 int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout_p, int B, int H, int S,
                            unsigned char* keep, gaot_stream_t stream);
+/* the seed stream: *out = *state; *state += stride -- the word one dropout call uses, and the advance, in one launch */
+int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride, unsigned long long* out,
+                           gaot_stream_t stream);
 
 /* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
