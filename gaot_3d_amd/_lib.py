@@ -61,7 +61,7 @@ SIGNATURES = {
     "gaot_attn_bwd_bf16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
-    "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p]),
+    "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gaot_colsum_workspace_bytes": (_sz, [_i64, _i64]),

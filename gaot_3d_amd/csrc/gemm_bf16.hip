@@ -388,6 +388,7 @@ int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t
             case 4: return launch_bm<A_KS, B_KS, 64, true, 2, false, false, true>(g, a_vec, b_vec, splits, st);
             case 5: return launch_bm<A_KS, B_KS, 64, true, 2, true, false, true>(g, a_vec, b_vec, splits, st);
             case 6: return launch_bm<A_KS, B_KS, 64, true, 2, false, true, true>(g, a_vec, b_vec, splits, st);
+            case 7: return launch_bm<A_KS, B_KS, 64, true, 2, true, true, true>(g, a_vec, b_vec, splits, st);
             default:
                 gaot_set_error("gemm: unsupported bf16 operand combination %d", dt);
                 return GAOT_ERR_UNSUPPORTED;

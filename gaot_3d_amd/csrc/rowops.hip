@@ -16,7 +16,7 @@ namespace {
 // RMSNorm: one wave per row, lanes stride the row in float4
 // ---------------------------------------------------------------------------------------------
 __global__ void k_rmsnorm_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                              float* __restrict__ rstd, int64_t rows, int d, float eps) {
+                              float* __restrict__ rstd, unsigned short* __restrict__ yb, int64_t rows, int d, float eps) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -33,7 +33,15 @@ __global__ void k_rmsnorm_fwd(const float* __restrict__ x, const float* __restri
     const float4* wr = reinterpret_cast<const float4*>(w);
     for (int i = lane; i < d / 4; i += 64) {
         const float4 v = xr[i], g = wr[i];
-        yr[i] = make_float4(v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w);
+        const float4 o = make_float4(v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w);
+        yr[i] = o;
+        if (yb) {   // the same row rounded to bf16: the A operand of the GEMM that consumes it (q|k|v, w1|w3)
+            const __bf16 b0 = (__bf16)o.x, b1 = (__bf16)o.y, b2 = (__bf16)o.z, b3 = (__bf16)o.w;
+            uint2 pk;
+            pk.x = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+            pk.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+            reinterpret_cast<uint2*>(yb + row * d)[i] = pk;
+        }
     }
 }
 
@@ -448,14 +456,14 @@ unsigned blocks_for(int64_t n, int tb = 256) { return (unsigned)std::max<int64_t
 
 }  // namespace
 
-extern "C" int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, int64_t rows, int dim,
-                                float eps, gaot_stream_t stream) {
+extern "C" int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, void* y_bf16, int64_t rows,
+                                int dim, float eps, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(x && weight && y, "null pointer");
     hipLaunchKernelGGL(k_rmsnorm_fwd, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, weight, y,
-                       rstd, rows, dim, eps);
+                       rstd, (unsigned short*)y_bf16, rows, dim, eps);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

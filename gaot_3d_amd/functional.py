@@ -152,16 +152,32 @@ class GnoFn(Function):
         return (gf, None, None, None, *grads)
 
 
+def _want_bf16_copy(x: Tensor) -> bool:
+    return ops.get_precision() == "bf16" and x.is_cuda and x.shape[-1] % 8 == 0
+
+
+def bf16_copy_of(x: Tensor, shape) -> Optional[Tensor]:
+    """the bf16 image its producer (RMSNorm) attached to x, if any: the GEMM's A operand without an in-kernel conversion"""
+    xb = getattr(x, "_gaot_bf16", None)
+    if xb is None or xb.numel() != x.numel() or not xb.is_contiguous():
+        return None
+    return xb.view(shape)
+
+
 class RMSNormFn(Function):
+    """-> (y, bf16 copy of y or an empty tensor).  The copy is not differentiable: it is the same values, for the GEMM"""
+
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, eps: float):
         xc = x if x.is_contiguous() else x.contiguous()
-        y, rstd = ops.rmsnorm_fwd(xc, weight, eps)
+        y, rstd, yb = ops.rmsnorm_fwd(xc, weight, eps, _want_bf16_copy(xc))
         ctx.save_for_backward(xc, weight, rstd)
-        return y
+        yb = yb if yb is not None else torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(yb)
+        return y, yb
 
     @staticmethod
-    def backward(ctx, dy: Tensor):
+    def backward(ctx, dy: Tensor, _dyb):
         x, w, rstd = ctx.saved_tensors
         d = dy if dy.is_contiguous() else dy.contiguous()
         dx, dw = ops.rmsnorm_bwd(x, w, d, rstd)
@@ -212,12 +228,14 @@ class RMSNormResFn(Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, eps: float):
         xc = x if x.is_contiguous() else x.contiguous()
-        y, rstd = ops.rmsnorm_fwd(xc, weight, eps)
+        y, rstd, yb = ops.rmsnorm_fwd(xc, weight, eps, _want_bf16_copy(xc))
         ctx.save_for_backward(xc, weight, rstd)
-        return y, xc.detach()
+        yb = yb if yb is not None else torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(yb)
+        return y, xc.detach(), yb
 
     @staticmethod
-    def backward(ctx, dy: Tensor, dres: Optional[Tensor]):
+    def backward(ctx, dy: Tensor, dres: Optional[Tensor], _dyb=None):
         x, w, rstd = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(x)
@@ -332,7 +350,9 @@ class FFNFn(Function):
         m = x2.shape[0]
         wcat = _wb(w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1)), 1)
         w2c = _wb(_w2d(w2), 1)
-        ag = ops.gemm(x2, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+        xb = bf16_copy_of(x, (m, d))
+        xa = xb if xb is not None else x2          # bf16 image written by the producing RMSNorm
+        ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
         u = ops.swiglu_fwd_bf16(ag, f)
         res = None
         if res_is_x:
@@ -342,7 +362,7 @@ class FFNFn(Function):
             if not res.is_contiguous():
                 res = res.contiguous()
         y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
-        ctx.save_for_backward(x2, wcat, w2c, ag, u)
+        ctx.save_for_backward(xa, wcat, w2c, ag, u)
         ctx.res_is_x = res_is_x
         ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
         return y.view(*x.shape[:-1], d)
@@ -510,8 +530,10 @@ class MultiLinearFn(Function):
         ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[2 + i] for i in range(len(ws)))
         if ctx.fused:   # the weights are slices of one buffer (colocate): one [ntot, k] matrix, one GEMM
             wcat = _wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), precision)
-            ops.gemm(x2, wcat, m, ntot, k, k, k, False, True, out=out, ldc=ntot, precision=precision)
-            ctx.save_for_backward(x2, wcat)
+            xb = bf16_copy_of(x, (m, k)) if wcat.dtype == torch.bfloat16 else None
+            xa = xb if xb is not None else x2      # bf16 image written by the producing RMSNorm: half the A traffic
+            ops.gemm(xa, wcat, m, ntot, k, k, k, False, True, out=out, ldc=ntot, precision=precision)
+            ctx.save_for_backward(xa, wcat)
         else:
             col = 0
             for w in ws:

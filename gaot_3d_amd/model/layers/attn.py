@@ -143,11 +143,17 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(dim))
 
     def forward(self, x):
-        return GF.RMSNormFn.apply(x, self.weight, self.eps)
+        y, yb = GF.RMSNormFn.apply(x, self.weight, self.eps)
+        if yb.numel():
+            y._gaot_bf16 = yb      # picked up by the GEMM that consumes y (functional.bf16_copy_of)
+        return y
 
     def forward_with_residual(self, x):
         """(norm(x), x) with x routed through the same autograd node: see functional.RMSNormResFn"""
-        return GF.RMSNormResFn.apply(x, self.weight, self.eps)
+        y, xres, yb = GF.RMSNormResFn.apply(x, self.weight, self.eps)
+        if yb.numel():
+            y._gaot_bf16 = yb
+        return y, xres
 
 
 class TransformerBlock(nn.Module):

@@ -263,15 +263,18 @@ def axpy(a: Tensor, b: Tensor, alpha: float = 1.0, period: Optional[int] = None)
     return out
 
 
-def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float):
+def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, want_bf16: bool = False):
+    """-> (y, rstd, y_bf16 | None); the bf16 copy (same rounding a GEMM would apply to y as its A operand) is written by
+    the same pass"""
     lib = _lib.load()
     d = x.shape[-1]
     rows = x.numel() // d
     y = torch.empty_like(x)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.gaot_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), rows, d, float(eps), _stream()),
+    yb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want_bf16 and d % 8 == 0) else None
+    check(lib.gaot_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), _ptr(yb), rows, d, float(eps), _stream()),
           "gaot_rmsnorm_fwd")
-    return y, rstd
+    return y, rstd, yb
 
 
 def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None):

@@ -131,7 +131,7 @@ int gaot_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, in
  * in elements): the FFN intermediates of the bf16 path ([rows, 2F] = w1 x | w3 x, silu(a)*g, and their gradients,
  * reference attn.py:156) are written once as bf16 by their producer and never exist as fp32 in HBM.  precision must
  * be 1 and N > 64; rows must be 16-byte aligned and K a multiple of 8; a bf16 result excludes split-K.  Supported
- * combinations: A, B, A+B, C, A+C, B+C; anything else returns GAOT_ERR_UNSUPPORTED. */
+ * any combination of bf16 A, B and C. */
 int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                  int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int c_bf16, const float* bias, int act,
                  const float* residual, int64_t ldr, float* preact, int precision, void* workspace,
@@ -195,7 +195,8 @@ int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, 
  *   mse     : nn.MSELoss mean reduction (src/trainer/base.py:56) and d(loss)/d(pred) * (*grad_loss)
  *   colsum  : out[n] = sum_m x[m][n]  (bias gradients)
  * ------------------------------------------------------------------------------------------- */
-int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, int64_t rows, int dim, float eps,
+int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, float* rstd, void* y_bf16 /* NULL, or the same rows
+                     rounded to bf16 for the GEMM that consumes them */, int64_t rows, int dim, float eps,
                      gaot_stream_t stream);
 size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim);
 /* dx_add (may be NULL): a gradient that reaches x through another consumer -- the block's residual

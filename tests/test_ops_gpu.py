@@ -231,6 +231,8 @@ def test_multi_linear_colocated(m, k, ns, precision):
     (256, 1024, 1203, True, False, False, True, False),   # bf16 B, k-strided (weight gradient of w2), split-K, odd K
     (333, 1024, 256, False, False, False, False, True),   # dy W -> bf16 result (input gradient of w2)
     (64, 128, 72, False, True, True, False, True),        # A and C bf16, ragged K tail (72 = 64 + 8)
+    (500, 2048, 256, False, True, True, True, True),      # A, B and C bf16 (w1|w3 forward on the RMSNorm's bf16 image)
+    (256, 768, 1000, True, False, False, True, False),    # dy^T x_bf16 (weight gradient of q|k|v on the bf16 image)
 ])
 def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     """gaot_gemm_ex: operands / result that are bf16 in memory must give what the fp32-in-memory bf16 GEMM gives on the
@@ -327,11 +329,27 @@ def test_rmsnorm_swiglu_rope_patchify_mse():
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     (orc.rmsnorm(xr, wr, 1e-6) * g).sum().backward()
     xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    y = GF.RMSNormFn.apply(xd, wd, 1e-6)
+    y, yb = GF.RMSNormFn.apply(xd, wd, 1e-6)
+    assert yb.numel() == 0                      # fp32 mode: no bf16 image
     (y * g.to(DEV)).sum().backward()
     close("rmsnorm_y", y, orc.rmsnorm(x, w, 1e-6), 1e-5, 1e-6)
     close("rmsnorm_dx", xd.grad, xr.grad, 1e-4, 1e-5)
     close("rmsnorm_dw", wd.grad, wr.grad, 1e-4, 1e-4)
+    # residual form: (norm(x), x) through one node; the residual's gradient is added inside the backward kernel; in
+    # bf16 mode the same pass also writes the bf16 image of y that the consuming GEMM reads
+    import gaot_3d_amd
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        x2 = x.to(DEV).requires_grad_(True)
+        w2 = w.to(DEV).requires_grad_(True)
+        y2, xres, yb2 = GF.RMSNormResFn.apply(x2, w2, 1e-6)
+        assert torch.equal(yb2, y2.detach().bfloat16()) and torch.equal(xres, x2.detach())
+        gres = gen(300, 256, seed=7).to(DEV)
+        ((y2 * g.to(DEV)).sum() + (xres * gres).sum()).backward()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    close("rmsnorm_res_dx", x2.grad, xr.grad + gres.cpu(), 1e-4, 1e-5)
+    close("rmsnorm_res_dw", w2.grad, wr.grad, 1e-4, 1e-4)
     # swiglu
     ag, du = gen(77, 2 * 128, seed=4), gen(77, 128, seed=5)
     ar = ag.clone().requires_grad_(True)
