@@ -363,7 +363,8 @@ __device__ __forceinline__ void stage_row_words(uint32_t* aw_s, uint32_t rk, int
     if (threadIdx.x < QS) {
         const uint32_t w = gdrop::row_word(rk, (uint32_t)q0 + threadIdx.x);
         aw_s[threadIdx.x] = w & 0xffffu;
-        aw_s[QS + threadIdx.x] = w >> 16;
+        aw_s[QS + 4 + threadIdx.x] = w >> 16;   // + 4 words: the odd-key lanes' 16-byte reads hit other banks than the even ones'
+
     }
 }
 __device__ __forceinline__ void load_row_words(uint32_t (&w)[16], const uint32_t* rows32, int hf) {
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // Q0 Q1 dO0 dO1
     __shared__ __attribute__((aligned(16))) float lse_s[64];
     __shared__ __attribute__((aligned(16))) float del_s[64];
-    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 128 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 128 + 4 : 4];
     // with dropout the dP tile is (keep ? dO.V : 0) / (1-p) - delta; the kernel works with (1-p) times that, i.e.
     // delta is staged pre-multiplied by (1-p), and dK is rescaled by 1/(1-p) once at the end (dV likewise)
     const float dscale = DROP ? a.drop.keep : 1.f;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dt, l31, hf, ks), vf[ks], dp, 0, 0, 0);
                 }
                 if constexpr (DROP) {
-                    const uint32_t* awp = aw_s + (l31 & 1) * 64 + 32 * t + 4 * hf;
+                    const uint32_t* awp = aw_s + (l31 & 1) * (64 + 4) + 32 * t + 4 * hf;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * NT * TILE_BYTES];  // Q tiles, then dO tiles
     __shared__ __attribute__((aligned(16))) float lse_s[QS];
     __shared__ __attribute__((aligned(16))) float del_s[QS];
-    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 2 * QS : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t aw_s[DROP ? 2 * QS + 4 : 4];
     const float dscale = DROP ? a.drop.keep : 1.f;   // see k_attn_bwd_dkv_bf16
     unsigned long long seed = 0;
     if constexpr (DROP) seed = *a.drop.seed;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
                 if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them
-                    const uint32_t* awp = aw_s + (l31 & 1) * QS + 32 * t + 4 * hf;
+                    const uint32_t* awp = aw_s + (l31 & 1) * (QS + 4) + 32 * t + 4 * hf;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
