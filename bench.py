@@ -3,16 +3,24 @@
 on ONE synthetic DrivAerNet++-shaped sample (BASELINE.json configs[1]: 500K points, latent 64x64x32, knn k=8
 encoder + flipped decoder, model section of the reference's pressure.yaml: C=32, P=2, d=256, h=8, F=1024, L=10, rope).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-N>1 shards the PHYSICAL POINTS of the one sample across ranks (latent tokens replicated, RCCL all-reduce of the
-encoder's per-token sums/counts and of the decoder's latent gradient); value = points of the whole sample / step time.
+N>1 from a plain shell: this process does NOT touch the GPU; it starts ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...`` as a fresh child (one rank per GPU over RCCL), relays the child's
+single JSON line and exits with its return code.  Under torchrun (WORLD_SIZE set) it is a rank.
+
+N>1 is STRONG scaling by default (BASELINE.json configs[2]): the ONE 500K-point sample is split over the N GPUs --
+physical points / edges by contiguous range, the latent Transformer by token rows, attention by heads (all-to-all on
+either side), RCCL all-reduce of the encoder's per-token sums into the replicated latent grid; value = points of the
+sample / step time.  ``--scaling weak`` keeps 500K points per GPU (an N x 500K-point sample) and says so in `metric`.
 Rank 0 prints ONE JSON line.  The timed region starts with all inputs resident in HBM; the neighbour-list (CSR) build
 and the geometric-embedding statistics are recomputed inside every timed step (nothing is cached across steps).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -20,7 +28,73 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=500000)
+    ap.add_argument("--latent", type=str, default="64,64,32")
+    ap.add_argument("--layers", type=int, default=10)
+    ap.add_argument("--knn", type=int, default=8)
+    ap.add_argument("--precision", type=str, default=os.environ.get("GAOT_PRECISION", "bf16"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["sample", "full"], default="sample",
+                    help="sample: the oracle on 1/8 of the points and of the latent grid (bounded, ~15 s); full: the oracle "
+                         "on the SAME 500K-point sample, one timed step, attention dropout off on the CPU side (its mask "
+                         "would be 8.6 GB per layer)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="also replay a captured hipGraph at N>1 (default: N=1 only)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--atten-dropout", type=float, default=0.1,
+                    help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
+                         "attn.py:22; no shipped config overrides it)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary timings (N=1: dropout-free step, fp32 mode; N>1: weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N>1: strong = ONE --points sample split over the N GPUs (BASELINE configs[2], default); weak = "
+                         "every GPU owns --points points of one N x --points sample")
+    ap.add_argument("--parallel", choices=["seq", "head", "replicated"], default="seq",
+                    help="N>1, how the latent Transformer is divided: seq = token rows per rank + heads per rank inside "
+                         "attention (all-to-all); head = replicated except the attention heads; replicated = not at all")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise launch + rendezvous only (gloo, no GPU work): prints a JSON line with n_ranks_seen")
+    return ap.parse_args(argv)
+
+
+def spawn_command(args, argv, port):
+    """the torchrun command line a plain `python bench.py --gpus N` (N>1) starts as its child"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """Called BEFORE torch is imported / any HIP call: run the N ranks as a fresh child process tree, relay the JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = spawn_command(args, argv, _free_port())
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.stdout.flush()
+    return r.returncode if (r.returncode != 0 or line is not None) else 1
 
 
 def model_config(latent, layers, k, atten_dropout=0.1):
@@ -45,6 +119,7 @@ def algorithmic_work(n_pts, m_lat, e_enc, e_dec, s_tok, layers, heads=8, dh=32, 
     att = 2 * s_tok * s_tok * dh * heads  # one S x S x dh product over all heads
     return {
         "attn_fwd": dict(flops=2 * att, bytes=None, bound="mfma"),
+        "attn_bwd": dict(flops=4 * att, bytes=None, bound="mfma"),       # fused backward: dP, dV, dK, dQ (S recompute not counted)
         "attn_bwd_dkv": dict(flops=3 * att, bytes=None, bound="mfma"),   # dP, dV, dK (S recompute not counted)
         "attn_bwd_dq": dict(flops=1 * att, bytes=None, bound="mfma"),    # dQ (S, dP recompute not counted)
         "gno_fwd_nh3": dict(flops=e_enc * 21280, bytes=e_enc * (32 + c * b) + m_lat * c * b, bound="hbm"),
@@ -54,15 +129,44 @@ def algorithmic_work(n_pts, m_lat, e_enc, e_dec, s_tok, layers, heads=8, dh=32, 
     }
 
 
-def cpu_baseline(layers, k, seed, atten_dropout):
-    """The oracle (CPU restatement of the reference, pure PyTorch fp32) timed on the host cores on a bounded sample
-    of the same workload: 1/16 of the points and 1/8 of the latent grid, same widths and depth."""
+def step_roofline_ms(n_pts, m_lat, e_enc, e_dec, s_tok, layers, precision, d=256, f=1024, c=32, out=1):
+    """t_roof = sum over stages of max(bytes / HBM rate, flops / matrix rate of the arithmetic used).
+    Transformer per layer forward 8 S d^2 + 4 S^2 d + 6 S d F (+ 4 S d^2 skip_proj in the decoder half), backward 2x;
+    patch_linear 2 S d^2; GNO edge MLPs 21 280 / 13 088 flop per edge forward, 3x with backward; gather/scatter bytes
+    per edge 32 + C b forward, 32 + 2 C b backward (+ one row written per output row); projection 16 896 flop per point."""
+    mfma = 157.3e12 if precision == "fp32" else 2.5e15
+    hbm = 8.0e12
+    per_layer = 8 * s_tok * d * d + 4 * s_tok * s_tok * d + 6 * s_tok * d * f
+    xf = layers * per_layer + (layers // 2) * 4 * s_tok * d * d + 2 * s_tok * d * d
+    t_xf = 3 * xf / mfma
+    gno_flops = 3 * (e_enc * 21280 + e_dec * 13088)
+    gno_bytes = (e_enc * (32 + c * 4) + m_lat * c * 4 + e_dec * (32 + c * 4) + n_pts * c * 4
+                 + e_enc * (32 + 2 * c * 4) + n_pts * c * 4 + e_dec * (32 + 2 * c * 4) + m_lat * c * 4)
+    t_gno = max(gno_bytes / hbm, gno_flops / mfma)
+    proj_flops = 3 * n_pts * 2 * (c * 256 + 256 * out)
+    point_bytes = n_pts * (6 * 4 + c * 4 + 2 * out * 4) * 2 + m_lat * (9 * 4 + 3 * c * 4) * 2
+    t_pt = max(point_bytes / hbm, proj_flops / mfma)
+    t_opt = 28 * 11.25e6 / hbm      # AdamW: 28 B per parameter
+    return dict(transformer_ms=t_xf * 1e3, gno_ms=t_gno * 1e3, per_node_ms=t_pt * 1e3, adamw_ms=t_opt * 1e3,
+                t_roof_ms=(t_xf + t_gno + t_pt + t_opt) * 1e3)
+
+
+def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full):
+    """The oracle (CPU restatement of the reference, pure PyTorch fp32) timed on the host cores.  mode 'sample': a bounded
+    sample of the same workload -- 1/8 of the points and 1/8 of the latent grid (so 1/8 of the tokens: attention, which is
+    quadratic in them, is 1/64), same widths and depth; mode 'full': the same 500K-point sample the GPU step runs, one
+    timed step after one warm-up, attention dropout off on the CPU side."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
     import gaot_oracle as orc  # timed CPU baseline only
     from gaot_3d_amd.data import make_synthetic_sample
     from gaot_3d_amd.model import init_model
-    n, latent = 62500, (32, 32, 16)
-    cores = min(os.cpu_count() or 1, 16)   # more threads only add fork/join overhead on these op sizes
+    if mode == "full":
+        n, latent = points, tuple(latent_full)
+        atten_dropout = 0.0
+    else:
+        n, latent = points // 8, (latent_full[0] // 2, latent_full[1] // 2, latent_full[2] // 2)
+    cores = min(os.cpu_count() or 1, 16 if mode == "sample" else 64)   # more threads only add fork/join overhead here
     torch.set_num_threads(cores)
     cfg = model_config(latent, layers, k)
     torch.manual_seed(seed)
@@ -81,47 +185,68 @@ def cpu_baseline(layers, k, seed, atten_dropout):
     one_step()  # warm-up
     times = []
     t_begin = time.perf_counter()
-    while len(times) < 3 and time.perf_counter() - t_begin < 25.0:
+    reps = 3 if mode == "sample" else 1
+    while len(times) < reps and time.perf_counter() - t_begin < 25.0:
         t0 = time.perf_counter()
         one_step()
         times.append(time.perf_counter() - t0)
     t = sorted(times)[0]
-    return dict(value=n / t, unit="points/s", cores=cores, kind="port",
-                sample=f"oracle fwd+MSE+bwd on N={n} points (1/8 of the sample), latent {latent[0]}x{latent[1]}x{latent[2]} "
-                       f"(1/8), k={k}, L={layers}, d=256, attention dropout {atten_dropout}, fp32, best of {len(times)} "
-                       f"after 1 warm-up ({t:.2f} s/step)")
+    frac = "the same sample as the GPU step" if mode == "full" else "1/8 of the points and 1/8 of the latent grid: a REDUCED sample"
+    return dict(value=n / t, unit="points/s", cores=cores, kind="port", reduced_sample=(mode != "full"),
+                sample=f"oracle fwd+MSE+bwd on N={n} points, latent {latent[0]}x{latent[1]}x{latent[2]} ({frac}), k={k}, "
+                       f"L={layers}, d=256, attention dropout {atten_dropout}, fp32, best of {len(times)} after 1 warm-up "
+                       f"({t:.2f} s/step)")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=500000)
-    ap.add_argument("--latent", type=str, default="64,64,32")
-    ap.add_argument("--layers", type=int, default=10)
-    ap.add_argument("--knn", type=int, default=8)
-    ap.add_argument("--precision", type=str, default=os.environ.get("GAOT_PRECISION", "bf16"), choices=["fp32", "bf16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--graph", action="store_true", help="also use the hipGraph replay for N>1 (default: N=1 only)")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--atten-dropout", type=float, default=0.1,
-                    help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
-                         "attn.py:22; no shipped config overrides it)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the extra dropout-free timing at N=1")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1: weak = every GPU owns --points points of one N x --points sample (default); strong = one "
-                         "--points sample split over the N GPUs (BASELINE configs[2])")
-    args = ap.parse_args()
+def csrc_sha16():
+    """hash of the kernel sources: profiles/pmc_traffic.json carries the hash of the sources it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaot_3d_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
+
+def dry_run(args):
+    """launch / rendezvous check without GPU work: every rank joins a gloo group and rank 0 prints the line"""
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", init_method="env://")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": 0.0, "unit": "points/s", "n_gpus": world,
+                          "n_ranks_seen": seen, "scaling": args.scaling, "dry_run": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks as a child BEFORE anything here touches the GPU
+        sys.exit(spawn_ranks(args, argv))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args)
+
+    import torch
     import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GAOT_BENCH_ONE_DEVICE=1 (testing only): every rank on cuda:0 over gloo, to exercise the N>1 code path -- sharding,
     # exchange steps, max-over-ranks timing -- on a single-GPU box.  The number it prints is not a scaling result.
     one_device = os.environ.get("GAOT_BENCH_ONE_DEVICE", "0") == "1"
@@ -136,54 +261,54 @@ def main():
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd import ops
-    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.data import make_synthetic_sample, make_synthetic_shard
     from gaot_3d_amd.model import init_model
-    gaot_3d_amd.set_precision(args.precision)
-
-    latent = tuple(int(v) for v in args.latent.split(","))
-    cfg = model_config(latent, args.layers, args.knn, args.atten_dropout)
-    torch.manual_seed(args.seed)
-    model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
-    use_graph = (not args.no_graph) and (world == 1 or args.graph)
     from gaot_3d_amd.optim import AdamW   # fused multi-tensor HIP step, same semantics as torch.optim.AdamW (tests)
-    opt = AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5)
+    gaot_3d_amd.set_precision(args.precision)
+    latent = tuple(int(v) for v in args.latent.split(","))
+    m_lat = latent[0] * latent[1] * latent[2]
+    s_tok = m_lat // 8
 
-    # Weak scaling (the path shards by mesh points): every GPU owns --points points of ONE sample of
-    # world x --points points (N = 1: configs[1], 500 K points; N = 8: a 4 M-point sample, between configs[1] and the
-    # 8-10 M-point configs[4]); latent grid, Transformer and parameters are replicated, as the north star prescribes.
-    n_total = args.points * world if args.scaling == "weak" else args.points
-    batch, tokens = make_synthetic_sample(n_total, latent, k=args.knn, seed=args.seed, device=str(dev))
-    tokens = tokens.to(dev)
-    if world > 1:
-        from gaot_3d_amd import sharding
-        batch = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
-        step_ctx = sharding.ShardedStep(model, dist.group.WORLD, n_total)
-    else:
-        step_ctx = None
-
-    def step():
-        gaot_3d_amd.clear_graph_cache(batch)
-        opt.zero_grad(set_to_none=True)
-        if step_ctx is None:
-            pred = model(batch=batch, tokens_pos=tokens)
-            loss = GF.mse_loss(pred, batch.x)
-            loss.backward()
+    def build(n_total, atten_dropout, parallel):
+        """model + optimizer + rank-local inputs + step() for one sample of n_total points"""
+        cfg = model_config(latent, args.layers, args.knn, atten_dropout)
+        torch.manual_seed(args.seed)
+        model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
+        opt = AdamW(model.parameters(), lr=3e-4, weight_decay=1e-5)
+        if world > 1:
+            from gaot_3d_amd import sharding
+            # every rank generates only ITS point range on the device (host RNG draws are the whole sample's: 7 floats/point)
+            batch, tokens = make_synthetic_shard(n_total, latent, rank, world, k=args.knn, seed=args.seed, device=str(dev))
+            step_ctx = sharding.ShardedStep(model, dist.group.WORLD, n_total, parallel=parallel)
         else:
-            loss = step_ctx.forward_backward(batch, tokens)
-        opt.step()
-        return loss
+            batch, tokens = make_synthetic_sample(n_total, latent, k=args.knn, seed=args.seed, device=str(dev))
+            step_ctx = None
+        tokens = tokens.to(dev)
 
-    # The step is ~600 short kernels; launched eagerly from Python the host becomes the bottleneck.  Capture ONE
-    # whole step (CSR build, forward, loss, backward, gradient exchange, AdamW) into a hipGraph after the warm-up and
+        def step():
+            gaot_3d_amd.clear_graph_cache(batch)
+            opt.zero_grad(set_to_none=True)
+            if step_ctx is None:
+                pred = model(batch=batch, tokens_pos=tokens)
+                loss = GF.mse_loss(pred, batch.x)
+                loss.backward()
+            else:
+                loss = step_ctx.forward_backward(batch, tokens)
+            opt.step()
+            return loss
+        return model, step
+
+    # The step is a few hundred short kernels; launched eagerly from Python the host can become the bottleneck.  Capture
+    # ONE whole step (CSR build, forward, loss, backward, gradient exchange, AdamW) into a hipGraph after the warm-up and
     # replay it: the timed region then measures the device work.  --no-graph times the eager launches instead.
-    def measure():
+    def measure(step, steps, warmup, use_graph):
         graph = None
         loss = None
         if use_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(max(args.warmup, 1)):
+                for _ in range(max(warmup, 1)):
                     step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -195,22 +320,22 @@ def main():
                 print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
                 graph = None
                 torch.cuda.synchronize()
-        if graph is None:
-            for _ in range(args.warmup):
-                step()
-        else:
-            for _ in range(args.warmup):
+        for _ in range(warmup):
+            if graph is None:
+                loss = step()
+            else:
                 graph.replay()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             if graph is None:
                 loss = step()
             else:
                 graph.replay()
+        t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -220,23 +345,60 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = tt.item()
-        return elapsed, graph, loss
+        return elapsed, graph, loss, t_host
 
-    elapsed, graph, loss = measure()
+    n_total = args.points * world if args.scaling == "weak" else args.points
+    use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    model, step = build(n_total, args.atten_dropout, args.parallel)
+    elapsed, graph, loss, t_host_main = measure(step, args.steps, args.warmup, use_graph)
+
     secondary = None
-    if world == 1 and args.atten_dropout > 0.0 and not args.no_secondary:
-        # the same step with the dropout switched off (what the kernels do in eval mode / atten_dropout = 0)
-        for mod in model.modules():
-            if hasattr(mod, "atten_dropout"):
-                mod.atten_dropout = 0.0
-        e2, g2, _ = measure()
-        secondary = dict(ms_per_step=e2 / args.steps * 1e3, value=n_total / (e2 / args.steps), atten_dropout=0.0)
-        del g2
-        for mod in model.modules():
-            if hasattr(mod, "atten_dropout"):
-                mod.atten_dropout = args.atten_dropout
+    fp32_mode = None
+    weak = None
+    if world == 1 and not args.no_secondary:
+        if args.atten_dropout > 0.0:
+            # the same step with the dropout switched off (what the kernels do in eval mode / atten_dropout = 0)
+            for mod in model.modules():
+                if hasattr(mod, "atten_dropout"):
+                    mod.atten_dropout = 0.0
+            e2, g2, _, _ = measure(step, args.steps, args.warmup, use_graph)
+            secondary = dict(ms_per_step=e2 / args.steps * 1e3, value=n_total / (e2 / args.steps), atten_dropout=0.0)
+            del g2
+            for mod in model.modules():
+                if hasattr(mod, "atten_dropout"):
+                    mod.atten_dropout = args.atten_dropout
+        if args.precision != "fp32":
+            # the reference's own arithmetic is fp32 end to end: the same step on the exact-fp32 MFMA kernels
+            try:
+                gaot_3d_amd.set_precision("fp32")
+                k3 = max(2, min(args.steps, 3))
+                e3, g3, _, _ = measure(step, k3, 1, use_graph)
+                fp32_mode = dict(ms_per_step=e3 / k3 * 1e3, value=n_total / (e3 / k3), dtype="f32", steps=k3)
+                del g3
+            except Exception as ex:
+                fp32_mode = dict(error=f"{type(ex).__name__}: {ex}")
+            finally:
+                gaot_3d_amd.set_precision(args.precision)
+    if world > 1 and not args.no_secondary:
+        other = "weak" if args.scaling == "strong" else "strong"
+        try:
+            n2 = args.points * world if other == "weak" else args.points
+            del model, step, graph
+            graph = None
+            torch.cuda.empty_cache()
+            model2, step2 = build(n2, args.atten_dropout, args.parallel)
+            k2 = max(2, min(args.steps, 5))
+            e2, _, _, _ = measure(step2, k2, 1, False)
+            weak = dict(scaling=other, points=n2, ms_per_step=e2 / k2 * 1e3, value=n2 / (e2 / k2), steps=k2)
+            model, step = model2, step2
+        except Exception as ex:
+            weak = dict(scaling=other, error=f"{type(ex).__name__}: {ex}")
+            model, step = build(n_total, args.atten_dropout, args.parallel)
+
     # per-kernel durations: HIP events around the instrumented launches of two more (eager) steps on the same stream
+    n_for_kernels = n_total if (weak is None or "error" in weak) else weak["points"]
     ops.timing_reset(True)
+    ops.launch_count_reset()
     t_e = time.perf_counter()
     for _ in range(2):
         step()
@@ -245,14 +407,14 @@ def main():
     t_eager = (time.perf_counter() - t_e) / 2
     n_timed_steps = 2
     timing = ops.timing_summary()
+    launches = ops.launch_count() / n_timed_steps
     ops.timing_reset(False)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        m_lat = latent[0] * latent[1] * latent[2]
-        s_tok = m_lat // 8
-        e = n_total * args.knn
-        work = algorithmic_work(n_total // world, m_lat, e // world, e // world, s_tok, args.layers)
+        e = n_for_kernels * args.knn
+        work = algorithmic_work(n_for_kernels // world, m_lat, e // world, e // world, s_tok, args.layers,
+                                heads=8 // world if (world > 1 and args.parallel != "replicated" and 8 % world == 0) else 8)
         peaks = {"mfma": (157.3 if args.precision == "fp32" else 2500.0, "TFLOP/s"), "hbm": (8000.0, "GB/s")}
         per_kernel = {}
         for name, (calls, tot_ms) in timing.items():
@@ -280,17 +442,47 @@ def main():
                 ach, (peak, unit), bound = d["tflops"], peaks["mfma"], "mfma"
             roof = dict(kernel=dom, bound=bound, achieved=round(ach, 3), peak=peak, unit=unit, frac=round(ach / peak, 4),
                         traffic=None, avg_ms=round(d["avg_ms"], 4))
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pass.sh); they are reported only
+            # when the committed file was measured on exactly these kernel sources, otherwise null
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    roof["traffic"] = json.load(open(pmc)).get(dom, {}).get("bytes_per_launch")
-                except Exception:
-                    pass
+            try:
+                pj = json.load(open(pmc))
+                src = pj.get("_source", {})
+                if src.get("csrc_sha16") == csrc_sha16() and world == 1:
+                    roof["traffic"] = pj.get(dom, {}).get("bytes_per_launch")
+                    roof["traffic_source"] = f"profiles/pmc_traffic.json (tag {src.get('tag')}, csrc {src.get('csrc_sha16')})"
+                else:
+                    roof["traffic_source"] = "profiles/pmc_traffic.json is from other kernel sources or another N: not reported"
+            except Exception:
+                pass
+        troof = step_roofline_ms(n_total // world, m_lat, n_total * args.knn // world, n_total * args.knn // world, s_tok,
+                                 args.layers, args.precision)
+        if world > 1:   # per-rank work of a perfectly divided step (Transformer rows / heads and points over the ranks)
+            troof["transformer_ms"] /= world
+            troof["adamw_ms"] = troof["adamw_ms"]
+            troof["t_roof_ms"] = troof["transformer_ms"] + troof["gno_ms"] + troof["per_node_ms"] + troof["adamw_ms"]
+        troof = {kk: round(v, 4) for kk, v in troof.items()}
+        troof["frac"] = round(troof["t_roof_ms"] / ms, 4)
+        if args.scaling == "strong":
+            metric = f"mesh-points/sec fwd+bwd, {n_total // 1000}K-pt DrivAerNet++ sample"
+            wl = "configs[1]" if world == 1 else f"configs[2] (the one sample split over {world} GPUs)"
+        else:
+            metric = (f"mesh-points/sec fwd+bwd, WEAK scaling: one {n_total // 1000}K-pt sample = {args.points // 1000}K points "
+                      f"per GPU x {world} GPUs")
+            wl = f"configs[1] x {world} points"
+        shard_txt = "none"
+        if world > 1:
+            shard_txt = {"seq": f"point-shard x{world}; latent Transformer split by token rows, attention by heads "
+                                f"(all-to-all), weight gradients all-reduced",
+                         "head": f"point-shard x{world}; latent Transformer replicated except the attention heads "
+                                 f"(all-gather of head outputs)",
+                         "replicated": f"point-shard x{world}; latent Transformer replicated"}[args.parallel]
         out = {
-            "metric": "mesh-points/sec fwd+bwd, 500K-pt DrivAerNet++ sample",
+            "metric": metric,
             "value": n_total / (elapsed / args.steps),
             "unit": "points/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
@@ -299,28 +491,34 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if world == 1 else ('configs[1] x ' + str(world) + ' points' if args.scaling == 'weak' else 'configs[2] (one sample split over ' + str(world) + ' GPUs)')}: one {n_total}-point car-like surface sample (pos+normals), latent "
+            "config": {"workload": f"{wl}: one {n_total}-point car-like surface sample (pos+normals), latent "
                                    f"{latent[0]}x{latent[1]}x{latent[2]}, knn k={args.knn} encoder + flipped decoder, "
                                    f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, attention dropout {args.atten_dropout} "
                                    f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step",
-                       "points": n_total, "latent_tokens": list(latent), "edges": e, "layers": args.layers,
+                       "points": n_total, "latent_tokens": list(latent), "edges": n_total * args.knn, "layers": args.layers,
                        "precision": args.precision, "points_per_gpu": n_total // world, "atten_dropout": args.atten_dropout,
-                       "sharding": f"point-shard x{world}; latent grid / Transformer replicated, attention heads split over the "
-                                   f"ranks (all-gather of head outputs)" if world > 1 else "none"},
+                       "sharding": shard_txt},
             "loss": float(loss.detach()),
             "launch": "hipGraph replay of one captured step" if graph is not None else "eager",
-            # wall time of the two instrumented eager steps (only meaningful without a captured graph: right after a
-            # capture the eager allocations go back to hipMalloc)
-            "instrumented_eager_ms_per_step": round(t_eager * 1e3, 3) if graph is None else None,
-            "instrumented_eager_host_ms_per_step": round(t_host * 1e3, 3) if graph is None else None,
+            "kernel_launches_per_step": launches,
+            "host_ms_per_step_timed_region": round(t_host_main / args.steps * 1e3, 3),
+            # wall / host time of the two instrumented eager steps (right after a capture the eager allocations go back
+            # to hipMalloc, so with a captured graph these overstate a warmed-up eager step)
+            "instrumented_eager_ms_per_step": round(t_eager * 1e3, 3),
+            "instrumented_eager_host_ms_per_step": round(t_host * 1e3, 3),
             "without_attention_dropout": secondary,
+            "fp32_mode": fp32_mode,
+            "other_scaling": weak,
             "roofline": roof,
+            "step_roofline": troof,
             "kernels": {kname: {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ent.items()}
                         for kname, ent in per_kernel.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.layers, args.knn, args.seed, args.atten_dropout)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline, args.layers, args.knn, args.seed, args.atten_dropout,
+                                               args.points, latent)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,6 +36,7 @@ _p, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_floa
 SIGNATURES = {
     "gaot_abi_version": (_i, []),
     "gaot_last_error": (C.c_char_p, []),
+    "gaot_launch_count": (_i64, [_i]),
     "gaot_csr_workspace_bytes": (_sz, [_i64, _i64]),
     "gaot_csr_build": (_i, [_p, _i, _i64, _i, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gaot_gno_fwd_workspace_bytes": (_sz, [_i64, _i]),
@@ -120,7 +121,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 3:
+    if lib.gaot_abi_version() != 4:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

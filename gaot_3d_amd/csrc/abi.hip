@@ -15,3 +15,10 @@ void gaot_set_error(const char* fmt, ...) {
 
 extern "C" const char* gaot_last_error(void) { return g_err; }
 extern "C" int gaot_abi_version(void) { return GAOT_ABI_VERSION; }
+
+long long g_gaot_launches = 0;
+extern "C" int64_t gaot_launch_count(int reset) {
+    const long long n = g_gaot_launches;
+    if (reset) g_gaot_launches = 0;
+    return (int64_t)n;
+}

@@ -74,7 +74,7 @@ extern "C" int gaot_adamw_step(const gaot_adamw_tensor_t* tensors, int num_tenso
     GAOT_CHECK_ARG(lr && step, "lr and step must be device pointers");
     GAOT_CHECK_ARG(num_tensors == 0 || tensors, "null tensor table");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adamw_tick, dim3(1), dim3(1), 0, st, step);
+    GAOT_KLAUNCH(k_adamw_tick, dim3(1), dim3(1), 0, st, step);
     for (int t0 = 0; t0 < num_tensors; t0 += AW_MAX) {
         AwTable tb;
         tb.count = 0;
@@ -91,7 +91,7 @@ extern "C" int gaot_adamw_step(const gaot_adamw_tensor_t* tensors, int num_tenso
         }
         tb.first_block[tb.count] = blocks;
         if (blocks)
-            hipLaunchKernelGGL(k_adamw, dim3(blocks), dim3(256), 0, st, tb, lr, (const float*)step, (float)beta1, (float)beta2,
+            GAOT_KLAUNCH(k_adamw, dim3(blocks), dim3(256), 0, st, tb, lr, (const float*)step, (float)beta1, (float)beta2,
                                (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     }
     GAOT_LAUNCH_CHECK();

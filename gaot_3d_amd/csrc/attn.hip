@@ -440,8 +440,8 @@ extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, flo
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     AttnArgs a{q, k, v, o, lse, ldq, ldk, ldv, ldo, B, S, H, HKV, scale, gdrop::make_drop(dropout_seed, dropout_p)};
     dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
-    if (a.drop.thr) hipLaunchKernelGGL(k_attn_fwd_f32<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_attn_fwd_f32<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (a.drop.thr) GAOT_KLAUNCH(k_attn_fwd_f32<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else GAOT_KLAUNCH(k_attn_fwd_f32<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -468,16 +468,16 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
     const bool drop = a.drop.thr != 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)B * S * H;
-    if (phase_mask & 1) hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a);
+    if (phase_mask & 1) GAOT_KLAUNCH(k_attn_delta, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, a);
     if (phase_mask & 2) {
         const dim3 g((unsigned)ceil_div(S, 128), (unsigned)HKV, (unsigned)B);
-        if (drop) hipLaunchKernelGGL(k_attn_bwd_dkv_f32<true>, g, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_attn_bwd_dkv_f32<false>, g, dim3(256), 0, st, a);
+        if (drop) GAOT_KLAUNCH(k_attn_bwd_dkv_f32<true>, g, dim3(256), 0, st, a);
+        else GAOT_KLAUNCH(k_attn_bwd_dkv_f32<false>, g, dim3(256), 0, st, a);
     }
     if (phase_mask & 4) {
         const dim3 g((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
-        if (drop) hipLaunchKernelGGL(k_attn_bwd_dq_f32<true>, g, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_attn_bwd_dq_f32<false>, g, dim3(256), 0, st, a);
+        if (drop) GAOT_KLAUNCH(k_attn_bwd_dq_f32<true>, g, dim3(256), 0, st, a);
+        else GAOT_KLAUNCH(k_attn_bwd_dq_f32<false>, g, dim3(256), 0, st, a);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -487,7 +487,7 @@ extern "C" int gaot_dropout_seed_next(unsigned long long* state, unsigned long l
                                       gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(state && out, "null pointer");
-    hipLaunchKernelGGL(k_seed_next, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, out);
+    GAOT_KLAUNCH(k_seed_next, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -498,7 +498,7 @@ extern "C" int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, fl
     GAOT_CHECK_ARG(B > 0 && H > 0 && S > 0 && dropout_seed && keep, "bad arguments");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0,1)");
     const int64_t n = (int64_t)B * H * S * S;
-    hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    GAOT_KLAUNCH(k_dropout_mask, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        gdrop::make_drop(dropout_seed, dropout_p), H, S, n, keep);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

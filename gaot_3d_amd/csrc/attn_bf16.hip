@@ -973,7 +973,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     const int ld = (H + 2 * HKV) * D;
     const int64_t rows = (int64_t)B * S;
     const int64_t n = rows * (ld / 2);
-    hipLaunchKernelGGL(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
+    GAOT_KLAUNCH(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                        HKV, S, rope_freqs, scale * LOG2E);
     // few heads (head-parallel ranks): split the key range over blockIdx.y so that the launch still fills the chip;
     // every part writes a normalised O / lse of its keys into the scratch behind the image, combined below
@@ -988,11 +988,11 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
     if (a.drop.thr)
-        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);   // 128-key stages: -2 % with the mask work
+        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);   // 128-key stages: -2 % with the mask work
     else
-        hipLaunchKernelGGL((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
+        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
     if (P > 1)
-        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)ceil_div(rows * H * 8, 256)), dim3(256), 0, st, o_parts, lse_parts,
+        GAOT_KLAUNCH(k_attn_combine, dim3((unsigned)ceil_div(rows * H * 8, 256)), dim3(256), 0, st, o_parts, lse_parts,
                            (int)fgrid.y, o_part, lse_part, B, S, H, o, lse);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -1026,7 +1026,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 1)
-        hipLaunchKernelGGL(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
+        GAOT_KLAUNCH(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
                            S, H);
     if (phase_mask & 2) {
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
@@ -1036,31 +1036,31 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         // live (at 4 per CU the dropout variant spills: 0.83 -> 0.49 ms at S = 16384, H = 4)
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
         if (kb_dkv) {
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<2, true>), g1, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<2, false>), g1, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<2, true>), g1, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<2, false>), g1, dim3(256), 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, true>), g1, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dkv_bf16<4, false>), g1, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<4, true>), g1, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<4, false>), g1, dim3(256), 0, st, a);
         }
     }
     if (phase_mask & 4) {
         const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), ny, (unsigned)B);
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
         if (kb_dq) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<2, true>), g1, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<2, false>), g1, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_bf16<2, true>), g1, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dq_bf16<2, false>), g1, dim3(256), 0, st, a);
         } else {
-            if (drop) hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, true>), g1, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_attn_bwd_dq_bf16<4, false>), g1, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_bf16<4, true>), g1, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_bwd_dq_bf16<4, false>), g1, dim3(256), 0, st, a);
         }
         if (P > 1)   // dK/dV (phase 2) and dQ parts are complete: fixed-order sum into dqkv
-            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)ceil_div(dqkv_part / 4, 256)), dim3(256), 0, st, parts, (int)ny, dqkv_part,
+            GAOT_KLAUNCH(k_sum_parts, dim3((unsigned)ceil_div(dqkv_part / 4, 256)), dim3(256), 0, st, parts, (int)ny, dqkv_part,
                                dqkv_part / 4, dqkv);
     }
     GAOT_LAUNCH_CHECK();

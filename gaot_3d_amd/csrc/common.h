@@ -15,6 +15,15 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 void gaot_set_error(const char* fmt, ...);
 
+// every kernel launch of the library goes through this macro: a process-wide launch counter (gaot_launch_count) lets the
+// host report launches per step without a profiler
+extern long long g_gaot_launches;
+#define GAOT_KLAUNCH(...)                \
+    do {                                 \
+        ++g_gaot_launches;               \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define GAOT_CHECK_ARG(cond, msg)                         \
     do {                                                  \
         if (!(cond)) {                                    \

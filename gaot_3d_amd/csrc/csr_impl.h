@@ -250,8 +250,8 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     }
     const int tb = 256;
     const int gb = (int)std::min<int64_t>(ceil_div(E, tb), 256 * 16);
-    hipLaunchKernelGGL((k_check_sorted<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, unsorted);
-    hipLaunchKernelGGL((k_sorted_build<IDX>), dim3(gb), dim3(tb), 0, st, keys, other, E, Q, unsorted, rowptr, perm,
+    GAOT_KLAUNCH((k_check_sorted<IDX>), dim3(gb), dim3(tb), 0, st, keys, E, unsorted);
+    GAOT_KLAUNCH((k_sorted_build<IDX>), dim3(gb), dim3(tb), 0, st, keys, other, E, Q, unsorted, rowptr, perm,
                        key_sorted, other_sorted);
     // general path (every kernel returns at once when the keys were sorted)
     const int bits = rs_bits(Q);
@@ -266,21 +266,21 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
         int* iout = (p & 1) ? ibuf1 : ibuf0;
         const int64_t n = (int64_t)nd * nblk;
         const int nb = (int)ceil_div(n, SCAN_TILE);
-        if (p == 0) hipLaunchKernelGGL((k_rs_hist<IDX>), dim3(nblk), dim3(256), 0, st, keys, E, shift, nd, nblk, table, unsorted);
-        else hipLaunchKernelGGL((k_rs_hist<int>), dim3(nblk), dim3(256), 0, st, kin, E, shift, nd, nblk, table, unsorted);
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum);
-        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum, tscan);
+        if (p == 0) GAOT_KLAUNCH((k_rs_hist<IDX>), dim3(nblk), dim3(256), 0, st, keys, E, shift, nd, nblk, table, unsorted);
+        else GAOT_KLAUNCH((k_rs_hist<int>), dim3(nblk), dim3(256), 0, st, kin, E, shift, nd, nblk, table, unsorted);
+        GAOT_KLAUNCH(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum);
+        GAOT_KLAUNCH(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
+        GAOT_KLAUNCH(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, table, n, bsum, tscan);
         if (p == 0)
-            hipLaunchKernelGGL((k_rs_scatter<IDX>), dim3(nblk), dim3(256), 0, st, keys, (const int*)nullptr, E, shift, width,
+            GAOT_KLAUNCH((k_rs_scatter<IDX>), dim3(nblk), dim3(256), 0, st, keys, (const int*)nullptr, E, shift, width,
                                nblk, tscan, kout, iout, unsorted);
         else
-            hipLaunchKernelGGL((k_rs_scatter<int>), dim3(nblk), dim3(256), 0, st, kin, iin, E, shift, width, nblk, tscan,
+            GAOT_KLAUNCH((k_rs_scatter<int>), dim3(nblk), dim3(256), 0, st, kin, iin, E, shift, width, nblk, tscan,
                                kout, iout, unsorted);
         kin = kout;
         iin = iout;
     }
-    hipLaunchKernelGGL((k_emit_sorted<IDX>), dim3(gb), dim3(tb), 0, st, kin, iin, other, E, Q, unsorted, rowptr, perm,
+    GAOT_KLAUNCH((k_emit_sorted<IDX>), dim3(gb), dim3(tb), 0, st, kin, iin, other, E, Q, unsorted, rowptr, perm,
                        key_sorted, other_sorted);
     return GAOT_OK;
 }

@@ -164,7 +164,7 @@ extern "C" int gaot_affine_cols(const float* x, const float* scale_minus_one, co
     GAOT_CHECK_ARG(rows >= 0 && C > 0, "bad shape");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(x && scale_minus_one && out, "null pointer");
-    hipLaunchKernelGGL(k_affine_cols, dim3((unsigned)ceil_div(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x,
+    GAOT_KLAUNCH(k_affine_cols, dim3((unsigned)ceil_div(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x,
                        scale_minus_one, bias, rows * C, C, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -176,7 +176,7 @@ extern "C" int gaot_gather_rows(const float* table, int64_t ld, const int* idx, 
     GAOT_CHECK_ARG(E >= 0 && C > 0 && ld >= C && ldo >= C, "bad shape");
     if (E == 0) return GAOT_OK;
     GAOT_CHECK_ARG(table && idx && out, "null pointer");
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div(E * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, table, ld, idx,
+    GAOT_KLAUNCH(k_gather_rows, dim3((unsigned)ceil_div(E * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, table, ld, idx,
                        E, C, out, ldo);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -188,7 +188,7 @@ extern "C" int gaot_segment_reduce(const float* vals, int64_t ldv, const int* ro
     GAOT_CHECK_ARG(R >= 0 && C > 0 && ldv >= C && mode >= 0 && mode <= 2, "bad shape / mode");
     if (R == 0) return GAOT_OK;
     GAOT_CHECK_ARG(rowptr && out, "null pointer");
-    hipLaunchKernelGGL(k_segment_reduce, dim3((unsigned)ceil_div(R * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, vals, ldv,
+    GAOT_KLAUNCH(k_segment_reduce, dim3((unsigned)ceil_div(R * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, vals, ldv,
                        rowptr, map, R, C, mode, out, argmax);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -208,10 +208,10 @@ extern "C" int gaot_segment_reduce_bwd(const float* d_out, const int* key, const
             return GAOT_ERR_LAUNCH;
         }
         if (R > 0)
-            hipLaunchKernelGGL(k_segment_max_bwd, dim3((unsigned)ceil_div(R * C, TPB)), dim3(TPB), 0, st, d_out, argmax, R, C, d_vals);
+            GAOT_KLAUNCH(k_segment_max_bwd, dim3((unsigned)ceil_div(R * C, TPB)), dim3(TPB), 0, st, d_out, argmax, R, C, d_vals);
     } else {
         GAOT_CHECK_ARG(key, "sum / mean need the row of every edge");
-        hipLaunchKernelGGL(k_segment_bcast, dim3((unsigned)ceil_div(E * C, TPB)), dim3(TPB), 0, st, d_out, key, rowptr, E, C,
+        GAOT_KLAUNCH(k_segment_bcast, dim3((unsigned)ceil_div(E * C, TPB)), dim3(TPB), 0, st, d_out, key, rowptr, E, C,
                            mode == 1, d_vals);
     }
     GAOT_LAUNCH_CHECK();
@@ -222,7 +222,7 @@ extern "C" int gaot_segment_softmax_fwd(const float* scores, const int* rowptr, 
     GAOT_ENTER();
     if (R <= 0) return GAOT_OK;
     GAOT_CHECK_ARG(rowptr && w, "null pointer");
-    hipLaunchKernelGGL(k_segment_softmax_fwd, dim3((unsigned)ceil_div(R, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, scores,
+    GAOT_KLAUNCH(k_segment_softmax_fwd, dim3((unsigned)ceil_div(R, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, scores,
                        rowptr, R, w);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -233,7 +233,7 @@ extern "C" int gaot_segment_softmax_bwd(const float* w, const float* dw, const i
     GAOT_ENTER();
     if (R <= 0) return GAOT_OK;
     GAOT_CHECK_ARG(rowptr && ds, "null pointer");
-    hipLaunchKernelGGL(k_segment_softmax_bwd, dim3((unsigned)ceil_div(R, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, w, dw,
+    GAOT_KLAUNCH(k_segment_softmax_bwd, dim3((unsigned)ceil_div(R, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, w, dw,
                        rowptr, R, ds);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -246,7 +246,7 @@ extern "C" int gaot_edge_coords(const float* y_pos, const float* x_pos, const in
     GAOT_CHECK_ARG(ldo >= (mode == 0 ? 6 : mode == 1 ? 3 : 1), "ldo too small for the mode");
     if (E == 0) return GAOT_OK;
     GAOT_CHECK_ARG(y_pos && x_pos && src && dst && out, "null pointer");
-    hipLaunchKernelGGL(k_edge_coords, dim3((unsigned)ceil_div(E, TPB)), dim3(TPB), 0, (hipStream_t)stream, y_pos, x_pos, src,
+    GAOT_KLAUNCH(k_edge_coords, dim3((unsigned)ceil_div(E, TPB)), dim3(TPB), 0, (hipStream_t)stream, y_pos, x_pos, src,
                        dst, E, mode, out, ldo);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -258,7 +258,7 @@ extern "C" int gaot_mul(const float* a, const float* b, int64_t rows, int C, int
     GAOT_CHECK_ARG(rows >= 0 && C > 0, "bad shape");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(a && b && out, "null pointer");
-    hipLaunchKernelGGL(k_mul, dim3((unsigned)ceil_div(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, b, rows * C, C,
+    GAOT_KLAUNCH(k_mul, dim3((unsigned)ceil_div(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, b, rows * C, C,
                        b_is_row_scalar, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -269,7 +269,7 @@ extern "C" int gaot_mul_rowsum(const float* a, const float* b, int64_t rows, int
     GAOT_CHECK_ARG(rows >= 0 && C > 0, "bad shape");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(a && b && out, "null pointer");
-    hipLaunchKernelGGL(k_mul_rowsum, dim3((unsigned)ceil_div(rows, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, a, b, rows, C,
+    GAOT_KLAUNCH(k_mul_rowsum, dim3((unsigned)ceil_div(rows, TPB / 64)), dim3(TPB), 0, (hipStream_t)stream, a, b, rows, C,
                        out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -281,7 +281,7 @@ void launch_cfg(const GemmArgs& g, int a_trans, int b_trans, int bf16, int a_vec
     const bool a_mc = a_trans != 0, b_nc = b_trans == 0;
 #define GAOT_GEMM_CASE(AM, BNc, BF)                                                                      \
     if (a_mc == AM && b_nc == BNc && (bf16 != 0) == BF) {                                                \
-        hipLaunchKernelGGL((k_gemm<WR, WC, MT, NT, AM, BNc, BF>), grid, dim3(256), 0, st, g, a_vec, b_vec); \
+        GAOT_KLAUNCH((k_gemm<WR, WC, MT, NT, AM, BNc, BF>), grid, dim3(256), 0, st, g, a_vec, b_vec); \
         return;                                                                                          \
     }
     GAOT_GEMM_CASE(false, false, false)
@@ -381,9 +381,9 @@ static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N
     else launch_cfg<2, 2, 2, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     if (gk.splits > 1) {
         if (gk.splits >= 64 && M * N <= 32768)
-            hipLaunchKernelGGL(k_splitk_reduce<16>, dim3((unsigned)ceil_div(M * N, 16)), dim3(256), 0, st, part, gk.splits, g);
+            GAOT_KLAUNCH(k_splitk_reduce<16>, dim3((unsigned)ceil_div(M * N, 16)), dim3(256), 0, st, part, gk.splits, g);
         else
-            hipLaunchKernelGGL(k_splitk_reduce<64>, dim3((unsigned)ceil_div(M * N, 64)), dim3(256), 0, st, part, gk.splits, g);
+            GAOT_KLAUNCH(k_splitk_reduce<64>, dim3((unsigned)ceil_div(M * N, 64)), dim3(256), 0, st, part, gk.splits, g);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

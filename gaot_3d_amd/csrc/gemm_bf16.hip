@@ -362,7 +362,7 @@ int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) 
     }
     dim3 grid((unsigned)ceil_div(g.M, BM), (unsigned)ceil_div(g.N, BN), (unsigned)splits);
     if (A_KS) grid = dim3((unsigned)(ceil_div(g.M, BM) * ceil_div(g.N, BN) * splits), 1, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
+    GAOT_KLAUNCH(kern, grid, dim3(256), lds, st, g, a_vec, b_vec);
     return GAOT_OK;
 }
 

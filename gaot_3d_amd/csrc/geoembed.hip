@@ -268,12 +268,12 @@ extern "C" int gaot_geoembed_stats(const float* source_pos, const float* query_p
     double* part = (double*)workspace;
     float* stats = (float*)(part + 256 * 2 * NF);
     const int64_t threads = num_queries * G;
-    hipLaunchKernelGGL(k_geo_raw, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, source_pos, query_pos,
+    GAOT_KLAUNCH(k_geo_raw, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, source_pos, query_pos,
                        rowptr_dst, src_sorted, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
-    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
-    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+    GAOT_KLAUNCH(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    GAOT_KLAUNCH(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
+    GAOT_KLAUNCH(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -285,7 +285,7 @@ extern "C" int gaot_geoembed_moments(const float* source_pos, const float* query
     GAOT_CHECK_ARG(num_queries >= 0, "negative size");
     if (num_queries == 0) return GAOT_OK;
     GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && moments, "null pointer");
-    hipLaunchKernelGGL(k_geo_moments, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, (hipStream_t)stream, source_pos,
+    GAOT_KLAUNCH(k_geo_moments, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, (hipStream_t)stream, source_pos,
                        query_pos, rowptr_dst, src_sorted, num_queries, moments);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -301,11 +301,11 @@ extern "C" int gaot_geoembed_from_moments(const double* moments, int64_t num_que
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)workspace;
     float* stats = (float*)(part + 256 * 2 * NF);
-    hipLaunchKernelGGL(k_geo_from_moments, dim3((unsigned)ceil_div(num_queries, 256)), dim3(256), 0, st, moments, num_queries, features);
+    GAOT_KLAUNCH(k_geo_from_moments, dim3((unsigned)ceil_div(num_queries, 256)), dim3(256), 0, st, moments, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
-    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
-    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+    GAOT_KLAUNCH(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    GAOT_KLAUNCH(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
+    GAOT_KLAUNCH(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -329,11 +329,11 @@ extern "C" int gaot_geoembed_raw(const float* source_pos, const float* query_pos
         return GAOT_OK;
     }
     GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && features, "null pointer");
-    hipLaunchKernelGGL(k_geo_raw, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, st, source_pos, query_pos,
+    GAOT_KLAUNCH(k_geo_raw, dim3((unsigned)ceil_div(num_queries * G, 256)), dim3(256), 0, st, source_pos, query_pos,
                        rowptr_dst, src_sorted, num_queries, features);
     const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
-    hipLaunchKernelGGL(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    hipLaunchKernelGGL(k_geo_colsums, dim3(1), dim3(256), 0, st, part, nb, colsums);
+    GAOT_KLAUNCH(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
+    GAOT_KLAUNCH(k_geo_colsums, dim3(1), dim3(256), 0, st, part, nb, colsums);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -347,8 +347,8 @@ extern "C" int gaot_geoembed_finalize(float* features, int64_t num_queries, cons
     GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* stats = (float*)((double*)workspace + 256 * 2 * NF);
-    hipLaunchKernelGGL(k_geo_stats_from_sums, dim3(1), dim3(64), 0, st, colsums, num_queries_total, stats);
-    hipLaunchKernelGGL(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
+    GAOT_KLAUNCH(k_geo_stats_from_sums, dim3(1), dim3(64), 0, st, colsums, num_queries_total, stats);
+    GAOT_KLAUNCH(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
                        num_queries, stats);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

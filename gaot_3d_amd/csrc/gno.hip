@@ -654,7 +654,7 @@ int launch_fwd(const MlpPtrs& p, const float* y_pos, const float* x_pos, const f
     }
     const int64_t n_macro = ceil_div(E, 32 * T);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_macro, 4), 256 * 2));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
     return GAOT_OK;
 }
 
@@ -669,7 +669,7 @@ int launch_bwd(const MlpPtrs& p, const MlpPtrs& pt, const float* y_pos, const fl
         gaot_set_error("gno_bwd: cannot set dynamic LDS %zu: %s", lds, hipGetErrorString(e));
         return GAOT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, pt, y_pos, x_pos, f_y, gs, src_s, dst_s,
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, p, pt, y_pos, x_pos, f_y, gs, src_s, dst_s,
                        rowptr_src, E, grad_f, part, wpart);
     return GAOT_OK;
 }
@@ -740,7 +740,7 @@ extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         if (rc != GAOT_OK) return rc;
     }
     const int64_t n = num_queries * 32;
-    hipLaunchKernelGGL((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_dst,
+    GAOT_KLAUNCH((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_dst,
                        num_queries, part, out, 1);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -797,7 +797,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         pt.w[l] = wt + off;
         pt.b[l] = p.b[l];
         if (num_edges > 0)
-            hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)ceil_div(out_dim * in_dim, 256)), dim3(256), 0, st, p.w[l],
+            GAOT_KLAUNCH(k_transpose_w, dim3((unsigned)ceil_div(out_dim * in_dim, 256)), dim3(256), 0, st, p.w[l],
                                out_dim, in_dim, wt + off);
         off += out_dim * in_dim;
     }
@@ -821,7 +821,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         hipMemsetAsync(flat, 0, sizeof(float) * total, st);
     } else {
         GAOT_CHECK_ARG(y_pos && x_pos && f_y && grad_out && src_sorted && dst_sorted && grad_f_y, "null pointer");
-        hipLaunchKernelGGL(k_scale_by_inv_deg, dim3((unsigned)ceil_div(num_queries * 8, 256)), dim3(256), 0, st, grad_out,
+        GAOT_KLAUNCH(k_scale_by_inv_deg, dim3((unsigned)ceil_div(num_queries * 8, 256)), dim3(256), 0, st, grad_out,
                            rowptr_dst, num_queries, gs);
         int rc = GAOT_OK;
         if (precision == 1) {
@@ -834,13 +834,13 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
             case 3: rc = launch_bwd<3, 64>(p, pt, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f_y, part, wpart, grid, st); break;
         }
         if (rc != GAOT_OK) return rc;
-        hipLaunchKernelGGL(k_reduce_params, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, st, wpart, n_waves,
+        GAOT_KLAUNCH(k_reduce_params, dim3((unsigned)ceil_div(total, 64)), dim3(256), 0, st, wpart, n_waves,
                            total, flat);
     }
-    hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, flat, sd);
+    GAOT_KLAUNCH(k_scatter_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, flat, sd);
     if (num_sources > 0) {
         const int64_t n = num_sources * 32;
-        hipLaunchKernelGGL((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
+        GAOT_KLAUNCH((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
                            num_sources, part, grad_f_y, 0);
     }
     GAOT_LAUNCH_CHECK();

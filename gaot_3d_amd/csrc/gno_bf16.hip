@@ -222,7 +222,7 @@ int launch_fwd_b(const MlpPtrs& p, const float* y_pos, const float* x_pos, const
     }
     const int64_t n_macro = ceil_div(E, 32 * T);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_macro, 4), 256 * 2));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
     return GAOT_OK;
 }
 
@@ -675,7 +675,7 @@ int launch_bwd_b(const BwdImgs& im, const MlpPtrs& p, const float* y_pos, const 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, im, p, y_pos, x_pos, f_y, gs, src_s, dst_s, rowptr_src, E,
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, im, p, y_pos, x_pos, f_y, gs, src_s, dst_s, rowptr_src, E,
                        grad_f, part, wpart);
     return GAOT_OK;
 }
@@ -693,7 +693,7 @@ int gaot_gno_bwd_bf16_dispatch(int n_hidden, const float* const* w, const float*
     MlpPtrs p;
     for (int l = 0; l <= n_hidden; ++l) { p.w[l] = w[l]; p.b[l] = b[l]; }
     bf16_t* base = (bf16_t*)images;
-    hipLaunchKernelGGL(k_prep_bwd_images, dim3(32), dim3(256), 0, st, p, n_hidden, base);
+    GAOT_KLAUNCH(k_prep_bwd_images, dim3(32), dim3(256), 0, st, p, n_hidden, base);
     const int per_hidden = 2 * 2 * 2 * 64 * 8, per_last = 2 * 2 * 64 * 8;
     BwdImgs im{};
     bf16_t* q = base;

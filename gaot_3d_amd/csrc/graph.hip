@@ -208,7 +208,7 @@ extern "C" int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_gr
     GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
-#define GAOT_KNN(KK) hipLaunchKernelGGL((k_knn_grid<KK>), grd, blk, 0, st, pos, num_points, g, token_pos, out_idx)
+#define GAOT_KNN(KK) GAOT_KLAUNCH((k_knn_grid<KK>), grd, blk, 0, st, pos, num_points, g, token_pos, out_idx)
     switch (k) {
         case 1: GAOT_KNN(1); break;
         case 2: GAOT_KNN(2); break;
@@ -238,7 +238,7 @@ extern "C" int gaot_radius_grid_count(const float* pos, int64_t num_points, cons
     GAOT_CHECK_ARG(num_points >= 0 && radius >= 0.f && cap >= 1, "bad argument");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && counts, "null pointer");
-    hipLaunchKernelGGL((k_radius_grid<false>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+    GAOT_KLAUNCH((k_radius_grid<false>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
                        num_points, g, token_pos, radius, cap, counts, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -253,7 +253,7 @@ extern "C" int gaot_radius_grid_fill(const float* pos, int64_t num_points, const
     GAOT_CHECK_ARG(num_points >= 0 && radius >= 0.f && cap >= 1, "bad argument");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && offsets && out_point && out_token, "null pointer");
-    hipLaunchKernelGGL((k_radius_grid<true>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+    GAOT_KLAUNCH((k_radius_grid<true>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
                        num_points, g, token_pos, radius, cap, (int*)nullptr, offsets, out_point, out_token);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -274,9 +274,9 @@ extern "C" int gaot_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* ou
     GAOT_CHECK_ARG(in && workspace && workspace_bytes >= gaot_exclusive_scan_workspace_bytes(n), "workspace too small");
     const int nb = (int)ceil_div(n, SCAN_TILE);
     int* bsum = (int*)workspace;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, bsum);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, bsum, out);
+    GAOT_KLAUNCH(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, bsum);
+    GAOT_KLAUNCH(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st, bsum, nb);
+    GAOT_KLAUNCH(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, bsum, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -287,7 +287,7 @@ extern "C" int gaot_segment_cap_flags(const int32_t* rowptr, const int32_t* key_
     GAOT_CHECK_ARG(n >= 0 && cap >= 1, "bad argument");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(rowptr && key_sorted && flags, "null pointer");
-    hipLaunchKernelGGL(k_segment_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, key_sorted,
+    GAOT_KLAUNCH(k_segment_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, key_sorted,
                        n, cap, flags);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -301,7 +301,7 @@ extern "C" int gaot_random_keep_flags(const unsigned long long* seed, int64_t n,
     GAOT_CHECK_ARG(seed && flags, "null pointer");
     double t = keep_prob * 4294967296.0 + 0.5;
     const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
-    hipLaunchKernelGGL(k_random_keep_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, n, thr, flags);
+    GAOT_KLAUNCH(k_random_keep_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, n, thr, flags);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -312,7 +312,7 @@ extern "C" int gaot_segment_random_cap_flags(const unsigned long long* seed, con
     GAOT_CHECK_ARG(n >= 0 && cap >= 1, "bad argument");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(seed && rowptr && key_sorted && flags, "null pointer");
-    hipLaunchKernelGGL(k_segment_random_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+    GAOT_KLAUNCH(k_segment_random_cap_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed,
                        rowptr, key_sorted, n, cap, flags);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -323,7 +323,7 @@ extern "C" int gaot_unique_pair_flags(const int32_t* a, const int32_t* b, int64_
     GAOT_CHECK_ARG(n >= 0, "negative size");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(a && b && flags, "null pointer");
-    hipLaunchKernelGGL(k_unique_pair_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, flags);
+    GAOT_KLAUNCH(k_unique_pair_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, flags);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -334,7 +334,7 @@ extern "C" int gaot_compact_pairs(const int32_t* a, const int32_t* b, const int3
     GAOT_CHECK_ARG(n >= 0, "negative size");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(a && b && flags && offsets && out_a && out_b, "null pointer");
-    hipLaunchKernelGGL(k_compact_pairs, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, flags, offsets, n,
+    GAOT_KLAUNCH(k_compact_pairs, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, flags, offsets, n,
                        out_a, out_b);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

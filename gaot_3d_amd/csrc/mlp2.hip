@@ -321,10 +321,10 @@ template <int NOB>
 int fwd_oc(const Mlp2Args& a, int oc, float* out, hipStream_t st) {
     const int grid = (int)std::min<int64_t>(ceil_div(a.N, MLP_ROWS), 2048);
     switch (oc) {
-        case 1: hipLaunchKernelGGL((k_mlp2_fwd<NOB, 1>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
-        case 2: hipLaunchKernelGGL((k_mlp2_fwd<NOB, 2>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
-        case 3: hipLaunchKernelGGL((k_mlp2_fwd<NOB, 3>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
-        case 4: hipLaunchKernelGGL((k_mlp2_fwd<NOB, 4>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
+        case 1: GAOT_KLAUNCH((k_mlp2_fwd<NOB, 1>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
+        case 2: GAOT_KLAUNCH((k_mlp2_fwd<NOB, 2>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
+        case 3: GAOT_KLAUNCH((k_mlp2_fwd<NOB, 3>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
+        case 4: GAOT_KLAUNCH((k_mlp2_fwd<NOB, 4>), dim3(grid), dim3(256), 0, st, a, out); return GAOT_OK;
     }
     return GAOT_ERR_UNSUPPORTED;
 }
@@ -341,7 +341,7 @@ int bwd_launch(const Mlp2Args& a, const float* dout, float* dx, float* wpart, in
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, dout, dx, wpart);
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, a, dout, dx, wpart);
     return GAOT_OK;
 }
 template <int NOB>
@@ -408,9 +408,9 @@ extern "C" int gaot_mlp2_bwd(const float* x, int64_t num_rows, int in_dim, int h
     if (rc != GAOT_OK) return rc;
     // partial layout [dW1 | db1 | dW2] -> the three outputs (contiguous pieces of one reduction)
     const int64_t n1 = (int64_t)hidden * MLP_IN, n2 = hidden, n3 = (int64_t)out_dim * hidden;
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n1, 64)), dim3(256), 0, st, wpart, grid, np, n1, d_w1);
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n2, 64)), dim3(256), 0, st, wpart + n1, grid, np, n2, d_b1);
-    hipLaunchKernelGGL(k_mlp2_reduce, dim3((unsigned)ceil_div(n3, 64)), dim3(256), 0, st, wpart + n1 + n2, grid, np, n3, d_w2);
+    GAOT_KLAUNCH(k_mlp2_reduce, dim3((unsigned)ceil_div(n1, 64)), dim3(256), 0, st, wpart, grid, np, n1, d_w1);
+    GAOT_KLAUNCH(k_mlp2_reduce, dim3((unsigned)ceil_div(n2, 64)), dim3(256), 0, st, wpart + n1, grid, np, n2, d_b1);
+    GAOT_KLAUNCH(k_mlp2_reduce, dim3((unsigned)ceil_div(n3, 64)), dim3(256), 0, st, wpart + n1 + n2, grid, np, n3, d_w2);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

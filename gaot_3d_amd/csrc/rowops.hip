@@ -462,7 +462,7 @@ extern "C" int gaot_rmsnorm_fwd(const float* x, const float* weight, float* y, f
     GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0, "dim must be a positive multiple of 4");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(x && weight && y, "null pointer");
-    hipLaunchKernelGGL(k_rmsnorm_fwd, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, weight, y,
+    GAOT_KLAUNCH(k_rmsnorm_fwd, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, weight, y,
                        rstd, (unsigned short*)y_bf16, rows, dim, eps);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -486,9 +486,9 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     GAOT_CHECK_ARG(x && weight && dy && rstd && dx && dweight && workspace, "null pointer");
     const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
+    GAOT_KLAUNCH(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
                        dx_add, dx, part, rows, dim);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
+    GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -514,12 +514,12 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
     const int64_t rpc = ceil_div(M, chunks);
     float* part = (float*)workspace;
     if (N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)
-        hipLaunchKernelGGL(k_colsum_part4, dim3((unsigned)ceil_div(N, 128), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
+        GAOT_KLAUNCH(k_colsum_part4, dim3((unsigned)ceil_div(N, 128), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
                            rpc, part);
     else
-        hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
+        GAOT_KLAUNCH(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
                            rpc, part);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
+    GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -535,7 +535,7 @@ extern "C" int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nhead
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(x && freqs, "null pointer");
     const int64_t n = rows * nheads * 16;
-    hipLaunchKernelGGL(k_rope, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, rows, ld, col0, nheads, seq_len,
+    GAOT_KLAUNCH(k_rope, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, rows, ld, col0, nheads, seq_len,
                        freqs, inverse ? -1.f : 1.f);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -546,7 +546,7 @@ extern "C" int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, g
     GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(ag && u, "null pointer");
-    hipLaunchKernelGGL(k_swiglu_fwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, u, rows, F);
+    GAOT_KLAUNCH(k_swiglu_fwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, u, rows, F);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -556,7 +556,7 @@ extern "C" int gaot_swiglu_bwd(const float* ag, const float* du, float* dag, int
     GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(ag && du && dag, "null pointer");
-    hipLaunchKernelGGL(k_swiglu_bwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, du, dag,
+    GAOT_KLAUNCH(k_swiglu_bwd, dim3(blocks_for(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, ag, du, dag,
                        rows, F);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -569,7 +569,7 @@ extern "C" int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_strea
     GAOT_CHECK_ARG(src && dst, "null pointer");
     GAOT_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "buffers must be 16-byte aligned");
     const int64_t n8 = n / 8;
-    hipLaunchKernelGGL(k_cast_bf16, dim3(blocks_for(n8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n8, n);
+    GAOT_KLAUNCH(k_cast_bf16, dim3(blocks_for(n8 + 1)), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n8, n);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -595,7 +595,7 @@ extern "C" int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_t
             blocks += (int)ceil_div(e.numel / 8 + 1, 256);
         }
         tb.first_block[tb.count] = blocks;
-        if (tb.count) hipLaunchKernelGGL(k_cast_bf16_multi, dim3(blocks), dim3(256), 0, st, tb);
+        if (tb.count) GAOT_KLAUNCH(k_cast_bf16_multi, dim3(blocks), dim3(256), 0, st, tb);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -607,7 +607,7 @@ extern "C" int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(ag && u, "null pointer");
     GAOT_CHECK_ARG((((uintptr_t)ag | (uintptr_t)u) & 15) == 0, "buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(k_swiglu_fwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+    GAOT_KLAUNCH(k_swiglu_fwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)ag, (unsigned short*)u, rows, F);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -619,7 +619,7 @@ extern "C" int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, i
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(ag && du && dag, "null pointer");
     GAOT_CHECK_ARG((((uintptr_t)ag | (uintptr_t)du | (uintptr_t)dag) & 15) == 0, "buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(k_swiglu_bwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+    GAOT_KLAUNCH(k_swiglu_bwd_bf16, dim3(blocks_for(rows * (F / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)ag, (const unsigned short*)du, (unsigned short*)dag, rows, F);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -630,7 +630,7 @@ extern "C" int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t 
     GAOT_CHECK_ARG(n >= 0 && act >= 0 && act <= 3, "bad argument");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(z && dh && dz, "null pointer");
-    hipLaunchKernelGGL(k_act_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, act);
+    GAOT_KLAUNCH(k_act_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, act);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -641,7 +641,7 @@ extern "C" int gaot_axpy(const float* a, const float* b, float alpha, float* out
     GAOT_CHECK_ARG(n >= 0 && period > 0, "bad argument");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(a && b && out, "null pointer");
-    hipLaunchKernelGGL(k_axpy, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n, period);
+    GAOT_KLAUNCH(k_axpy, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n, period);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -654,7 +654,7 @@ extern "C" int gaot_patchify(const float* src, float* dst, int B, int Dd, int Hh
     GAOT_CHECK_ARG(C % 4 == 0, "channels must be a multiple of 4");
     GAOT_CHECK_ARG(src && dst, "null pointer");
     const int64_t total = (int64_t)B * Dd * Hh * Ww * (C / 4);
-    hipLaunchKernelGGL(k_patchify, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, Dd, Hh, Ww, P,
+    GAOT_KLAUNCH(k_patchify, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, Dd, Hh, Ww, P,
                        C, to_tokens);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -670,8 +670,8 @@ extern "C" int gaot_mse_fwd(const float* pred, const float* target, int64_t n, f
     const int nb = (int)std::min<int64_t>(1024, ceil_div(n, 256));
     double* part = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mse_part, dim3(nb), dim3(256), 0, st, pred, target, n, part);
-    hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, st, part, nb, 1.0 / (double)n, loss);
+    GAOT_KLAUNCH(k_mse_part, dim3(nb), dim3(256), 0, st, pred, target, n, part);
+    GAOT_KLAUNCH(k_mse_final, dim3(1), dim3(64), 0, st, part, nb, 1.0 / (double)n, loss);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -681,7 +681,7 @@ extern "C" int gaot_mse_bwd(const float* pred, const float* target, int64_t n, c
     GAOT_ENTER();
     GAOT_CHECK_ARG(n > 0, "empty input");
     GAOT_CHECK_ARG(pred && target && grad_loss && dpred, "null pointer");
-    hipLaunchKernelGGL(k_mse_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, grad_loss,
+    GAOT_KLAUNCH(k_mse_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, grad_loss,
                        (float)(2.0 / (double)n), dpred);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -700,7 +700,7 @@ extern "C" int gaot_scale_mix_fwd(const float* const* xs, int num_scales, const 
     GAOT_CHECK_ARG(xs && logits && out && weights, "null pointer");
     ScalePtrs p{};
     for (int s = 0; s < num_scales; ++s) p.x[s] = xs[s];
-    hipLaunchKernelGGL(k_scale_mix_fwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales, logits,
+    GAOT_KLAUNCH(k_scale_mix_fwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales, logits,
                        out, weights, n);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -718,7 +718,7 @@ extern "C" int gaot_scale_mix_bwd(const float* const* xs, int num_scales, const 
     GAOT_CHECK_ARG(xs && weights && dout && dxs && dlogits, "null pointer");
     ScalePtrs p{};
     for (int s = 0; s < num_scales; ++s) { p.x[s] = xs[s]; p.dx[s] = dxs[s]; }
-    hipLaunchKernelGGL(k_scale_mix_bwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales,
+    GAOT_KLAUNCH(k_scale_mix_bwd, dim3(blocks_for(n * 32)), dim3(256), 0, (hipStream_t)stream, p, num_scales,
                        weights, dout, dlogits, n);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -178,12 +178,7 @@ def rescale(x: Tensor, lims=(-1.0, 1.0)) -> Tensor:
     return (x - x.min()) / (x.max() - x.min()) * (lims[1] - lims[0]) + lims[0]
 
 
-def make_synthetic_sample(n_points: int, latent_tokens: Sequence[int], k: int = 8, in_normals: bool = True,
-                          out_channels: int = 1, seed: int = 0, surface: bool = True,
-                          device: str = "cpu") -> Tuple[MeshBatch, Tensor]:
-    """Seeded synthetic sample of the BASELINE shapes (SURVEY §8d): points on a car-like surface
-    (or uniform in the cube), rescaled to [-1,1]; ``c`` = unit normals; knn(k) encoder edges
-    (phys-major) and the flipped list as decoder edges; N(0,1) target.  Returns (batch, tokens_pos)."""
+def _synthetic_fields(n_points: int, out_channels: int, seed: int, surface: bool):
     g = torch.Generator().manual_seed(seed)
     if surface:
         pos, nrm = superellipsoid_surface(n_points, generator=g)
@@ -193,6 +188,37 @@ def make_synthetic_sample(n_points: int, latent_tokens: Sequence[int], k: int = 
         nrm = torch.randn(n_points, 3, generator=g)
         nrm = nrm / nrm.norm(dim=1, keepdim=True)
     x = torch.randn(n_points, out_channels, generator=g)
+    return pos, nrm, x
+
+
+def make_synthetic_shard(n_points: int, latent_tokens: Sequence[int], rank: int, world: int, k: int = 8,
+                         in_normals: bool = True, out_channels: int = 1, seed: int = 0, surface: bool = True,
+                         device: str = "cpu") -> Tuple[MeshBatch, Tensor]:
+    """Rank ``rank``'s share of ``make_synthetic_sample(n_points, ...)`` -- identical values to
+    ``sharding.shard_batch`` of the whole sample -- without ever holding the whole sample on the device: the host
+    draws the per-point fields (7 floats a point; the global rescale needs all of them), the rank's contiguous point
+    range goes to the device and only ITS edges are built there."""
+    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface)
+    lo, hi = (n_points * rank) // world, (n_points * (rank + 1)) // world
+    pos_d = pos[lo:hi].contiguous().to(device)
+    enc = knn_edges_grid(pos_d, latent_tokens, (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), k)
+    b = MeshBatch(pos=pos_d, x=x[lo:hi].contiguous().to(device), batch=torch.zeros(hi - lo, dtype=torch.long, device=device),
+                  encoder_edge_index_s0=enc.to(torch.int32), decoder_edge_index_s0=enc.flip(0).to(torch.int32))
+    if in_normals:
+        b.c = nrm[lo:hi].contiguous().to(device)
+    b.num_graphs = 1
+    b.shard = (rank, world, lo, hi, n_points)
+    b.ptr = torch.tensor([0, hi - lo], dtype=torch.long, device=device)
+    return b, latent_grid(latent_tokens).to(device)
+
+
+def make_synthetic_sample(n_points: int, latent_tokens: Sequence[int], k: int = 8, in_normals: bool = True,
+                          out_channels: int = 1, seed: int = 0, surface: bool = True,
+                          device: str = "cpu") -> Tuple[MeshBatch, Tensor]:
+    """Seeded synthetic sample of the BASELINE shapes (SURVEY §8d): points on a car-like surface
+    (or uniform in the cube), rescaled to [-1,1]; ``c`` = unit normals; knn(k) encoder edges
+    (phys-major) and the flipped list as decoder edges; N(0,1) target.  Returns (batch, tokens_pos)."""
+    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface)
     pos_d = pos.to(device)
     enc = knn_edges_grid(pos_d, latent_tokens, (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), k)
     b = MeshBatch(pos=pos_d, x=x.to(device), batch=torch.zeros(n_points, dtype=torch.long, device=device),

@@ -251,7 +251,7 @@ class AttentionFn(Function):
 
     @staticmethod
     def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, dropout_p: float = 0.0,
-                head_group=None):
+                head_group=None, seed_rank: int = 0):
         """``head_group`` (extension, gaot_3d_amd/sharding.py): a process group whose ranks hold the SAME qkv (replicated
         Transformer of a point-sharded sample); rank r computes heads [r*h/G, (r+1)*h/G) only and the outputs are
         all-gathered, so the attention work -- 60 % of a 500 K-point step -- is divided by G instead of repeated G times."""
@@ -268,10 +268,10 @@ class AttentionFn(Function):
                 qkv = local_qkv(qkv, grk, gsz, h, hkv)
                 h, hkv = h // gsz, hkv // gsz
         seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
-        if seed is not None and ctx.hp is not None:
+        if seed is not None and (ctx.hp is not None or seed_rank):
             # the kernels key a head's mask by its LOCAL index: give every rank its own seed word so that the heads
-            # of different ranks do not share masks
-            seed = seed + ctx.hp[2] * 0x632BE59BD9B4E019 % (1 << 63)
+            # of different ranks do not share masks (seed_rank: the rank of a sequence-parallel caller)
+            seed = seed + (ctx.hp[2] if ctx.hp is not None else seed_rank) * 0x632BE59BD9B4E019 % (1 << 63)
         if bf16:
             o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed)
             keep = img
@@ -308,7 +308,7 @@ class AttentionFn(Function):
             from .sharding import gather_qkv_grads
             group, gsz, grk, hg, kg = ctx.hp
             dqkv = gather_qkv_grads(dqkv, group, gsz, hg, kg)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 class SwiGLUFn(Function):

@@ -77,14 +77,32 @@ class GAOT3D(nn.Module):
         s = (d // p) * (h // p) * (w // p)
         tok = p * p * p * c
         x = GF.PatchifyFn.apply(rndata, b, d, h, w, p, c, True).view(b * s, tok)
+        seq_group = getattr(self, "_seq_group", None)
+        s_loc, pe = s, None
+        if self.positional_embedding_name == "absolute":
+            pe = self._absolute_pe(x.device)
+        if seq_group is not None:
+            # sequence-parallel Transformer of a point-sharded sample (gaot_3d_amd/sharding.py): every row-wise operator
+            # from here to the un-patchify runs on this rank's S/G token rows
+            import torch.distributed as dist
+            from ..sharding import AllGatherRowsFn, SliceRowsFn
+            assert b == 1, "sequence-parallel processing splits ONE sample"
+            x = SliceRowsFn.apply(x, seq_group)
+            s_loc = x.shape[0]
+            if pe is not None:
+                r0 = dist.get_rank(seq_group) * s_loc
+                pe = pe[r0:r0 + s_loc].contiguous()
         x = GF.linear(x, self.patch_linear.weight, self.patch_linear.bias)
         relative_positions = None
-        if self.positional_embedding_name == "absolute":
-            x = GF.AddFn.apply(x, self._absolute_pe(x.device), s * tok)
+        if pe is not None:
+            x = GF.AddFn.apply(x, pe, s_loc * tok)
         elif self.positional_embedding_name == "rope":
             relative_positions = True  # the reference passes the 3-D positions only as an on/off flag
-        x = self.processor(x.view(b, s, tok), condition=condition, relative_positions=relative_positions)
-        x = GF.PatchifyFn.apply(x.reshape(b * s, tok), b, d, h, w, p, c, False)
+        x = self.processor(x.view(b, s_loc, tok), condition=condition, relative_positions=relative_positions)
+        x = x.reshape(b * s_loc, tok)
+        if seq_group is not None:
+            x = AllGatherRowsFn.apply(x, seq_group)
+        x = GF.PatchifyFn.apply(x, b, d, h, w, p, c, False)
         return x.view(b, d * h * w, c)
 
     def forward(self, batch, tokens_pos: Optional[torch.Tensor] = None, tokens_batch_idx: Optional[torch.Tensor] = None,
@@ -113,7 +131,9 @@ class GAOT3D(nn.Module):
         rndata = self.process(rndata=rndata, condition=condition)
         flat = rndata.view(-1, self.node_latent_size)
         shard_group = getattr(self, "_shard_group", None)
-        if shard_group is not None:  # decoder runs on this rank's points only: its latent gradient is a partial sum
+        if shard_group is not None and getattr(self, "_seq_group", None) is None:
+            # decoder runs on this rank's points only: its latent gradient is a partial sum (sequence-parallel: the
+            # reduce-scatter inside process() already sums it)
             from ..sharding import AllReduceGradFn
             flat = AllReduceGradFn.apply(flat, shard_group)
         return self.decoder(rndata_flat=flat, phys_pos_query=q_pos, batch_idx_phys_query=q_bidx, latent_tokens_pos=lat,

@@ -94,7 +94,20 @@ class GroupQueryFlashAttention(nn.Module):
         GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
-        o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp, getattr(self, "_head_group", None))
+        seq_group = getattr(self, "_seq_group", None)
+        if seq_group is not None:
+            # sequence-parallel (gaot_3d_amd/sharding.py): x holds this rank's token rows; one all-to-all hands every rank
+            # ALL rows of ITS heads, the kernels run unchanged on them, a second all-to-all brings the rows back
+            import torch.distributed as dist
+            from ...sharding import HeadsToSeqFn, SeqToHeadsFn
+            g, r = dist.get_world_size(seq_group), dist.get_rank(seq_group)
+            assert b == 1, "sequence-parallel attention splits ONE sample"
+            qkv = SeqToHeadsFn.apply(qkv, seq_group, self.num_heads, self.num_kv_heads)
+            o = GF.AttentionFn.apply(qkv, freqs, b, s * g, self.num_heads // g, self.num_kv_heads // g, dp, None, r)
+            o = HeadsToSeqFn.apply(o, seq_group)
+        else:
+            o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp,
+                                     getattr(self, "_head_group", None))
         y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
 

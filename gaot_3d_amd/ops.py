@@ -576,3 +576,12 @@ def mlp2_backward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, dout: Tensor):
     check(lib.gaot_mlp2_bwd(_ptr(x), rows, x.shape[1], hid, oc, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(dout), _ptr(dx), _ptr(dw1),
                             _ptr(db1), _ptr(dw2), _ptr(ws), ws.numel(), _stream()), "gaot_mlp2_bwd")
     return dx, dw1, db1, dw2
+
+
+def launch_count_reset() -> None:
+    _lib.load().gaot_launch_count(1)
+
+
+def launch_count() -> int:
+    """kernel launches issued by the library since the last reset (ATen launches -- fills, cats, index plumbing -- excluded)"""
+    return int(_lib.load().gaot_launch_count(0))

@@ -24,13 +24,16 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 3
+#define GAOT_ABI_VERSION 4
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
 
 int gaot_abi_version(void);
 const char* gaot_last_error(void);
+/* kernel launches issued by this library in this process since the last reset (measurement aid for bench.py: the reference
+ * has no counterpart; its step is a few thousand ATen launches, src/trainer/optimizers.py:272-275) */
+int64_t gaot_launch_count(int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * Neighbour lists.  Replaces the implicit "group edges by index" of the scatter calls

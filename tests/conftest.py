@@ -20,3 +20,25 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_runtest_logreport(report):
+    """Keep the achieved errors: every `[parity] ...` line a test prints (max-abs / max-rel / cosine against the oracle or
+    the goldens) is appended to $GAOT_PARITY_LOG (default gpurun_out/parity_last.txt on a GPU box); tools/gpu_pass.sh
+    copies that file to profiles/parity_<tag>.txt."""
+    if report.when != "call":
+        return
+    lines = [ln for ln in (report.capstdout or "").splitlines() if ln.startswith("[parity]") or ln.startswith("[train]")]
+    if not lines:
+        return
+    path = os.environ.get("GAOT_PARITY_LOG")
+    if path is None:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        path = os.path.join(REPO, "gpurun_out", "parity_last.txt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a") as f:
+        f.write(f"# {report.nodeid} [{report.outcome}]\n")
+        for ln in lines:
+            f.write(ln + "\n")

@@ -156,15 +156,17 @@ def test_point_shard_plumbing_on_gpu_world1():
         loss = GF.mse_loss(pred, batch.x)
         loss.backward()
         ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-        model.zero_grad(set_to_none=True)
         local = sharding.shard_batch(batch, 0, 1, tokens.shape[0])
-        step = sharding.ShardedStep(model, dist.group.WORLD, 4096)
-        total = step.forward_backward(local, tokens)
-        torch.cuda.synchronize()
-        close("shard1/loss", total, loss, 1e-6, 1e-8)
-        for k, p in model.named_parameters():
-            if p.grad is not None:
-                close(f"shard1/grad/{k}", p.grad, ref[k], 1e-5, 1e-7)
+        for parallel in ("seq", "head", "replicated"):   # "seq" on RCCL: all_to_all_single, reduce_scatter_tensor, all-gather
+            model.zero_grad(set_to_none=True)
+            step = sharding.ShardedStep(model, dist.group.WORLD, 4096, parallel=parallel)
+            total = step.forward_backward(local, tokens)
+            torch.cuda.synchronize()
+            close(f"shard1/{parallel}/loss", total, loss, 1e-6, 1e-8)
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    close(f"shard1/{parallel}/grad/{k}", p.grad, ref[k], 1e-5, 1e-7)
+            step.release()
         # the RCCL form of the head-parallel exchange (all_gather_into_tensor) on the 1-rank group
         t = torch.randn(37, 96, device=DEV)
         assert torch.equal(GF._all_gather_stack(t, dist.group.WORLD, 1), t[None])
@@ -172,9 +174,11 @@ def test_point_shard_plumbing_on_gpu_world1():
         model.encoder._shard_group = None
         model.decoder._shard_group = None
         model._shard_group = None
+        model._seq_group = None
         for mod in model.modules():
             if hasattr(mod, "_head_group"):
                 mod._head_group = None
+                mod._seq_group = None
         if created:
             dist.destroy_process_group()
 
@@ -196,7 +200,8 @@ model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
 batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device="cuda:0")
 tokens = tokens.to(dev)
 local = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
-step = sharding.ShardedStep(model, dist.group.WORLD, 3001)
+step = sharding.ShardedStep(model, dist.group.WORLD, 3001, parallel=os.environ.get("GAOT_TEST_PARALLEL") or None)
+assert step.parallel == (os.environ.get("GAOT_TEST_PARALLEL") or "seq")
 loss = step.forward_backward(local, tokens)
 torch.cuda.synchronize()
 if rank == 0:
@@ -226,12 +231,14 @@ def small_config(dec_geo=None):
         latent_tokens=(8, 8, 4))
 
 
-@pytest.mark.parametrize("dec_geo", [False, True])
-def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo):
+@pytest.mark.parametrize("dec_geo,parallel", [(False, "seq"), (True, "seq"), (False, "head"), (True, "replicated")])
+def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel):
     """The N>1 path end to end on the real kernels: two processes (both on cuda:0, gloo) each take half of the points
     of one sample; loss and every parameter gradient must equal the unsharded step on the same model and sample.
-    Head-parallel attention is on (one of the two heads per rank); dec_geo adds the decoder-side GeoEmbed, whose
-    z-score runs over the points of both ranks."""
+    parallel = "seq": the latent Transformer runs on half of the token rows per rank with one of the two heads per rank
+    inside attention (all-to-all both ways, reduce-scatter of the decoder's latent gradient, all-reduced weight
+    gradients); "head": replicated Transformer with the attention heads split; dec_geo adds the decoder-side GeoEmbed,
+    whose z-score runs over the points of both ranks."""
     import json, subprocess
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
@@ -248,9 +255,11 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     out = tmp_path / "out.json"
-    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", GAOT_TEST_DEC_GEO="1" if dec_geo else "0")
+    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", GAOT_TEST_DEC_GEO="1" if dec_geo else "0",
+               GAOT_TEST_PARALLEL=parallel)
+    port = 29533 + ["seq", "head", "replicated"].index(parallel) * 2 + int(dec_geo)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29534" if dec_geo else "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
+                        "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))
     loss = loss.detach()

@@ -189,3 +189,94 @@ def test_head_parallel_exchange_two_ranks_matches_full_attention():
         out, grad = ret[r]
         assert torch.allclose(out, ref.detach(), rtol=1e-5, atol=1e-6)
         assert torch.allclose(grad, qkv.grad, rtol=1e-4, atol=1e-6)
+
+
+# ---- sequence-parallel Transformer exchange (sharding.SliceRowsFn / SeqToHeadsFn / HeadsToSeqFn / AllGatherRowsFn) -----
+def _seq_layer(x, wqkv, wo, s_total, h, hkv, group=None):
+    """one stand-in block on token rows: q|k|v projection, attention (all rows of the rank's heads), output projection"""
+    from gaot_3d_amd import sharding as sh
+    qkv = x @ wqkv.t()
+    if group is None:
+        o = _attn_math(qkv, s_total, h, hkv)
+    else:
+        world = dist.get_world_size(group)
+        loc = sh.SeqToHeadsFn.apply(qkv, group, h, hkv)
+        o = sh.HeadsToSeqFn.apply(_attn_math(loc, s_total, h // world, hkv // world), group)
+    return x + o @ wo.t()
+
+
+def _seq_problem():
+    g = torch.Generator().manual_seed(11)
+    s, h, hkv, d = 24, 4, 2, 48
+    x = torch.randn(s, d, generator=g)
+    wqkv = torch.randn((h + 2 * hkv) * 32, d, generator=g) * 0.2
+    wo = torch.randn(d, h * 32, generator=g) * 0.2
+    wdec = torch.randn(s, d, generator=g)       # stands for the decoder: every rank consumes the full latent grid
+    return s, h, hkv, x, wqkv, wo, wdec
+
+
+def _seq_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaot_3d_amd import sharding as sh
+        torch.set_num_threads(1)
+        s, h, hkv, x, wqkv, wo, wdec = _seq_problem()
+        x = x.requires_grad_(True)
+        wqkv, wo = wqkv.clone().requires_grad_(True), wo.clone().requires_grad_(True)
+        grp = dist.group.WORLD
+        rows = sh.SliceRowsFn.apply(x, grp)                      # replicated latent -> my token rows
+        y = _seq_layer(_seq_layer(rows, wqkv, wo, s, h, hkv, grp), wqkv, wo, s, h, hkv, grp)
+        full = sh.AllGatherRowsFn.apply(y, grp)                  # my rows -> replicated latent for the decoder
+        # every rank's "decoder" sees only its share of the loss (its physical points): partial gradients of `full`
+        share = (full * wdec)[rank::world].sum()
+        share.backward()
+        for p in (wqkv, wo):                                     # row-partial weight gradients -> flat SUM all-reduce
+            dist.all_reduce(p.grad)
+        ret[rank] = (full.detach(), x.grad.clone(), wqkv.grad.clone(), wo.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_parallel_exchange_two_ranks_matches_unsharded():
+    """world 2 over gloo: token rows split over the ranks, heads split inside attention (all-to-all both ways), rows
+    all-gathered for the replicated consumer; output, input gradient and weight gradients equal the unsharded layer"""
+    from gaot_3d_amd import sharding as sh
+    q = torch.arange(5 * 8 * 32, dtype=torch.float32).view(5, 8 * 32)
+    assert torch.equal(sh._unpack_heads(sh._pack_heads(q, 2, 4, 2), 2, 4, 2), q)
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_seq_worker, args=(world, port, ret), nprocs=world, join=True)
+    s, h, hkv, x, wqkv, wo, wdec = _seq_problem()
+    x = x.requires_grad_(True)
+    wqkv, wo = wqkv.requires_grad_(True), wo.requires_grad_(True)
+    y = _seq_layer(_seq_layer(x, wqkv, wo, s, h, hkv), wqkv, wo, s, h, hkv)
+    (y * wdec).sum().backward()
+    for r in range(world):
+        full, gx, gq, go = ret[r]
+        assert torch.allclose(full, y.detach(), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(gx, x.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(gq, wqkv.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(go, wo.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_bench_spawns_its_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` outside torchrun must start the ranks as a fresh child (before any GPU call), relay the
+    child's JSON line and exit 0; --dry-run keeps the ranks off the GPU (gloo rendezvous only)"""
+    import json
+    import subprocess
+    import bench
+    args = bench.parse_args(["--gpus", "4", "--steps", "3"])
+    cmd = bench.spawn_command(args, ["--gpus", "4", "--steps", "3"], 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert args.scaling == "strong"                     # BASELINE configs[2]: ONE 500K-point sample over the N GPUs
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "strong"

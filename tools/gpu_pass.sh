@@ -1,19 +1,22 @@
 #!/bin/bash
-# One GPU-box pass: parity tests, graph bench, eager rocprof kernel stats, PMC traffic passes.  usage: gpu_pass.sh <tag>
+# One GPU-box pass: parity tests, graph bench, eager rocprof kernel stats, PMC traffic passes.  usage: gpu_pass.sh <tag> [notests]
 tag=${1:-pass}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -5 > $out/${tag}_tests.log
+if [ "$2" != "notests" ]; then
+  rm -f $out/${tag}_parity.txt
+  GAOT_PARITY_LOG=$out/${tag}_parity.txt python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $out/${tag}_tests.log
+fi
 python bench.py --steps 10 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/${tag}_prof --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $out/${tag}_prof.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_prof --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-secondary > $out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-secondary > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-secondary > $out/${tag}_pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json > /dev/null 2>$out/${tag}_pmc.err
+python3 tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json $tag > /dev/null 2>$out/${tag}_pmc.err
 # keep only the small summaries of the traces
 find $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*_kernel_trace.csv" -delete
 find $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*_counter_collection.csv" -delete
-cat $out/${tag}_tests.log; head -c 1500 $out/${tag}_bench.json
+cat $out/${tag}_tests.log 2>/dev/null; head -c 1500 $out/${tag}_bench.json

@@ -2,7 +2,7 @@
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counter_collection.csv) into profiles/pmc_traffic.json:
 HBM-side bytes per launch for the kernels bench.py instruments.  Corrections per MI355X_MICROARCH.md §HBM:
 counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled (the raw
-value is kept alongside).  usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+value is kept alongside).  usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [tag]"""
 import collections, csv, glob, json, sys
 
 NAMES = [("k_attn_fwd_bf16", "attn_fwd"), ("k_attn_bwd_dkv_kb", "attn_bwd_dkv"), ("k_attn_bwd_dkv_bf16", "attn_bwd_dkv"), ("k_attn_bwd_dq_kb", "attn_bwd_dq"), ("k_attn_bwd_dq_bf16", "attn_bwd_dq"),
@@ -33,5 +33,10 @@ for k in sorted(set(fetch) | set(write)):
     f_raw, w_raw = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
     out[k] = dict(bytes_per_launch=2 * f_raw + w_raw, fetch_raw_bytes=f_raw, fetch_corrected_bytes=2 * f_raw,
                   write_bytes=w_raw, note="FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes")
+# provenance: bench.py reports these bytes only while the kernel sources still hash to this value
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["_source"] = dict(tag=sys.argv[4] if len(sys.argv) > 4 else None, csrc_sha16=bench.csrc_sha16())
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
