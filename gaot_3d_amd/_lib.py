@@ -82,6 +82,7 @@ SIGNATURES = {
     "gaot_segment_cap_flags": (_i, [_p, _p, _i64, _i, _p, _p]),
     "gaot_unique_pair_flags": (_i, [_p, _p, _i64, _p, _p]),
     "gaot_random_keep_flags": (_i, [_p, _i64, _d, _p, _p]),
+    "gaot_dropout": (_i, [_p, _p, _d, _i64, _p, _p]),
     "gaot_segment_random_cap_flags": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
     "gaot_compact_pairs": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "gaot_cast_bf16": (_i, [_p, _p, _i64, _p]),

@@ -34,13 +34,13 @@ __global__ void k_segment_reduce(const float* __restrict__ vals, int64_t ldv, co
     const int64_t r = i / C;
     const int c = (int)(i - r * C);
     const int lo = rowptr[r], hi = rowptr[r + 1];
-    if (mode == 2) {
+    if (mode >= 2) {   // 2: max, 3: min (first extremum wins; empty row -> 0, scatter_native.py:32-50)
         float best = 0.f;
         int arg = -1;
         for (int j = lo; j < hi; ++j) {
             const int e = map ? map[j] : j;
             const float v = vals[(int64_t)e * ldv + c];
-            if (arg < 0 || v > best) { best = v; arg = e; }
+            if (arg < 0 || (mode == 2 ? v > best : v < best)) { best = v; arg = e; }
         }
         out[i] = best;
         if (argmax) argmax[i] = arg;
@@ -185,7 +185,7 @@ extern "C" int gaot_gather_rows(const float* table, int64_t ld, const int* idx, 
 extern "C" int gaot_segment_reduce(const float* vals, int64_t ldv, const int* rowptr, const int* map, int64_t R, int C,
                                    int mode, float* out, int* argmax, gaot_stream_t stream) {
     GAOT_ENTER();
-    GAOT_CHECK_ARG(R >= 0 && C > 0 && ldv >= C && mode >= 0 && mode <= 2, "bad shape / mode");
+    GAOT_CHECK_ARG(R >= 0 && C > 0 && ldv >= C && mode >= 0 && mode <= 3, "bad shape / mode");
     if (R == 0) return GAOT_OK;
     GAOT_CHECK_ARG(rowptr && out, "null pointer");
     GAOT_KLAUNCH(k_segment_reduce, dim3((unsigned)ceil_div(R * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, vals, ldv,
@@ -197,12 +197,12 @@ extern "C" int gaot_segment_reduce(const float* vals, int64_t ldv, const int* ro
 extern "C" int gaot_segment_reduce_bwd(const float* d_out, const int* key, const int* rowptr, const int* argmax, int64_t R,
                                        int64_t E, int C, int mode, float* d_vals, gaot_stream_t stream) {
     GAOT_ENTER();
-    GAOT_CHECK_ARG(R >= 0 && E >= 0 && C > 0 && mode >= 0 && mode <= 2, "bad shape / mode");
+    GAOT_CHECK_ARG(R >= 0 && E >= 0 && C > 0 && mode >= 0 && mode <= 3, "bad shape / mode");
     if (E == 0) return GAOT_OK;
     GAOT_CHECK_ARG(d_out && d_vals && rowptr, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 2) {
-        GAOT_CHECK_ARG(argmax, "max needs the argmax of the forward");
+    if (mode >= 2) {
+        GAOT_CHECK_ARG(argmax, "max / min need the arg-extremum of the forward");
         if (hipMemsetAsync(d_vals, 0, sizeof(float) * (size_t)E * C, st) != hipSuccess) {
             gaot_set_error("gaot_segment_reduce_bwd: memset failed");
             return GAOT_ERR_LAUNCH;

@@ -140,6 +140,14 @@ __device__ __forceinline__ uint32_t sample_hash(unsigned long long seed, uint32_
     x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15;
     return x;
 }
+// element dropout (nn.Dropout of the reference's channel MLPs, mlp.py:268-272, 318-322): out = keep ? x / (1 - p) : 0 with
+// keep(i) = sample_hash(seed, i) >= thr; the backward applies the same mask to the gradient
+__global__ void k_dropout(const float* __restrict__ x, const unsigned long long* __restrict__ seed, uint32_t thr, float scale,
+                          int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = sample_hash(*seed, (uint32_t)i) >= thr ? x[i] * scale : 0.f;
+}
 // 'ratio': keep edge i with probability thr / 2^32
 __global__ void k_random_keep_flags(const unsigned long long* __restrict__ seed, int64_t n, uint32_t thr, int* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,6 +310,21 @@ extern "C" int gaot_random_keep_flags(const unsigned long long* seed, int64_t n,
     double t = keep_prob * 4294967296.0 + 0.5;
     const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
     GAOT_KLAUNCH(k_random_keep_flags, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, n, thr, flags);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_dropout(const float* x, const uint64_t* seed_, double p, int64_t n, float* out, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && p >= 0.0 && p < 1.0, "bad argument");
+    GAOT_CHECK_ARG(n < ((int64_t)1 << 32), "more than 2^32 elements");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(x && seed_ && out, "null pointer");
+    const unsigned long long* seed = (const unsigned long long*)seed_;
+    double t = p * 4294967296.0 + 0.5;
+    const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    GAOT_KLAUNCH(k_dropout, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, seed, thr,
+                 (float)(1.0 / (1.0 - p)), n, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -19,7 +19,7 @@ from ._lib import check
 from .ops import BipartiteGraph, _ptr, _req, _stream
 
 Tensor = torch.Tensor
-SUM, MEAN, MAX = 0, 1, 2
+SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 
 
 def _off(t: Tensor, elems: int) -> C.c_void_p:
@@ -55,7 +55,7 @@ def segment_reduce(vals: Tensor, rowptr: Tensor, pos_map: Optional[Tensor], num_
     vals = _req(vals, torch.float32, "vals")
     c = vals.shape[1] - col0 if channels is None else channels
     out = torch.empty(num_rows, c, dtype=torch.float32, device=vals.device)
-    arg = torch.empty(num_rows, c, dtype=torch.int32, device=vals.device) if (mode == MAX and want_argmax) else None
+    arg = torch.empty(num_rows, c, dtype=torch.int32, device=vals.device) if (mode in (MAX, MIN) and want_argmax) else None
     check(lib.gaot_segment_reduce(_off(vals, col0), vals.shape[1], _ptr(rowptr), _ptr(pos_map), num_rows, c, mode, _ptr(out),
                                   _ptr(arg), _stream()), "gaot_segment_reduce")
     return (out, arg) if want_argmax else out
@@ -140,13 +140,13 @@ class EdgeInputFn(Function):
 
 
 class SegmentReduceFn(Function):
-    """scatter(vals, dst, reduce) over the queries (scatter_native.py:4-54): sum / mean / max, empty rows -> 0"""
+    """scatter(vals, dst, reduce) over the queries (scatter_native.py:4-54): sum / mean / max / min, empty rows -> 0"""
 
     @staticmethod
     def forward(ctx, vals: Tensor, g: BipartiteGraph, mode: int):
         ctx.g, ctx.mode, ctx.shape = g, mode, tuple(vals.shape)
-        if mode == MAX:
-            out, arg = segment_reduce(vals, g.by_dst.rowptr, None, g.num_dst, MAX, want_argmax=True)
+        if mode in (MAX, MIN):
+            out, arg = segment_reduce(vals, g.by_dst.rowptr, None, g.num_dst, mode, want_argmax=True)
             ctx.save_for_backward(arg)
             return out
         return segment_reduce(vals, g.by_dst.rowptr, None, g.num_dst, mode)
@@ -158,10 +158,76 @@ class SegmentReduceFn(Function):
         d = _req(d, torch.float32, "d_out")
         e, c = ctx.shape
         dv = torch.empty(e, c, dtype=torch.float32, device=d.device)
-        arg = ctx.saved_tensors[0] if ctx.mode == MAX else None
+        arg = ctx.saved_tensors[0] if ctx.mode in (MAX, MIN) else None
         check(lib.gaot_segment_reduce_bwd(_ptr(d), _ptr(g.by_dst.key), _ptr(g.by_dst.rowptr), _ptr(arg), g.num_dst, e, c,
                                           ctx.mode, _ptr(dv), _stream()), "gaot_segment_reduce_bwd")
         return dv, None, None
+
+
+class ScatterFn(Function):
+    """torch_scatter.scatter / scatter_native (reference src/model/layers/utils/scatter_native.py:4-54) on an UNSORTED
+    index: one stable radix sort of the index (csr_build) gives every output row its contributions in input order, then
+    the fixed-order segment reduction -- no atomics, bit-reproducible; empty rows -> 0."""
+
+    @staticmethod
+    def forward(ctx, src2: Tensor, index: Tensor, dim_size: int, mode: int):
+        from . import ops
+        e, c = src2.shape
+        idx = index.to(torch.int32) if index.dtype != torch.int32 else index
+        se = ops.csr_build(torch.stack([idx, idx]), 1, dim_size)          # perm: sorted position -> input position
+        ctx.mode, ctx.shape, ctx.rows = mode, (e, c), dim_size
+        if mode in (MAX, MIN):
+            out, arg = segment_reduce(src2, se.rowptr, se.perm, dim_size, mode, want_argmax=True)
+            ctx.save_for_backward(idx, se.rowptr, arg)
+            return out
+        ctx.save_for_backward(idx, se.rowptr)
+        return segment_reduce(src2, se.rowptr, se.perm, dim_size, mode)
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        lib = _lib.load()
+        d = _req(d, torch.float32, "d_out")
+        e, c = ctx.shape
+        saved = ctx.saved_tensors
+        arg = saved[2] if ctx.mode in (MAX, MIN) else None
+        dv = torch.empty(e, c, dtype=torch.float32, device=d.device)
+        check(lib.gaot_segment_reduce_bwd(_ptr(d), _ptr(saved[0]), _ptr(saved[1]), _ptr(arg), ctx.rows, e, c, ctx.mode,
+                                          _ptr(dv), _stream()), "gaot_segment_reduce_bwd")
+        return dv, None, None, None
+
+
+_REDUCE = {"sum": SUM, "add": SUM, "mean": MEAN, "max": MAX, "amax": MAX, "min": MIN, "amin": MIN}
+
+
+def scatter(src: Tensor, index: Tensor, dim: int = -1, out: Optional[Tensor] = None, dim_size: Optional[int] = None,
+            reduce: str = "sum") -> Tensor:
+    """Drop-in for the reference's ``scatter`` (scatter_native.py:4-54 / torch_scatter.scatter as the reference calls it:
+    dim=0, 1-D index over the leading axis).  Same argument meaning and errors: dim != 0 raises NotImplementedError,
+    an unknown ``reduce`` ValueError; ``out`` (if given) is overwritten like the reference's ``out.fill_(0)`` + scatter;
+    dim_size=None takes index.max()+1 (a host read, as in the reference)."""
+    if dim != 0:
+        raise NotImplementedError("Native scatter fallback only supports dim=0")
+    if reduce not in _REDUCE:
+        raise ValueError(f"Unsupported reduce operation '{reduce}' in native scatter")
+    if not src.is_cuda:
+        raise _lib.GaotError(f"scatter: expected tensors on the GPU (the HIP path has no CPU fallback), got {src.device}")
+    if index.dim() != 1 or index.shape[0] != src.shape[0]:
+        raise ValueError("scatter: index must be 1-D over the leading axis of src")
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    tail = tuple(src.shape[1:])
+    c = 1
+    for t in tail:
+        c *= t
+    if src.shape[0] == 0 or dim_size == 0 or c == 0:
+        res = torch.zeros((dim_size,) + tail, dtype=src.dtype, device=src.device)
+    else:
+        res = ScatterFn.apply(src.reshape(src.shape[0], c).to(torch.float32), index, dim_size, _REDUCE[reduce])
+        res = res.view((dim_size,) + tail).to(src.dtype)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 class SegmentSoftmaxFn(Function):

@@ -311,6 +311,28 @@ class AttentionFn(Function):
         return dqkv, None, None, None, None, None, None, None, None
 
 
+class DropoutFn(Function):
+    """nn.Dropout in training mode (reference mlp.py:268-272, 318-322): counter-based mask from one word of the device seed
+    stream, regenerated for the gradient"""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, p: float):
+        xc = x if x.is_contiguous() else x.contiguous()
+        seed = next_dropout_seed(xc.device)
+        ctx.save_for_backward(seed)
+        ctx.p = p
+        return ops.dropout(xc, seed, p)
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        (seed,) = ctx.saved_tensors
+        return ops.dropout(d if d.is_contiguous() else d.contiguous(), seed, ctx.p), None
+
+
+def dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    return DropoutFn.apply(x, float(p)) if (training and p > 0.0) else x
+
+
 class SwiGLUFn(Function):
     @staticmethod
     def forward(ctx, ag: Tensor, f: int):

@@ -37,11 +37,37 @@ class _Bag:
             self.__dict__["_state"] = state
 
 
+# Globals a tensor pickle legitimately needs.  Everything else met in a sample file is either a data-container class
+# (torch_geometric.*, the reference's EnrichedData, any other class) -> inert attribute bag, or refused: a crafted .pt
+# cannot import and call arbitrary functions (os.system, builtins.eval, ...) through this reader.
+_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "bytes"),
+    ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_tensor_v3"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"), ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Tensor"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+}
+_STORAGE_SUFFIX = "Storage"
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
-        if module.split(".")[0] == "torch_geometric" or name in ("EnrichedData",):
-            return type(name, (_Bag,), {"__module__": module})
-        return super().find_class(module, name)
+        if (module, name) in _ALLOWED:
+            return super().find_class(module, name)
+        if module in ("torch", "torch.storage") and name.endswith(_STORAGE_SUFFIX):   # FloatStorage, UntypedStorage, ...
+            return super().find_class(module, name)
+        if module == "gaot_3d_amd.data" and name == "MeshBatch":
+            return MeshBatch
+        root = module.split(".")[0]
+        if root in ("os", "posix", "nt", "subprocess", "sys", "builtins", "importlib", "runpy", "shutil", "socket", "pickle",
+                    "ctypes", "operator", "functools", "types", "code", "codecs", "pty", "commands", "webbrowser"):
+            raise pickle.UnpicklingError(f"refusing to load global {module}.{name} from a sample file")
+        # torch_geometric.*, the reference's src.data.pyg_datasets.EnrichedData and any other data-container class
+        return type(name, (_Bag,), {"__module__": module})
 
 
 class _PickleModule:

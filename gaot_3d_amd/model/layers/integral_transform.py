@@ -14,19 +14,23 @@ import torch.nn as nn
 from ... import edgeops as EO
 from ... import functional as GF
 from ... import ops
-from .mlp import LinearChannelMLP
+from .mlp import LinearChannelMLP, activation_name
 
 
 def graph_for(edge_index: torch.Tensor, num_src: int, num_dst: int, cache_owner=None, key=None):
-    """Row-sorted neighbour lists for one edge_index; cached on the batch object so that encoder GNO,
-    GeoEmbed and the backward pass share one build per sample and scale."""
+    """Row-sorted neighbour lists for one edge_index; cached on the batch object so that encoder GNO, GeoEmbed and the
+    backward pass share one build per sample and scale.  An entry is valid only for the very tensor it was built from
+    (object identity and in-place version counter; the entry keeps the tensor alive, so its address cannot be handed to
+    another edge list meanwhile): edges rebuilt or re-uploaded per forward replace the entry of their slot, they never
+    hit a stale one, and the cache holds one entry per (side, scale)."""
     if cache_owner is not None:
         cache = cache_owner.__dict__.setdefault("_gaot_graphs", {})
-        k = (key, edge_index.data_ptr(), tuple(edge_index.shape), num_src, num_dst)
-        g = cache.get(k)
-        if g is None:
-            g = ops.build_graph(edge_index, num_src, num_dst)
-            cache[k] = g
+        k = (key, num_src, num_dst)
+        ent = cache.get(k)
+        if ent is not None and ent[0] is edge_index and ent[1] == edge_index._version:
+            return ent[2]
+        g = ops.build_graph(edge_index, num_src, num_dst)
+        cache[k] = (edge_index, edge_index._version, g)
         return g
     return ops.build_graph(edge_index, num_src, num_dst)
 
@@ -34,6 +38,7 @@ def graph_for(edge_index: torch.Tensor, num_src: int, num_dst: int, cache_owner=
 class IntegralTransform(nn.Module):
     def __init__(self, channel_mlp=None, channel_mlp_layers=None, channel_mlp_non_linearity="gelu",
                  transform_type="linear", use_attn=None, coord_dim=None, attention_type="cosine"):
+        """``channel_mlp_non_linearity``: the reference's callable (F.gelu, integral_transform.py:35) or its name"""
         super().__init__()
         self.transform_type = transform_type
         self.use_attn = use_attn
@@ -76,7 +81,9 @@ class IntegralTransform(nn.Module):
     def _fused_eligible(self, fcs, f_y) -> bool:
         if self.use_attn or self.transform_type != "linear" or f_y is None:
             return False
-        if getattr(self.channel_mlp, "non_linearity", "gelu") != "gelu" or not (2 <= len(fcs) <= 5):
+        if activation_name(getattr(self.channel_mlp, "non_linearity", "gelu")) != "gelu" or not (2 <= len(fcs) <= 5):
+            return False
+        if self.training and getattr(self.channel_mlp, "dropout_p", 0.0) > 0.0:
             return False
         dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
         ok = dims[0] == (64, 6) and dims[-1] == (32, 64) and all(d == (64, 64) for d in dims[1:-1])
@@ -85,11 +92,13 @@ class IntegralTransform(nn.Module):
     def _forward_general(self, fcs, y_pos, x_pos, f_y, g):
         """integral_transform.py:114-171 on per-edge tensors (dst-sorted order)"""
         tt = self.transform_type
-        act = getattr(self.channel_mlp, "non_linearity", "gelu")
+        act = activation_name(getattr(self.channel_mlp, "non_linearity", "gelu"))
+        pdrop = getattr(self.channel_mlp, "dropout_p", 0.0)
         k = EO.EdgeInputFn.apply(y_pos, x_pos, f_y if (f_y is not None and tt != "linear") else None, g)   # :146-152
         for i, fc in enumerate(fcs):                                                                        # :154
             w = fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight
             k = GF.linear(k, w, fc.bias, act=act if i < len(fcs) - 1 else None)
+            k = GF.dropout(k, pdrop, self.training)
         if f_y is not None and tt != "nonlinear_kernelonly":                                                # :156-157
             k = EO.MulFn.apply(k, EO.GatherFn.apply(f_y, g, 0))
         mode = EO.MEAN

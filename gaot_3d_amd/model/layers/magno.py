@@ -15,6 +15,7 @@ import torch.nn as nn
 from ... import functional as GF
 from ...data import coalesce_edges, knn_edges_bruteforce, radius_edges_bruteforce
 from .geoembed import GeometricEmbedding
+from ...graph import apply_neighbor_sampling  # noqa: F401  (the reference exports it from this module, magno.py:297-371)
 from .integral_transform import IntegralTransform, graph_for
 from .mlp import ChannelMLP, LinearChannelMLP
 
@@ -250,9 +251,10 @@ class MAGNOEncoder(nn.Module):
         phys_feat = self._features(batch)
         lifted = None
         if self.use_gno:  # scale-independent: lift once; [f0|f1|..] W^T is evaluated without materialising the cat
-            if len(self.lifting.fcs) != 1:
-                raise NotImplementedError("lifting MLP with more than one layer")
-            lifted = GF.cat_linear(phys_feat, self.lifting.fcs[0].weight, self.lifting.fcs[0].bias, precision=0)
+            if len(self.lifting.fcs) == 1 and not (self.training and getattr(self.lifting, "dropout_p", 0.0) > 0.0):
+                lifted = GF.cat_linear(phys_feat, self.lifting.fcs[0].weight, self.lifting.fcs[0].bias, precision=0)
+            else:   # a caller-supplied deeper lifting MLP (the reference's constructor always builds one layer)
+                lifted = self.lifting.forward_rows(phys_feat[0] if len(phys_feat) == 1 else torch.cat(phys_feat, dim=1))
         outs = []
         for si, scale in enumerate(self.scales):
             if self.precompute_edges:
@@ -353,4 +355,4 @@ class MAGNODecoder(nn.Module):
                     geo = self.geoembed(latent_tokens_pos, phys_pos_query, edge_index, graph=g)
                 dec = GF.cat_linear([dec, geo], self.recovery.fcs[0].weight, self.recovery.fcs[0].bias, precision=0)
             outs.append(dec)
-        return self.projection(_mix_scales(self, outs, phys_pos_query))
+        return self.projection.forward_rows(_mix_scales(self, outs, phys_pos_query))

@@ -10,32 +10,61 @@ from ... import functional as GF
 _FP32 = 0
 
 
+def activation_name(fn) -> str:
+    """The reference passes activations as callables (``non_linearity=F.gelu``, mlp.py:227-335,
+    ``channel_mlp_non_linearity=F.gelu``, integral_transform.py:35); the HIP kernels take an activation id.  Accepts the
+    callable (F.gelu / F.relu / F.silu, torch.relu, nn.GELU() / nn.ReLU() / nn.SiLU() instances) or its name."""
+    import torch.nn.functional as F
+    if fn is None:
+        return "none"
+    if isinstance(fn, str):
+        name = {"swish": "silu"}.get(fn.lower(), fn.lower())
+    elif fn in (F.gelu,) or isinstance(fn, nn.GELU):
+        if isinstance(fn, nn.GELU) and getattr(fn, "approximate", "none") != "none":
+            raise NotImplementedError("tanh-approximated GELU: the HIP kernels evaluate the erf form (F.gelu default)")
+        name = "gelu"
+    elif fn in (F.relu, torch.relu) or isinstance(fn, nn.ReLU):
+        name = "relu"
+    elif fn in (F.silu,) or isinstance(fn, nn.SiLU):
+        name = "silu"
+    else:
+        raise NotImplementedError(f"activation {fn!r} has no HIP kernel (supported: gelu, relu, silu)")
+    if name not in ("gelu", "relu", "silu", "none"):
+        raise NotImplementedError(f"activation '{name}' has no HIP kernel (supported: gelu, relu, silu)")
+    return name
+
+
 class LinearChannelMLP(nn.Module):
-    """Stack of nn.Linear parameters [layers[j] -> layers[j+1]], GELU(erf) between, none after the last."""
+    """Stack of nn.Linear parameters [layers[j] -> layers[j+1]], activation (default erf-GELU) between, none after the
+    last, nn.Dropout after every layer when ``dropout`` > 0 (reference mlp.py:308-335)."""
 
     def __init__(self, layers, non_linearity="gelu", dropout=0.0):
         super().__init__()
         self.n_layers = len(layers) - 1
         assert self.n_layers >= 1
-        if dropout > 0.0:
-            raise NotImplementedError("dropout > 0 is not supported by the HIP path (reference default is 0)")
-        self.non_linearity = non_linearity
+        self.non_linearity = activation_name(non_linearity)
+        self.dropout_p = float(dropout)
         self.fcs = nn.ModuleList([nn.Linear(layers[j], layers[j + 1]) for j in range(self.n_layers)])
 
     def forward(self, x):
-        if GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused, no [N, hidden] in HBM
+        p = self.dropout_p if self.training else 0.0
+        if p == 0.0 and GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused
             return GF.Mlp2Fn.apply(x, self.fcs[0].weight, self.fcs[0].bias, self.fcs[1].weight, self.fcs[1].bias)
         for i, fc in enumerate(self.fcs):
             x = GF.linear(x, fc.weight, fc.bias, act=self.non_linearity if i < self.n_layers - 1 else None,
                           precision=_FP32)
+            x = GF.dropout(x, p, self.training)
         return x
+
+    forward_rows = forward      # [N, C] rows in, rows out (what the encoder / decoder hand over)
 
 
 class ChannelMLP(nn.Module):
-    """Conv1d(k=1) parameter storage ([out,in,1]) of mlp_type='channel'.  The reference applies it to
-    [C, N] tensors (callers transpose around it, magno.py:545,575,775,796-797); numerically it is the
-    same per-node affine map, so ``forward`` here takes and returns the row-major [N, C] layout and
-    callers skip the two transposes."""
+    """Conv1d(k=1) parameter storage ([out,in,1]) of mlp_type='channel' (reference mlp.py:227-305).  ``forward`` takes the
+    reference's channels-first layout -- [C, N], [B, C, N] or [B, C, x1, x2, ...] -- and returns the same layout;
+    numerically a Conv1d(k=1) is the per-node affine map, so the kernels run on row-major [N, C] and ``forward_rows`` is
+    the entry point the encoder / decoder use (they hold [N, C] and the reference only transposes around this module,
+    magno.py:545,575,775,796-797)."""
 
     def __init__(self, in_channels, out_channels=None, hidden_channels=None, n_layers=2, n_dim=2,
                  non_linearity="gelu", dropout=0.0, **kwargs):
@@ -44,22 +73,34 @@ class ChannelMLP(nn.Module):
         self.in_channels = in_channels
         self.out_channels = in_channels if out_channels is None else out_channels
         self.hidden_channels = in_channels if hidden_channels is None else hidden_channels
-        if dropout > 0.0:
-            raise NotImplementedError("dropout > 0 is not supported by the HIP path (reference default is 0)")
-        self.non_linearity = non_linearity
+        self.non_linearity = activation_name(non_linearity)
+        self.dropout_p = float(dropout)
         self.fcs = nn.ModuleList()
         for i in range(n_layers):
             cin = self.in_channels if i == 0 else self.hidden_channels
             cout = self.out_channels if i == n_layers - 1 else self.hidden_channels
             self.fcs.append(nn.Conv1d(cin, cout, 1))
 
-    def forward(self, x):
-        if GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused, no [N, hidden] in HBM
+    def forward_rows(self, x):
+        p = self.dropout_p if self.training else 0.0
+        if p == 0.0 and GF.Mlp2Fn.eligible(x, self.fcs, self.non_linearity):   # bf16 mode, C -> {64,128,256} -> <=4: fused
             return GF.Mlp2Fn.apply(x, self.fcs[0].weight, self.fcs[0].bias, self.fcs[1].weight, self.fcs[1].bias)
         for i, fc in enumerate(self.fcs):
             x = GF.linear(x, fc.weight, fc.bias, act=self.non_linearity if i < self.n_layers - 1 else None,
                           precision=_FP32)
+            x = GF.dropout(x, p, self.training)
         return x
+
+    def forward(self, x):
+        size = list(x.shape)
+        if x.dim() == 2:                                   # unbatched Conv1d input [C, N]
+            return self.forward_rows(x.transpose(0, 1)).transpose(0, 1)
+        if x.dim() < 2:
+            raise ValueError(f"ChannelMLP expects [C, N] or [B, C, ...], got {tuple(size)}")
+        b, c = size[0], size[1]
+        rows = x.reshape(b, c, -1).permute(0, 2, 1).reshape(-1, c)      # [B * N, C]
+        y = self.forward_rows(rows)
+        return y.view(b, -1, self.out_channels).permute(0, 2, 1).reshape(b, self.out_channels, *size[2:])
 
 
 class MLP(nn.Module):

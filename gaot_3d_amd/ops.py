@@ -313,6 +313,15 @@ def dropout_seed_next(state: Tensor, stride: int) -> Tensor:
     return out
 
 
+def dropout(x: Tensor, seed: Tensor, p: float) -> Tensor:
+    """x .* keep / (1 - p) with keep(i) = hash(seed, i) >= round(p 2^32)  (include/gaot3d_hip.h: gaot_dropout)"""
+    lib = _lib.load()
+    x = _req(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    check(lib.gaot_dropout(_ptr(x), _ptr(seed), float(p), x.numel(), _ptr(out), _stream()), "gaot_dropout")
+    return out
+
+
 def attn_dropout_mask(seed: Tensor, p: float, b: int, h: int, s: int) -> Tensor:
     """keep[b, h, q, k] (uint8) of the attention dropout mask the kernels regenerate from ``seed`` (checks only)"""
     lib = _lib.load()

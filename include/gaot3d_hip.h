@@ -299,6 +299,10 @@ int gaot_unique_pair_flags(const int32_t* a, const int32_t* b, int64_t n, int32_
  * seed = DEVICE pointer to one 64-bit word; compact with gaot_exclusive_scan_i32 + gaot_compact_pairs. */
 int gaot_random_keep_flags(const unsigned long long* seed, int64_t n, double keep_prob, int32_t* flags,
                            gaot_stream_t stream);
+/* nn.Dropout of the reference's channel MLPs (src/model/layers/mlp.py:268-272, 318-322, training mode):
+ * out[i] = keep(i) ? x[i] / (1 - p) : 0, keep(i) = hash(seed word, i) >= round(p 2^32); call it on the gradient with
+ * the same seed for the backward.  (torch's own Philox draw cannot be reproduced: the draw is "parity unpinned".) */
+int gaot_dropout(const float* x, const uint64_t* seed, double p, int64_t n, float* out, gaot_stream_t stream);
 int gaot_segment_random_cap_flags(const unsigned long long* seed, const int32_t* rowptr, const int32_t* key_sorted,
                                   int64_t n, int cap, int32_t* flags, gaot_stream_t stream);
 int gaot_compact_pairs(const int32_t* a, const int32_t* b, const int32_t* flags, const int32_t* offsets, int64_t n,
@@ -328,9 +332,9 @@ int gaot_mlp2_bwd(const float* x, int64_t num_rows, int in_dim, int hidden, int 
  * a reduction over the other endpoint walks that endpoint's CSR through `map` (position in its order ->
  * position in the dst order).  Fixed-order reductions, no atomics.
  *   gather_rows        out[e] = table[idx[e]]                       (backward: segment_reduce sum over idx's CSR)
- *   segment_reduce     out[r] = sum | mean | max over the row's edges (mode 0 | 1 | 2; empty row -> 0, like
- *                      scatter_native.py:4-54); max also returns the arg-max edge per (row, channel)
- *   segment_reduce_bwd d_vals from d_out (sum / mean: broadcast [/ degree]; max: routed to the arg-max edge)
+ *   segment_reduce     out[r] = sum | mean | max | min over the row's edges (mode 0 | 1 | 2 | 3; empty row -> 0, like
+ *                      scatter_native.py:4-54); max / min also return the arg-extremum edge per (row, channel)
+ *   segment_reduce_bwd d_vals from d_out (sum / mean: broadcast [/ degree]; max / min: routed to the arg edge)
  *   segment_softmax    w = exp(s - max_seg) / max(sum_seg, FLT_MIN)   and   ds = w * (dw - sum_seg(w dw))
  *   edge_coords        mode 0: [y[src], x[dst]] (6)   1: y[src] - x[dst] (3)   2: cos(x[dst], y[src]) (1)
  *   mul / mul_rowsum   a .* b with b per element or per row;  row-wise sum of a .* b

@@ -403,6 +403,35 @@ def dropout_keep_mask(seed: int, b: int, h: int, s: int, p: float) -> Tensor:
     return torch.from_numpy((half >= thr).reshape(b, h, s, s))
 
 
+def dropout_keep_rows(seed: int, bh: int, q_rows, s: int, p: float) -> Tensor:
+    """rows ``q_rows`` of dropout_keep_mask(...)[b, h] for the flattened head index bh = b * H + h -> bool [len(q_rows), s]
+    (the same integer function, evaluated for a subset of query rows: full-size checks at S = 16 384)"""
+    import numpy as np
+    seed &= 0xFFFFFFFFFFFFFFFF
+    lo, hi = seed & _M32, seed >> 32
+    thr = dropout_threshold(p)
+    one = np.array([bh + 1], dtype=np.uint64)
+    rk = _mix_a((np.uint64(lo) + np.uint64(0x9E3779B9) * one) & _M32)
+    ck = _mix_b((np.uint64(hi) + np.uint64(0x85EBCA6B) * one) & _M32)
+    q = np.asarray(q_rows, dtype=np.uint64)
+    kk = np.arange(s, dtype=np.uint64)
+    aw = _mix_a((rk + q) & _M32)                                   # [R]
+    bw = _mix_b((ck + (kk >> np.uint64(1))) & _M32)                # [S]
+    w = aw[:, None] ^ bw[None, :]
+    half = np.where((kk & np.uint64(1))[None, :] == 1, w >> np.uint64(16), w & np.uint64(0xFFFF))
+    return torch.from_numpy(half >= thr)
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, keep: Optional[Tensor] = None, p_drop: float = 0.0) -> Tensor:
+    """F.scaled_dot_product_attention(q, k, v, dropout_p) as the reference calls it (attn.py:122-127): non-causal, no mask,
+    scale 1/sqrt(head_dim); ``keep`` = the Bernoulli mask of the training path (torch.dropout on the attention weights:
+    mask and rescale by 1/(1-p)).  q, k, v: [B, H, S, d] (any float dtype: the full-size checks call it in fp64)."""
+    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1]), dim=-1)  # SDPA :126
+    if keep is not None:
+        att = att * keep.to(att.dtype) / (1.0 - p_drop)
+    return att @ v
+
+
 def conditioned_norm(sd: SD, prefix: str, c: Tensor, x: Tensor) -> Tensor:
     """mlp.py:74-128 (ConditionedNorm; its MLPs have num_layers=2 -> one Linear each, activation "none")"""
     sc = 1 + c * F.linear(c, sd[prefix + "mlp_scale.layers.0.weight"], sd[prefix + "mlp_scale.layers.0.bias"])
@@ -432,10 +461,7 @@ def attention(sd: SD, prefix: str, x: Tensor, num_heads: int, num_kv_heads: int,
         fr = sd[prefix + "rotary_emb.freqs"]
         q = rope_rotate(q, fr)
         k = rope_rotate(k, fr)
-    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)  # SDPA :126
-    if keep is not None:   # torch.dropout(attn_weight, p, train=True): mask and rescale
-        att = att * keep.to(att.dtype) / (1.0 - p_drop)
-    o = (att @ v).transpose(1, 2).contiguous().view(b, s, -1)
+    o = sdpa(q, k, v, keep, p_drop).transpose(1, 2).contiguous().view(b, s, -1)
     return F.linear(o, sd[prefix + "o_proj.weight"])
 
 
@@ -559,3 +585,11 @@ def train_step_grads(sd: SD, mcfg, batch, tokens_pos: Optional[Tensor] = None, d
     loss.backward()
     grads = {k: v.grad for k, v in leaf.items() if v.requires_grad and v.grad is not None}
     return pred.detach(), loss.detach(), grads
+
+
+def element_dropout_keep(seed: int, n: int, p: float) -> Tensor:
+    """bool keep[n] of the product's element dropout (csrc/graph.hip k_dropout; stands for nn.Dropout in the reference's
+    channel MLPs, mlp.py:268-272, 318-322 -- torch's own draw is "parity unpinned"): hash(seed, i) >= round(p 2^32)"""
+    import numpy as np
+    thr = min(int(p * 4294967296.0 + 0.5), 4294967295)
+    return torch.from_numpy(_sample_hash(seed, np.arange(n, dtype=np.uint64)) >= np.uint64(thr))

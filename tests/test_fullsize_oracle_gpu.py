@@ -1,0 +1,204 @@
+"""Oracle parity AT BASELINE configs[1] sizes (VERDICT r1 "full-size parity is self-comparison only"):
+
+* attention at S = 16 384 tokens, head_dim 32: one head against the oracle's SDPA restatement (oracle.sdpa, reference
+  attn.py:110-127) evaluated in fp64 on the host, query-chunked -- forward output and dQ / dK / dV, for the exact-fp32
+  kernels and for the bf16 matrix-core kernels, without and with the training-mode dropout mask (the mask the kernels
+  regenerate is checked bit for bit against the oracle's integer restatement on sampled rows of the 2.7 x 10^8-element
+  mask, then taken from the device for the fp64 reference);
+* the fused GNO integral transform on the full 4.0 M-edge graphs of the 500 000-point sample, both directions
+  (points -> 131 072 latent tokens: variable degree with empty rows and rows of hundreds of edges; tokens -> points):
+  forward against oracle.integral_transform (reference integral_transform.py:114-171) on the sub-graph of >= 1 000 sampled
+  query rows that include the heaviest row and empty rows; backward: grad f_y on >= 1 000 sampled source rows (all of
+  their edges) and ALL weight / bias gradients against the oracle's kernel MLP evaluated in fp64 over all 4 M edges.
+
+Tolerances: fp32 kernels rtol 1e-4 / atol 1e-5-of-peak on outputs, rtol 1e-3 on gradients; bf16 kernels
+max-abs <= 2e-2 of the reference's peak on outputs, cosine >= 0.999 and max-abs <= 5e-2 of peak on gradients."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+import parity as PAR
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import gaot_oracle as orc  # noqa: E402  (checker only)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S_FULL = 16384
+N_PTS, LATENT, KNN = 500_000, (64, 64, 32), 8
+
+
+def _attention_fp64(qkv, w, freqs, keep, p_eff, chunk=2048):
+    """oracle.sdpa in fp64 on [1, 1, S, 32] operands, one query chunk at a time (S x S in fp64 is 2 GB): returns the
+    output and the gradients of <out, w> with respect to the fused q | k | v projection"""
+    s = qkv.shape[0]
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (t.view(1, s, 1, 32).transpose(1, 2) for t in x.split(32, dim=1))
+    if freqs is not None:
+        q, k = orc.rope_rotate(q, freqs.double()), orc.rope_rotate(k, freqs.double())
+    outs = []
+    for lo in range(0, s, chunk):
+        hi = min(lo + chunk, s)
+        kp = None if keep is None else keep[None, None, lo:hi]
+        o = orc.sdpa(q[:, :, lo:hi], k, v, kp, p_eff)                     # [1, 1, c, 32]
+        (o[0, 0] * w[lo:hi].double()).sum().backward(retain_graph=True)
+        outs.append(o.detach()[0, 0])
+    return torch.cat(outs), x.grad
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_attention_full_sequence_vs_fp64_oracle(precision, p):
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd import ops
+    s = S_FULL
+    g = torch.Generator().manual_seed(1234)
+    qkv = torch.randn(s, 96, generator=g)
+    qkv[:, :64] *= 1.5                         # logits of spread ~2.2: a softmax that is neither flat nor one-hot
+    w = torch.randn(s, 32, generator=g)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    seed0 = 0x5EED_F011 + int(p * 100)
+    keep, p_eff = None, 0.0
+    gaot_3d_amd.set_precision(precision)
+    try:
+        GF.set_dropout_seed(seed0, DEV)
+        qd = qkv.to(DEV).requires_grad_(True)
+        out = GF.AttentionFn.apply(qd, freqs.to(DEV), 1, s, 1, 1, p)
+        (out * w.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    if p > 0.0:
+        p_eff = orc.dropout_threshold(p) / 65536.0
+        word = GF.dropout_seed_sequence(seed0, 1)[0]
+        st = torch.tensor([word - (1 << 64) if word >= (1 << 63) else word], dtype=torch.int64, device=DEV)
+        keep = ops.attn_dropout_mask(st, p, 1, 1, s).cpu()[0, 0].bool()     # what the kernels regenerate
+        rows = [0, 1, 31, 32, 4095, 4096, 8191, 12345, s - 2, s - 1] + torch.randint(0, s, (54,), generator=g).tolist()
+        assert torch.equal(keep[rows], orc.dropout_keep_rows(word, 0, rows, s, p))   # bit-exact against the oracle's draw
+        rate = keep.float().mean().item()
+        print(f"[parity] attn_full_{precision}_p{p}: mask rows bit-exact on {len(rows)} sampled rows, keep rate {rate:.5f}")
+        assert abs(rate - (1.0 - p_eff)) < 1e-3
+    ref, gref = _attention_fp64(qkv, w, freqs, keep, p_eff)
+    tag = f"attn_full_S{s}_{precision}_p{p}"
+    names = (("dq", 0, 32), ("dk", 32, 64), ("dv", 64, 96))
+    if precision == "fp32":
+        PAR.close(f"{tag}/out", out, ref, 1e-4, 1e-5 * float(ref.abs().max()))
+        for nm, lo, hi in names:
+            PAR.close(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 1e-3, 2e-5 * float(gref[:, lo:hi].abs().max()))
+    else:
+        PAR.close_peak(f"{tag}/out", out, ref, 2e-2, rel_l2=1e-2)
+        for nm, lo, hi in names:
+            PAR.cosine(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 0.999)
+            PAR.close_peak(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 5e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sample():
+    from gaot_3d_amd.data import make_synthetic_sample
+    batch, tokens = make_synthetic_sample(N_PTS, LATENT, k=KNN, seed=0, device=DEV)
+    return batch, tokens.to(DEV)
+
+
+def _mlp_sd(nh, seed):
+    g = torch.Generator().manual_seed(seed)
+    dims = [6] + [64] * nh + [32]
+    sd = {}
+    for i in range(len(dims) - 1):
+        bound = 1.0 / math.sqrt(dims[i])
+        sd[f"channel_mlp.fcs.{i}.weight"] = (torch.rand(dims[i + 1], dims[i], generator=g) * 2 - 1) * bound * 1.7
+        sd[f"channel_mlp.fcs.{i}.bias"] = (torch.rand(dims[i + 1], generator=g) * 2 - 1) * bound
+    return sd
+
+
+def _sample_rows(deg, n, gen):
+    """>= n rows: the heaviest, the lightest non-empty, some empty ones, the first / last row and random ones"""
+    rows = {int(deg.argmax()), 0, deg.numel() - 1}
+    empty = (deg == 0).nonzero().flatten()
+    if empty.numel():
+        rows.update(empty[torch.randint(0, empty.numel(), (50,), generator=gen)].tolist())
+    nz = (deg > 0).nonzero().flatten()
+    rows.add(int(nz[deg[nz].argmin()]))
+    rows.update(nz[torch.randint(0, nz.numel(), (n,), generator=gen)].tolist())
+    return torch.tensor(sorted(rows), dtype=torch.long)
+
+
+@pytest.mark.parametrize("side,nh", [("encoder", 3), ("decoder", 2)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
+    from gaot_3d_amd import ops
+    batch, tokens = sample
+    m = tokens.shape[0]
+    if side == "encoder":      # points -> tokens: variable degree, empty tokens, tokens with hundreds of points
+        ei, y_pos, x_pos, n_src, n_dst = batch.encoder_edge_index_s0, batch.pos, tokens, N_PTS, m
+    else:                      # tokens -> points: degree k everywhere
+        ei, y_pos, x_pos, n_src, n_dst = batch.decoder_edge_index_s0, tokens, batch.pos, m, N_PTS
+    gen = torch.Generator().manual_seed(77)
+    sd = _mlp_sd(nh, 5 + nh)
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(nh + 1)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(nh + 1)]
+    f_y = torch.randn(n_src, 32, generator=gen)
+    dout = torch.randn(n_dst, 32, generator=gen)
+    graph = ops.build_graph(ei, n_src, n_dst)
+    prec = 0 if precision == "fp32" else 1
+    out = ops.gno_forward(ws, bs, y_pos, x_pos, f_y.to(DEV), graph, precision=prec)
+    gf, gw, gb = ops.gno_backward(ws, bs, y_pos, x_pos, f_y.to(DEV), dout.to(DEV), graph, precision=prec)
+    torch.cuda.synchronize()
+    ei_c = ei.cpu().long()
+    src, dst = ei_c[0], ei_c[1]
+    deg_dst = torch.bincount(dst, minlength=n_dst)
+    deg_src = torch.bincount(src, minlength=n_src)
+    y_c, x_c = y_pos.cpu(), x_pos.cpu()
+    tag = f"gno_full_{side}_nh{nh}_{precision}"
+    print(f"[parity] {tag}: E={ei.shape[1]} max query degree {int(deg_dst.max())}, empty query rows {int((deg_dst == 0).sum())}, "
+          f"max source degree {int(deg_src.max())}")
+
+    # ---- forward: the oracle's IntegralTransform on the sub-graph of the sampled query rows --------------------------------
+    qs = _sample_rows(deg_dst, 1000, gen)
+    local = torch.full((n_dst,), -1, dtype=torch.long)
+    local[qs] = torch.arange(qs.numel())
+    sel = local[dst] >= 0
+    sub = torch.stack([src[sel], local[dst[sel]]])
+    ref = orc.integral_transform(sd, "", y_c, x_c[qs], sub, f_y)
+    assert int((deg_dst[qs] == 0).sum()) > 0 or side == "decoder"
+    if precision == "fp32":
+        PAR.close(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 1e-4, 1e-5 * float(ref.abs().max()))
+    else:
+        PAR.close_peak(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 2e-2, rel_l2=1e-2)
+
+    # ---- backward, grad f_y: every edge of >= 1 000 sampled source rows; mean reduction = sum / degree of the query -------
+    ss = _sample_rows(deg_src, 1000, gen)
+    local = torch.full((n_src,), -1, dtype=torch.long)
+    local[ss] = torch.arange(ss.numel())
+    sel = local[src] >= 0
+    es, ed = src[sel], dst[sel]
+    sd64 = {k: v.double() for k, v in sd.items()}
+    fsub = f_y[ss].double().requires_grad_(True)
+    kern = orc.channel_mlp(sd64, "channel_mlp.", torch.cat([y_c[es], x_c[ed]], dim=1).double())       # :146-154
+    msg = kern * fsub[local[es]]                                                                          # :156-157
+    (msg * (dout[ed].double() / deg_dst[ed].clamp(min=1)[:, None])).sum().backward()                      # :165-171 (mean)
+    if precision == "fp32":
+        PAR.close(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-3, 1e-5 * float(fsub.grad.abs().max()))
+    else:
+        PAR.cosine(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 0.999)
+        PAR.close_peak(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 5e-2)
+
+    # ---- backward, weight / bias gradients: all E edges through the oracle's kernel MLP in fp64, chunked -------------------
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    f64, d64 = f_y.double(), dout.double() / deg_dst.clamp(min=1).double()[:, None]
+    for lo in range(0, src.numel(), 500_000):
+        e_s, e_d = src[lo:lo + 500_000], dst[lo:lo + 500_000]
+        kern = orc.channel_mlp(leaves, "channel_mlp.", torch.cat([y_c[e_s], x_c[e_d]], dim=1).double())
+        (kern * f64[e_s] * d64[e_d]).sum().backward()
+    for i in range(nh + 1):
+        for nm, got in (("weight", gw[i]), ("bias", gb[i])):
+            r = leaves[f"channel_mlp.fcs.{i}.{nm}"].grad
+            if precision == "fp32":
+                PAR.close(f"{tag}/grad_{nm}{i}", got, r, 1e-3, 2e-5 * float(r.abs().max()))
+            else:
+                PAR.cosine(f"{tag}/grad_{nm}{i}", got, r, 0.999)
+                PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 5e-2)
