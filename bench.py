@@ -45,7 +45,12 @@ def parse_args(argv=None):
                          "on the SAME 500K-point sample, one timed step, attention dropout off on the CPU side (its mask "
                          "would be 8.6 GB per layer)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--graph", action="store_true", help="also replay a captured hipGraph at N>1 (default: N=1 only)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N>1: time ONLY the hipGraph replay (default at N>1: time eager launches first, then try capture + "
+                         "replay of the whole step, RCCL collectives included, under a watchdog, and report the faster)")
+    ap.add_argument("--no-graph-attempt", action="store_true", help="N>1: eager launches only, no guarded graph attempt")
+    ap.add_argument("--graph-attempt-timeout", type=float, default=150.0,
+                    help="N>1: seconds the guarded capture + replay may take before the eager result is printed instead")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--atten-dropout", type=float, default=0.1,
                     help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
@@ -314,7 +319,9 @@ def main(argv=None):
             torch.cuda.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # N>1: ProcessGroupNCCL's watchdog thread polls events of earlier collectives while this thread captures;
+                # under the default "global" capture mode that query is an error that aborts the process
+                with torch.cuda.graph(graph, capture_error_mode="global" if world == 1 else "thread_local"):
                     loss = step()
             except Exception as ex:  # capture is a launch optimisation only; fall back to eager launches
                 print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
@@ -346,6 +353,35 @@ def main(argv=None):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = tt.item()
         return elapsed, graph, loss, t_host
+
+    def measure_graph_guarded(step, steps, warmup, on_timeout, timeout_s):
+        """N>1: capture + replay of the whole sharded step (RCCL collectives included).  This cannot be exercised on the
+        one-GPU development boxes, so it runs under a watchdog: if capture or replay has not finished after timeout_s,
+        rank 0 prints the (already measured) eager result and every rank leaves the process."""
+        import threading
+        done = threading.Event()
+
+        def fire():
+            if done.is_set():
+                return
+            try:
+                on_timeout()
+            finally:
+                os._exit(0)
+        timer = threading.Timer(timeout_s + (0.0 if rank == 0 else 15.0), fire)
+        timer.daemon = True
+        timer.start()
+        try:
+            e, g, l, th = measure(step, steps, warmup, True)
+        except Exception as ex:
+            done.set()
+            timer.cancel()
+            return None, f"{type(ex).__name__}: {ex}"
+        done.set()
+        timer.cancel()
+        if g is None:
+            return None, "capture failed (see stderr); eager launches timed instead"
+        return (e, g, l, th), "ok"
 
     n_total = args.points * world if args.scaling == "weak" else args.points
     use_graph = (not args.no_graph) and (world == 1 or args.graph)
@@ -379,24 +415,8 @@ def main(argv=None):
                 fp32_mode = dict(error=f"{type(ex).__name__}: {ex}")
             finally:
                 gaot_3d_amd.set_precision(args.precision)
-    if world > 1 and not args.no_secondary:
-        other = "weak" if args.scaling == "strong" else "strong"
-        try:
-            n2 = args.points * world if other == "weak" else args.points
-            del model, step, graph
-            graph = None
-            torch.cuda.empty_cache()
-            model2, step2 = build(n2, args.atten_dropout, args.parallel)
-            k2 = max(2, min(args.steps, 5))
-            e2, _, _, _ = measure(step2, k2, 1, False)
-            weak = dict(scaling=other, points=n2, ms_per_step=e2 / k2 * 1e3, value=n2 / (e2 / k2), steps=k2)
-            model, step = model2, step2
-        except Exception as ex:
-            weak = dict(scaling=other, error=f"{type(ex).__name__}: {ex}")
-            model, step = build(n_total, args.atten_dropout, args.parallel)
 
     # per-kernel durations: HIP events around the instrumented launches of two more (eager) steps on the same stream
-    n_for_kernels = n_total if (weak is None or "error" in weak) else weak["points"]
     ops.timing_reset(True)
     ops.launch_count_reset()
     t_e = time.perf_counter()
@@ -410,10 +430,22 @@ def main(argv=None):
     launches = ops.launch_count() / n_timed_steps
     ops.timing_reset(False)
 
-    if rank == 0:
+    if world > 1 and not args.no_secondary:
+        other = "weak" if args.scaling == "strong" else "strong"
+        try:
+            n2 = args.points * world if other == "weak" else args.points
+            model2, step2 = build(n2, args.atten_dropout, args.parallel)
+            k2 = max(2, min(args.steps, 5))
+            e2, _, _, _ = measure(step2, k2, 1, False)
+            weak = dict(scaling=other, points=n2, ms_per_step=e2 / k2 * 1e3, value=n2 / (e2 / k2), steps=k2, launch="eager")
+            del model2, step2
+        except Exception as ex:
+            weak = dict(scaling=other, error=f"{type(ex).__name__}: {ex}")
+
+    def make_out(elapsed, launch_txt, host_ms):
         ms = elapsed / args.steps * 1e3
-        e = n_for_kernels * args.knn
-        work = algorithmic_work(n_for_kernels // world, m_lat, e // world, e // world, s_tok, args.layers,
+        e = n_total * args.knn
+        work = algorithmic_work(n_total // world, m_lat, e // world, e // world, s_tok, args.layers,
                                 heads=8 // world if (world > 1 and args.parallel != "replicated" and 8 % world == 0) else 8)
         peaks = {"mfma": (157.3 if args.precision == "fp32" else 2500.0, "TFLOP/s"), "hbm": (8000.0, "GB/s")}
         per_kernel = {}
@@ -457,9 +489,8 @@ def main(argv=None):
                 pass
         troof = step_roofline_ms(n_total // world, m_lat, n_total * args.knn // world, n_total * args.knn // world, s_tok,
                                  args.layers, args.precision)
-        if world > 1:   # per-rank work of a perfectly divided step (Transformer rows / heads and points over the ranks)
+        if world > 1 and args.parallel == "seq":   # per-rank work of a perfectly divided step (token rows / heads / points)
             troof["transformer_ms"] /= world
-            troof["adamw_ms"] = troof["adamw_ms"]
             troof["t_roof_ms"] = troof["transformer_ms"] + troof["gno_ms"] + troof["per_node_ms"] + troof["adamw_ms"]
         troof = {kk: round(v, 4) for kk, v in troof.items()}
         troof["frac"] = round(troof["t_roof_ms"] / ms, 4)
@@ -477,7 +508,7 @@ def main(argv=None):
                          "head": f"point-shard x{world}; latent Transformer replicated except the attention heads "
                                  f"(all-gather of head outputs)",
                          "replicated": f"point-shard x{world}; latent Transformer replicated"}[args.parallel]
-        out = {
+        return {
             "metric": metric,
             "value": n_total / (elapsed / args.steps),
             "unit": "points/s",
@@ -499,9 +530,9 @@ def main(argv=None):
                        "precision": args.precision, "points_per_gpu": n_total // world, "atten_dropout": args.atten_dropout,
                        "sharding": shard_txt},
             "loss": float(loss.detach()),
-            "launch": "hipGraph replay of one captured step" if graph is not None else "eager",
+            "launch": launch_txt,
             "kernel_launches_per_step": launches,
-            "host_ms_per_step_timed_region": round(t_host_main / args.steps * 1e3, 3),
+            "host_ms_per_step_timed_region": round(host_ms / args.steps * 1e3, 3),
             # wall / host time of the two instrumented eager steps (right after a capture the eager allocations go back
             # to hipMalloc, so with a captured graph these overstate a warmed-up eager step)
             "instrumented_eager_ms_per_step": round(t_eager * 1e3, 3),
@@ -514,12 +545,40 @@ def main(argv=None):
             "kernels": {kname: {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in ent.items()}
                         for kname, ent in per_kernel.items()},
         }
+
+    launch_txt = "hipGraph replay of one captured step" if graph is not None else "eager"
+    out = make_out(elapsed, launch_txt, t_host_main) if rank == 0 else None
+    attempted = False
+    if world > 1 and graph is None and not args.no_graph and not args.no_graph_attempt and not one_device:
+        def on_timeout():
+            if rank == 0:
+                out["graph_attempt"] = f"no result after {args.graph_attempt_timeout:.0f} s: eager result reported"
+                print(json.dumps(out))
+                sys.stdout.flush()
+        attempted = True
+        res, note = measure_graph_guarded(step, args.steps, args.warmup, on_timeout, args.graph_attempt_timeout)
+        if rank == 0:
+            out["graph_attempt"] = note
+            if res is not None:
+                eg, _, _, thg = res
+                out["eager"] = dict(ms_per_step=out["ms_per_step"], value=out["value"])
+                out["graph"] = dict(ms_per_step=eg / args.steps * 1e3, value=n_total / (eg / args.steps))
+                if eg < elapsed:
+                    eager_keep, attempt = out["eager"], out["graph_attempt"]
+                    out = make_out(eg, "hipGraph replay of one captured step (RCCL collectives captured)", thg)
+                    out["eager"], out["graph"], out["graph_attempt"] = eager_keep, dict(ms_per_step=out["ms_per_step"], value=out["value"]), attempt
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline, args.layers, args.knn, args.seed, args.atten_dropout,
                                                args.points, latent)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
+        if attempted or graph is not None:
+            # tearing the process group down after its collectives were captured into a hipGraph was seen to block
+            # (1-rank RCCL group, tools/try_graph_rccl1.py): the result is out, leave without the teardown
+            sys.stderr.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,7 +38,9 @@ def _attention_fp64(qkv, w, freqs, keep, p_eff, chunk=2048):
     x = qkv.double().requires_grad_(True)
     q, k, v = (t.view(1, s, 1, 32).transpose(1, 2) for t in x.split(32, dim=1))
     if freqs is not None:
-        q, k = orc.rope_rotate(q, freqs.double()), orc.rope_rotate(k, freqs.double())
+        # fp32 frequencies: the reference forms the rotation angles position * frequency in fp32 (rotary_embedding_torch on
+        # fp32 tensors), and at position 16 383 that rounding (~1e-3 rad) is part of the operator's definition
+        q, k = orc.rope_rotate(q, freqs.float()), orc.rope_rotate(k, freqs.float())
     outs = []
     for lo in range(0, s, chunk):
         hi = min(lo + chunk, s)

@@ -115,8 +115,8 @@ def test_cfg0_vs_oracle(precision):
         close("cfg0/pred", pred, pred_r, 1e-4, 2e-5)
         close("cfg0/loss", loss, loss_r, 1e-5, 1e-7)
         for k, p in model.named_parameters():
-            if p.requires_grad:
-                close(f"cfg0/grad/{k}", p.grad, grads_r[k], 1e-3, 1e-5)
+            if p.requires_grad:   # atol relative to the tensor's peak: the rescaled last layer multiplies every gradient
+                close(f"cfg0/grad/{k}", p.grad, grads_r[k], 1e-3, 1e-5 * max(1.0, float(grads_r[k].abs().max())))
     else:
         # bf16 bar (outputs rtol 2e-2, loss rtol 1e-2, gradient cosine >= 0.999), stated relative to the
         # reference's peak so that it scales with the signal: max|pred - oracle| <= 2e-2 * max|oracle|, relative L2 <= 1e-2

@@ -6,7 +6,7 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 if [ "$2" != "notests" ]; then
   rm -f $out/${tag}_parity.txt
-  GAOT_PARITY_LOG=$out/${tag}_parity.txt python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $out/${tag}_tests.log
+  GAOT_PARITY_LOG=$out/${tag}_parity.txt python -m pytest tests -q -m gpu --maxfail=12 2>&1 | tail -40 > $out/${tag}_tests.log
 fi
 python bench.py --steps 10 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 export TMPDIR=/tmp

@@ -31,13 +31,14 @@ side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(2): l0 = step()
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
-print("eager loss", float(l0))
+print("eager loss", float(l0), flush=True)
+print("capturing", flush=True)
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
     loss = step()
 for i in range(3):
     g.replay(); torch.cuda.synchronize(); print("replay", i, float(loss))
 t0 = time.perf_counter()
 for _ in range(5): g.replay()
 torch.cuda.synchronize(); print("ms/step graph", (time.perf_counter() - t0) / 5 * 1e3)
-dist.destroy_process_group()
+os._exit(0)   # destroy_process_group() blocks after the group's collectives were captured
