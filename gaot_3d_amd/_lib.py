@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgaot3d_hip.so")
+# GAOT_LIB: another build of the same library (kernel A/B experiments: tools/); default = the in-tree build
+LIB_PATH = os.environ.get("GAOT_LIB") or os.path.join(_HERE, "lib", "libgaot3d_hip.so")
 
 MAX_MLP_LAYERS = 5
 

@@ -65,19 +65,24 @@ __device__ __forceinline__ void gelu_fast_pair(float x, float& g, float& dg) {
     const float u = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
     const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float h = 0.5f * t * p * e;             // Phi(-|x|)
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);              // the 1/2 of Phi folded into the coefficients
+    p = fmaf(t, p, 0.5f * 1.421413741f);
+    p = fmaf(t, p, 0.5f * -0.284496736f);
+    p = fmaf(t, p, 0.5f * 0.254829592f);
+    const float h = t * p * e;                    // Phi(-|x|)
     const float cdf = x >= 0.f ? 1.0f - h : h;
     g = x * cdf;
     dg = fmaf(x * e, 0.39894228040143267794f, cdf);
 }
-__device__ __forceinline__ float gelu_fast(float x) {
-    float g, dg;
-    gelu_fast_pair(x, g, dg);
-    return g;
+__device__ __forceinline__ float gelu_fast(float x) {   // same function, forward only: no Phi(x) select
+    const float u = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(t, p, 0.5f * 1.421413741f);
+    p = fmaf(t, p, 0.5f * -0.284496736f);
+    p = fmaf(t, p, 0.5f * 0.254829592f);
+    return fmaf(-fabsf(x), t * p * e, fmaxf(x, 0.f));   // x Phi(x) = max(x, 0) - |x| Phi(-|x|)
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

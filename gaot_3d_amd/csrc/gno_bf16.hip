@@ -8,6 +8,8 @@
 //   * the fp32 C/D tile of a layer is rounded to bf16 IN REGISTERS into the two k-step fragments of the next
 //     layer (k order 16s + 8(j>>2) + 4*half + (j&3), cdna_hip_programming.md §3); the weights are laid out in LDS
 //     (forward) as ready-made per-lane fragments in that same k order, one conflict-free ds_read_b128 each.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "gno_common.h"
@@ -682,6 +684,11 @@ int launch_bwd_b(const BwdImgs& im, const MlpPtrs& p, const float* y_pos, const 
 
 }  // namespace
 
+int gaot_gno_bwd2_bf16_launch(int n_hidden, const void* images, const float* w0t, const float* const* w, const float* const* b,
+                              const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
+                              const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
+                              int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st);
+
 size_t gaot_gno_bwd_bf16_image_bytes(int n_hidden) { return sizeof(bf16_t) * (size_t)bwd_img_elems(n_hidden) + 256; }
 
 // called from gaot_gno_bwd (gno.hip) for precision == 1.  `images` = scratch of gaot_gno_bwd_bf16_image_bytes();
@@ -702,6 +709,12 @@ int gaot_gno_bwd_bf16_dispatch(int n_hidden, const float* const* w, const float*
     for (int l = 1; l < n_hidden; ++l) { im.bw[l] = q; q += per_hidden; }
     im.bw[n_hidden] = q;
     im.w0t = w0t;
+    // second design (gno_bwd2_bf16.hip: LDS-resident operand images, one weight-gradient phase per 128 edges);
+    // GAOT_GNO_BWD_V1=1 keeps the first design for A/B measurements
+    static const bool v1 = getenv("GAOT_GNO_BWD_V1") != nullptr;
+    if (!v1)
+        return gaot_gno_bwd2_bf16_launch(n_hidden, images, w0t, w, b, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src,
+                                         num_edges, grad_f, part, wpart, grid, st);
     switch (n_hidden) {
         case 1: return launch_bwd_b<1>(im, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
         case 2: return launch_bwd_b<2>(im, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
