@@ -987,7 +987,10 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
-    if (a.drop.thr)
+    static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;   // A/B switch (tools/microbench.py)
+    if (a.drop.thr && nt_env == 3)
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true>), fgrid, dim3(256), 0, st, a);
+    else if (a.drop.thr)
         GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);   // 128-key stages: -2 % with the mask work
     else
         GAOT_KLAUNCH((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
@@ -1035,8 +1038,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         // one key block per wave: 2 workgroups per CU (256 registers) when the grid is small or the dropout words are
         // live (at 4 per CU the dropout variant spills: 0.83 -> 0.49 ms at S = 16384, H = 4)
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
+        static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;
         if (kb_dkv) {
-            if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            // dropout: 64-query stages (NT = 2) keep the kernel free of scratch spills (237 registers; the 128-query
+            // form spilled 25) and measure 3 % faster: 0.848 -> 0.823 ms at S = 16384, H = 8
+            if (drop && nt_env == 4) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
             else GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
             if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<2, true>), g1, dim3(256), 0, st, a);
@@ -1049,8 +1056,11 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 4) {
         const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), ny, (unsigned)B);
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
+        static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;
         if (kb_dq) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
-            if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            // dropout: 64-key stages, no scratch spills (the 128-key form spilled 11 registers), same time
+            if (drop && nt_env == 4) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
+            else if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
             else GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
             if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_bf16<2, true>), g1, dim3(256), 0, st, a);
