@@ -170,21 +170,21 @@ __global__ void k_colsum_part4(const float* __restrict__ x, int64_t M, int64_t N
 }
 
 // ---------------------------------------------------------------------------------------------
-// RoPE, in place: rows of width ld; nheads heads of 32 starting at column col0.  pos = row % S.
+// RoPE, in place: rows of width ld; nheads heads of head_dim = 2 * HP starting at column col0.  pos = row % S.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rope(float* __restrict__ x, int64_t rows, int64_t ld, int col0, int nheads, int S,
+__global__ void k_rope(float* __restrict__ x, int64_t rows, int64_t ld, int col0, int nheads, int HP, int S,
                        const float* __restrict__ freqs, float sign) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = rows * nheads * 16;
+    const int64_t n = rows * nheads * HP;
     if (i >= n) return;
-    const int p = (int)(i % 16);
-    const int hd = (int)((i / 16) % nheads);
-    const int64_t row = i / (16 * nheads);
+    const int p = (int)(i % HP);
+    const int hd = (int)((i / HP) % nheads);
+    const int64_t row = i / ((int64_t)HP * nheads);
     const float ang = (float)(row % S) * freqs[p];
     float sn, cs;
     sincosf(ang, &sn, &cs);
     sn *= sign;
-    float2* px = reinterpret_cast<float2*>(x + row * ld + col0 + hd * 32 + 2 * p);
+    float2* px = reinterpret_cast<float2*>(x + row * ld + col0 + hd * (2 * HP) + 2 * p);
     const float2 v = *px;
     *px = make_float2(v.x * cs - v.y * sn, v.y * cs + v.x * sn);
 }
@@ -527,16 +527,13 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
 extern "C" int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head_dim, int seq_len,
                          const float* freqs, int inverse, gaot_stream_t stream) {
     GAOT_ENTER();
-    if (head_dim != 32) {
-        gaot_set_error("gaot_rope: head_dim %d unsupported (only 32)", head_dim);
-        return GAOT_ERR_UNSUPPORTED;
-    }
+    GAOT_CHECK_ARG(head_dim >= 2 && head_dim % 2 == 0, "head_dim must be even");
     GAOT_CHECK_ARG(rows >= 0 && nheads > 0 && seq_len > 0 && ld % 2 == 0 && col0 % 2 == 0, "bad shape");
     if (rows == 0) return GAOT_OK;
     GAOT_CHECK_ARG(x && freqs, "null pointer");
-    const int64_t n = rows * nheads * 16;
-    GAOT_KLAUNCH(k_rope, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, rows, ld, col0, nheads, seq_len,
-                       freqs, inverse ? -1.f : 1.f);
+    const int64_t n = rows * nheads * (head_dim / 2);
+    GAOT_KLAUNCH(k_rope, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, rows, ld, col0, nheads, head_dim / 2,
+                       seq_len, freqs, inverse ? -1.f : 1.f);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -333,6 +333,94 @@ def dropout(x: Tensor, p: float, training: bool) -> Tensor:
     return DropoutFn.apply(x, float(p)) if (training and p > 0.0) else x
 
 
+class MatmulFn(Function):
+    """C = A B (trans_b False) or A B^T (True) on contiguous 2-D fp32 matrices, exact-fp32 MFMA GEMM, with its autograd"""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, trans_b: bool):
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        m, k = a.shape
+        n = b.shape[0] if trans_b else b.shape[1]
+        ctx.save_for_backward(a, b)
+        ctx.trans_b = trans_b
+        return ops.gemm(a, b, m, n, k, k, b.shape[1], False, trans_b, precision=0)
+
+    @staticmethod
+    def backward(ctx, dc: Tensor):
+        a, b = ctx.saved_tensors
+        dc = dc if dc.is_contiguous() else dc.contiguous()
+        m, k = a.shape
+        n = dc.shape[1]
+        if ctx.trans_b:   # C = A B^T, B [n, k]: dA = dC B ; dB = dC^T A
+            da = ops.gemm(dc, b, m, k, n, n, k, False, False, precision=0)
+            db = ops.gemm(dc, a, n, k, m, n, k, True, False, precision=0)
+        else:             # C = A B, B [k, n]: dA = dC B^T ; dB = A^T dC
+            da = ops.gemm(dc, b, m, k, n, n, n, False, True, precision=0)
+            db = ops.gemm(a, dc, k, n, m, k, n, True, False, precision=0)
+        return da, db, None
+
+
+class RowSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, s: Tensor):
+        w = ops.row_softmax(s if s.is_contiguous() else s.contiguous())
+        ctx.save_for_backward(w)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw: Tensor):
+        (w,) = ctx.saved_tensors
+        return ops.row_softmax(w, grad=dw if dw.is_contiguous() else dw.contiguous(), w=w)
+
+
+class RopeFn(Function):
+    """1-D RoPE over the flattened token index on the q and k heads of a fused projection, any even head_dim"""
+
+    @staticmethod
+    def forward(ctx, qkv: Tensor, freqs: Tensor, rows: int, s: int, nheads: int, head_dim: int):
+        out = qkv.clone()
+        ops.rope_(out, rows, out.shape[1], 0, nheads, s, freqs, False, head_dim)
+        ctx.save_for_backward(freqs)
+        ctx.meta = (rows, s, nheads, head_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        (freqs,) = ctx.saved_tensors
+        rows, s, nheads, head_dim = ctx.meta
+        g = d.clone()
+        ops.rope_(g, rows, g.shape[1], 0, nheads, s, freqs, True, head_dim)
+        return g, None, None, None, None, None
+
+
+def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, head_dim: int,
+                      dropout_p: float = 0.0) -> Tensor:
+    """softmax(Q K^T / sqrt(d)) V for ANY head_dim (reference attn.py:110-127 accepts every hidden_size % num_heads == 0):
+    the unfused general path -- per (batch, head) an S x S score matrix in HBM, exact-fp32 MFMA GEMMs, the row softmax and
+    element dropout kernels, autograd by composition.  head_dim 32 (every shipped configuration) runs the flash kernels."""
+    from . import edgeops as EO
+    rows = b * s
+    if freqs is not None:
+        qkv = RopeFn.apply(qkv, freqs, rows, s, h + hkv, head_dim)
+    scale = torch.full((s,), 1.0 / (head_dim ** 0.5), dtype=torch.float32, device=qkv.device)
+    rep = h // hkv
+    outs = []
+    for bi in range(b):
+        blk = qkv[bi * s:(bi + 1) * s]
+        heads = []
+        for hi in range(h):
+            kv = hi // rep
+            q = EO.RowScaleFn.apply(blk[:, hi * head_dim:(hi + 1) * head_dim].contiguous(), scale)
+            k = blk[:, (h + kv) * head_dim:(h + kv + 1) * head_dim]
+            v = blk[:, (h + hkv + kv) * head_dim:(h + hkv + kv + 1) * head_dim]
+            p = RowSoftmaxFn.apply(MatmulFn.apply(q, k, True))
+            p = dropout(p, dropout_p, dropout_p > 0.0)
+            heads.append(MatmulFn.apply(p, v, False))
+        outs.append(torch.cat(heads, dim=1))
+    return outs[0] if b == 1 else torch.cat(outs, dim=0)
+
+
 class SwiGLUFn(Function):
     @staticmethod
     def forward(ctx, ag: Tensor, f: int):

@@ -71,9 +71,7 @@ class GroupQueryFlashAttention(nn.Module):
         self.num_heads = num_heads
         self.num_kv_heads = num_kv_heads
         self.num_repeat = num_heads // num_kv_heads
-        self.head_dim = hidden_size // num_heads
-        if self.head_dim != 32:
-            raise NotImplementedError(f"head_dim {self.head_dim}: the HIP attention kernels are built for head_dim 32")
+        self.head_dim = hidden_size // num_heads   # 32: flash kernels; anything else: the unfused general path
         self.atten_dropout = atten_dropout
         kv_hidden = self.head_dim * num_kv_heads
         self.q_proj = nn.Linear(input_size, hidden_size, bias=False)
@@ -95,7 +93,11 @@ class GroupQueryFlashAttention(nn.Module):
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
         seq_group = getattr(self, "_seq_group", None)
-        if seq_group is not None:
+        if self.head_dim != 32:
+            if seq_group is not None or getattr(self, "_head_group", None) is not None:
+                raise NotImplementedError("the sharded attention exchanges are written for head_dim 32")
+            o = GF.attention_general(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, self.head_dim, dp)
+        elif seq_group is not None:
             # sequence-parallel (gaot_3d_amd/sharding.py): x holds this rank's token rows; one all-to-all hands every rank
             # ALL rows of ITS heads, the kernels run unchanged on them, a second all-to-all brings the rows back
             import torch.distributed as dist

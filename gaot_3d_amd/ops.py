@@ -291,10 +291,29 @@ def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional
     return dx, dw
 
 
-def rope_(buf: Tensor, rows: int, ld: int, col0: int, nheads: int, seq_len: int, freqs: Tensor, inverse: bool):
+def rope_(buf: Tensor, rows: int, ld: int, col0: int, nheads: int, seq_len: int, freqs: Tensor, inverse: bool,
+          head_dim: int = 32):
     lib = _lib.load()
-    check(lib.gaot_rope(_ptr(buf), rows, ld, col0, nheads, 32, seq_len, _ptr(freqs), int(inverse), _stream()),
+    check(lib.gaot_rope(_ptr(buf), rows, ld, col0, nheads, head_dim, seq_len, _ptr(freqs), int(inverse), _stream()),
           "gaot_rope")
+
+
+def row_softmax(scores: Tensor, grad: Optional[Tensor] = None, w: Optional[Tensor] = None) -> Tensor:
+    """softmax over the last axis of a dense [rows, n] fp32 matrix (grad / w given: its backward ds = w (dw - sum(w dw))):
+    the per-row segment kernels of csrc/edgeops.hip on the row pointer 0, n, 2n, ..."""
+    lib = _lib.load()
+    rows, n = scores.shape
+    if rows * n >= 2 ** 31:
+        raise GaotError("row_softmax: more than 2^31 scores")
+    rowptr = torch.arange(0, rows * n + 1, n, dtype=torch.int32, device=scores.device)
+    out = torch.empty_like(scores)
+    if grad is None:
+        check(lib.gaot_segment_softmax_fwd(_ptr(_req(scores, torch.float32, "scores")), _ptr(rowptr), rows, _ptr(out), _stream()),
+              "gaot_segment_softmax_fwd")
+    else:
+        check(lib.gaot_segment_softmax_bwd(_ptr(w), _ptr(_req(grad, torch.float32, "dw")), _ptr(rowptr), rows, _ptr(out), _stream()),
+              "gaot_segment_softmax_bwd")
+    return out
 
 
 def _drop_args(p: float, seed: Optional[Tensor]):

@@ -205,3 +205,38 @@ def test_neighbour_list_cache_is_never_stale():
         o3 = model2(batch=batch, tokens_pos=tokens)
     assert not torch.equal(o1, o2)
     close("cache/in_place_edit", o2, o3, 0.0, 0.0)
+
+
+@pytest.mark.parametrize("hidden,heads,kv_heads,rope,s", [(64, 4, 2, True, 77), (128, 2, 2, False, 130), (96, 2, 1, True, 33)])
+def test_attention_any_head_dim_matches_oracle(hidden, heads, kv_heads, rope, s):
+    """the reference accepts every hidden_size % num_heads == 0 (attn.py:66-67); head_dim 16 / 64 / 48 run the unfused
+    general path (S x S scores per head in HBM, exact-fp32 GEMMs, row softmax) and equal the oracle's attention, forward
+    and every gradient; with dropout the step runs and its masks differ from call to call"""
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers.attn import GroupQueryFlashAttention
+    gaot_3d_amd.set_precision("fp32")
+    torch.manual_seed(hidden + s)
+    att = GroupQueryFlashAttention(hidden, hidden, hidden_size=hidden, num_heads=heads, num_kv_heads=kv_heads,
+                                   atten_dropout=0.0, positional_embedding="rope" if rope else "absolute")
+    assert att.head_dim == hidden // heads and att.head_dim != 32
+    sd = {"a." + k: v.detach().clone() for k, v in att.state_dict().items()}
+    x = torch.randn(2, s, hidden)
+    w = torch.randn(2, s, hidden)
+    leaves = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "freqs" not in k) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = orc.attention(leaves, "a.", xr, heads, kv_heads, rope)
+    (ref * w).sum().backward()
+    att = att.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    out = att(xd, relative_positions=True if rope else None)
+    (out * w.to(DEV)).sum().backward()
+    tag = f"attn_general_hd{att.head_dim}"
+    close(f"{tag}/out", out, ref, 1e-4, 1e-5)
+    close(f"{tag}/dx", xd.grad, xr.grad, 1e-3, 1e-5)
+    for k, p in att.named_parameters():
+        if p.requires_grad:
+            close(f"{tag}/grad/{k}", p.grad, leaves["a." + k].grad, 1e-3, 1e-5)
+    att.atten_dropout = 0.2
+    with torch.no_grad():
+        a, b = att(xd, relative_positions=True if rope else None), att(xd, relative_positions=True if rope else None)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
