@@ -78,6 +78,9 @@ SIGNATURES = {
     "gaot_knn_grid": (_i, [_p, _i64, _p, _p, _i, _p, _p]),
     "gaot_radius_grid_count": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p]),
     "gaot_radius_grid_fill": (_i, [_p, _i64, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "gaot_knn_brute": (_i, [_p, _i64, _p, _i64, _i, _p, _p]),
+    "gaot_radius_brute_count": (_i, [_p, _i64, _p, _i64, _f, _i, _p, _p]),
+    "gaot_radius_brute_fill": (_i, [_p, _i64, _p, _i64, _f, _i, _p, _p, _p, _p]),
     "gaot_exclusive_scan_workspace_bytes": (_sz, [_i64]),
     "gaot_exclusive_scan_i32": (_i, [_p, _i64, _p, _p, _sz, _p]),
     "gaot_segment_cap_flags": (_i, [_p, _p, _i64, _i, _p, _p]),

@@ -121,6 +121,77 @@ __global__ __launch_bounds__(256) void k_radius_grid(const float* __restrict__ p
     if (!FILL) counts[i] = n;
 }
 
+// ---- token sets that are NOT a regular grid (custom `tokens_pos`: the reference's get_neighbor_strategy takes any latent
+// coordinates, magno.py:116-124): every point scans ALL tokens, staged through LDS in tiles -- O(N M) distance evaluations on
+// the device (6.5 x 10^10 at configs[1] sizes: milliseconds) instead of an N x M distance matrix in host or device memory.
+// Same distance arithmetic, order and tie rules as the grid kernels above, so the lists are identical where both apply.
+constexpr int BRUTE_TILE = 2048;
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_brute(const float* __restrict__ pos, int64_t N, const float* __restrict__ tok,
+                                                   int64_t M, int* __restrict__ out) {
+    __shared__ float ts[BRUTE_TILE * 3];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    const float px = live ? pos[3 * i] : 0.f, py = live ? pos[3 * i + 1] : 0.f, pz = live ? pos[3 * i + 2] : 0.f;
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = FLT_MAX; bi[j] = 0x7fffffff; }
+    for (int64_t t0 = 0; t0 < M; t0 += BRUTE_TILE) {
+        const int nt = (int)min((int64_t)BRUTE_TILE, M - t0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nt * 3; j += 256) ts[j] = tok[t0 * 3 + j];
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const float d = dist2(ts, j, px, py, pz);
+            const int lin = (int)(t0 + j);
+            if (d < bd[K - 1] || (d == bd[K - 1] && lin < bi[K - 1])) {
+                bd[K - 1] = d;
+                bi[K - 1] = lin;
+#pragma unroll
+                for (int q = K - 1; q > 0; --q) {
+                    const bool lt = bd[q] < bd[q - 1] || (bd[q] == bd[q - 1] && bi[q] < bi[q - 1]);
+                    if (lt) {
+                        const float td = bd[q]; bd[q] = bd[q - 1]; bd[q - 1] = td;
+                        const int ti = bi[q]; bi[q] = bi[q - 1]; bi[q - 1] = ti;
+                    }
+                }
+            }
+        }
+    }
+    if (live)
+#pragma unroll
+        for (int j = 0; j < K; ++j) out[i * K + j] = bi[j];
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_radius_brute(const float* __restrict__ pos, int64_t N, const float* __restrict__ tok,
+                                                      int64_t M, float radius, int cap, int* __restrict__ counts,
+                                                      const int* __restrict__ offsets, int* __restrict__ out_center,
+                                                      int* __restrict__ out_other) {
+    __shared__ float ts[BRUTE_TILE * 3];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    const float px = live ? pos[3 * i] : 0.f, py = live ? pos[3 * i + 1] : 0.f, pz = live ? pos[3 * i + 2] : 0.f;
+    const float r2 = radius * radius;
+    int n = 0;
+    const int o = (FILL && live) ? offsets[i] : 0;
+    for (int64_t t0 = 0; t0 < M; t0 += BRUTE_TILE) {
+        const int nt = (int)min((int64_t)BRUTE_TILE, M - t0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nt * 3; j += 256) ts[j] = tok[t0 * 3 + j];
+        __syncthreads();
+        if (live)
+            for (int j = 0; j < nt && n < cap; ++j)
+                if (dist2(ts, j, px, py, pz) <= r2) {
+                    if (FILL) { out_center[o + n] = (int)i; out_other[o + n] = (int)(t0 + j); }
+                    ++n;
+                }
+    }
+    if (!FILL && live) counts[i] = n;
+}
+
 // flags[i] = 1 when element i of a key-sorted list is among the first `cap` of its segment
 __global__ void k_segment_cap_flags(const int* __restrict__ rowptr, const int* __restrict__ key_sorted, int64_t P, int cap,
                                     int* __restrict__ flags) {
@@ -234,6 +305,62 @@ extern "C" int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_gr
             return GAOT_ERR_UNSUPPORTED;
     }
 #undef GAOT_KNN
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_knn_brute(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens, int k,
+                              int32_t* out_idx, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_points >= 0 && num_tokens >= 1, "bad size");
+    GAOT_CHECK_ARG(k >= 1 && k <= 32 && k <= num_tokens, "k must be in [1, min(32, number of tokens)]");
+    if (num_points == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
+#define GAOT_KNNB(KK) GAOT_KLAUNCH((k_knn_brute<KK>), grd, blk, 0, st, pos, num_points, token_pos, num_tokens, out_idx)
+    switch (k) {
+        case 1: GAOT_KNNB(1); break;
+        case 2: GAOT_KNNB(2); break;
+        case 3: GAOT_KNNB(3); break;
+        case 4: GAOT_KNNB(4); break;
+        case 5: GAOT_KNNB(5); break;
+        case 6: GAOT_KNNB(6); break;
+        case 7: GAOT_KNNB(7); break;
+        case 8: GAOT_KNNB(8); break;
+        case 12: GAOT_KNNB(12); break;
+        case 16: GAOT_KNNB(16); break;
+        case 32: GAOT_KNNB(32); break;
+        default:
+            gaot_set_error("gaot_knn_brute: k = %d is not instantiated (1-8, 12, 16, 32)", k);
+            return GAOT_ERR_UNSUPPORTED;
+    }
+#undef GAOT_KNNB
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_radius_brute_count(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens,
+                                       float radius, int cap, int32_t* counts, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_points >= 0 && num_tokens >= 0 && radius >= 0.f && cap >= 1, "bad argument");
+    if (num_points == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(pos && counts && (token_pos || num_tokens == 0), "null pointer");
+    GAOT_KLAUNCH((k_radius_brute<false>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                 num_points, token_pos, num_tokens, radius, cap, counts, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_radius_brute_fill(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens,
+                                      float radius, int cap, const int32_t* offsets, int32_t* out_point, int32_t* out_token,
+                                      gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_points >= 0 && num_tokens >= 0 && radius >= 0.f && cap >= 1, "bad argument");
+    if (num_points == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(pos && offsets && out_point && out_token, "null pointer");
+    GAOT_KLAUNCH((k_radius_brute<true>), dim3((unsigned)ceil_div(num_points, 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                 num_points, token_pos, num_tokens, radius, cap, (int*)nullptr, offsets, out_point, out_token);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -61,6 +61,16 @@ def as_latent_grid(latent_pos: Tensor, dims: Sequence[int], rtol: float = 1e-4) 
     return LatentGrid((d, h, w), tuple(lo), tuple(hi), p)
 
 
+@dataclass
+class TokenSet:
+    """latent tokens that are NOT a regular grid: searched by the brute-force device kernels (every point scans all tokens)"""
+    pos: Tensor   # [M, 3] fp32 on the device
+
+    @property
+    def num_tokens(self) -> int:
+        return int(self.pos.shape[0])
+
+
 def _need_cuda(t: Tensor, what: str):
     if not t.is_cuda:
         raise GaotError(f"{what}: device graph construction runs on the HIP device only (got a {t.device} tensor)")
@@ -83,6 +93,10 @@ def knn_to_grid(phys_pos: Tensor, grid: LatentGrid, k: int) -> Tensor:
     lib = _lib.load()
     p = phys_pos.detach().to(torch.float32).contiguous()
     out = torch.empty(p.shape[0], k, dtype=torch.int32, device=p.device)
+    if isinstance(grid, TokenSet):
+        check(lib.gaot_knn_brute(ops._ptr(p), p.shape[0], ops._ptr(grid.pos), grid.num_tokens, k, ops._ptr(out), ops._stream()),
+              "gaot_knn_brute")
+        return out
     gs = grid.c_struct()
     check(lib.gaot_knn_grid(ops._ptr(p), p.shape[0], C.byref(gs), ops._ptr(grid.pos), k, ops._ptr(out), ops._stream()),
           "gaot_knn_grid")
@@ -96,16 +110,24 @@ def radius_pairs(phys_pos: Tensor, grid: LatentGrid, radius: float, cap: Optiona
     lib = _lib.load()
     p = phys_pos.detach().to(torch.float32).contiguous()
     n = p.shape[0]
-    gs = grid.c_struct()
+    brute = isinstance(grid, TokenSet)
+    gs = None if brute else grid.c_struct()
     capv = int(cap) if cap is not None else 0x7fffffff
     counts = torch.empty(n, dtype=torch.int32, device=p.device)
-    check(lib.gaot_radius_grid_count(ops._ptr(p), n, C.byref(gs), ops._ptr(grid.pos), float(radius), capv, ops._ptr(counts),
-                                     ops._stream()), "gaot_radius_grid_count")
+    if brute:
+        check(lib.gaot_radius_brute_count(ops._ptr(p), n, ops._ptr(grid.pos), grid.num_tokens, float(radius), capv,
+                                          ops._ptr(counts), ops._stream()), "gaot_radius_brute_count")
+    else:
+        check(lib.gaot_radius_grid_count(ops._ptr(p), n, C.byref(gs), ops._ptr(grid.pos), float(radius), capv, ops._ptr(counts),
+                                         ops._stream()), "gaot_radius_grid_count")
     offs = exclusive_scan(counts)
     total = int(offs[-1])     # host sync: sizes the output
     pt = torch.empty(total, dtype=torch.int32, device=p.device)
     tk = torch.empty(total, dtype=torch.int32, device=p.device)
-    if total:
+    if total and brute:
+        check(lib.gaot_radius_brute_fill(ops._ptr(p), n, ops._ptr(grid.pos), grid.num_tokens, float(radius), capv, ops._ptr(offs),
+                                         ops._ptr(pt), ops._ptr(tk), ops._stream()), "gaot_radius_brute_fill")
+    elif total:
         check(lib.gaot_radius_grid_fill(ops._ptr(p), n, C.byref(gs), ops._ptr(grid.pos), float(radius), capv, ops._ptr(offs),
                                         ops._ptr(pt), ops._ptr(tk), ops._stream()), "gaot_radius_grid_fill")
     return pt, tk
@@ -242,12 +264,18 @@ def get_neighbor_strategy(neighbor_strategy: str, phys_pos: Tensor, batch_idx_ph
     ``latent_tokens_pos`` holds the tokens of every graph of the batch back to back (gaot_3d.py:283-285: the same grid
     tiled ``num_graphs`` times); ``batch_idx_*`` are the sorted PyG batch vectors (None = one graph)."""
     _need_cuda(phys_pos, "get_neighbor_strategy")
-    if latent_dims is None:
-        raise GaotError("get_neighbor_strategy (device): latent_dims=(D, H, W) is required")
-    m = int(latent_dims[0]) * int(latent_dims[1]) * int(latent_dims[2])
-    nb = latent_tokens_pos.shape[0] // m
-    if nb * m != latent_tokens_pos.shape[0]:
-        raise GaotError("latent token count is not a multiple of D*H*W")
+    lat = latent_tokens_pos.detach().to(phys_pos.device, torch.float32).contiguous()
+    m = int(latent_dims[0]) * int(latent_dims[1]) * int(latent_dims[2]) if latent_dims is not None else 0
+    regular = m > 0 and lat.shape[0] % m == 0 and lat.shape[0] > 0
+    if regular:
+        nb = lat.shape[0] // m
+        lptr = [b * m for b in range(nb + 1)]
+    else:   # any token set: the graphs of the batch are the runs of the (sorted) token batch vector
+        if batch_idx_latent is None or batch_idx_latent.numel() == 0:
+            nb, lptr = 1, [0, lat.shape[0]]
+        else:
+            nb = int(batch_idx_latent.max().item()) + 1
+            lptr = [0] + torch.cumsum(torch.bincount(batch_idx_latent, minlength=nb), 0).tolist()
     if batch_idx_phys is None or nb == 1:
         ptr = [0, phys_pos.shape[0]]
     else:
@@ -255,11 +283,19 @@ def get_neighbor_strategy(neighbor_strategy: str, phys_pos: Tensor, batch_idx_ph
         ptr = [0] + torch.cumsum(cnt, 0).tolist()
     outs = []
     for b in range(nb):
-        grid = as_latent_grid(latent_tokens_pos[b * m:(b + 1) * m], latent_dims)
+        toks = lat[lptr[b]:lptr[b + 1]]
+        grid = None
+        if regular:
+            try:
+                grid = as_latent_grid(toks, latent_dims)
+            except GaotError:
+                grid = None
+        if grid is None:   # not the reference's regular grid: brute-force kernels (csrc/graph.hip: k_knn_brute, k_radius_brute)
+            grid = TokenSet(toks)
         p = phys_pos[ptr[b]:ptr[b + 1]]
         e = (_decoder_edges if is_decoder else _encoder_edges)(neighbor_strategy, p, grid, radius, k_neighbors)
         if b:
-            inc = torch.tensor([[b * m], [ptr[b]]] if is_decoder else [[ptr[b]], [b * m]], dtype=torch.int32, device=e.device)
+            inc = torch.tensor([[lptr[b]], [ptr[b]]] if is_decoder else [[ptr[b]], [lptr[b]]], dtype=torch.int32, device=e.device)
             e = e + inc
         outs.append(e)
     return outs[0] if nb == 1 else torch.cat(outs, dim=1)

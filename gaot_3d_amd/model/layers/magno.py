@@ -94,11 +94,12 @@ def get_neighbor_strategy(neighbor_strategy: str, phys_pos, batch_idx_phys, late
     """Edge construction with the reference's conventions (magno.py:116-295): encoder edges are
     [phys_idx, latent_idx], decoder edges [latent_idx, phys_idx]; 'bidirectional' = coalesce(knn U radius);
     'reverse' (decoder only) = flip of the *bidirectional* encoder graph; PyG radius keeps at most 32
-    neighbours per centre.  With the points on the HIP device and ``latent_dims`` given (the tokens are the
-    model's regular D x H x W grid) the graph is built by the device kernels (gaot_3d_amd/graph.py,
-    csrc/graph.hip); otherwise by the brute-force torch restatement below (host-side data preparation, also
-    the checker of the device path in tests/test_graph_gpu.py)."""
-    if latent_dims is not None and phys_pos.is_cuda:
+    neighbours per centre.  With the points on the HIP device the graph is built by the device kernels
+    (gaot_3d_amd/graph.py, csrc/graph.hip): closed-form cell lookups when the tokens are the model's regular
+    D x H x W grid (``latent_dims``), brute-force scans of all tokens for any other token set; for CPU tensors by
+    the brute-force torch restatement below (host-side data preparation, also the checker of the device path in
+    tests/test_graph_gpu.py)."""
+    if phys_pos.is_cuda:   # device kernels: cell lookups on the regular token grid, brute-force scans for any other token set
         from ... import graph as device_graph
         return device_graph.get_neighbor_strategy(neighbor_strategy, phys_pos, batch_idx_phys, latent_tokens_pos,
                                                   batch_idx_latent, radius, k_neighbors, is_decoder, latent_dims=latent_dims)

@@ -287,6 +287,15 @@ int gaot_radius_grid_count(const float* pos, int64_t num_points, const gaot_grid
 int gaot_radius_grid_fill(const float* pos, int64_t num_points, const gaot_grid_t* grid, const float* token_pos,
                           float radius, int cap, const int32_t* offsets, int32_t* out_point, int32_t* out_token,
                           gaot_stream_t stream);
+/* The same searches against token coordinates that are NOT a regular grid (custom `tokens_pos`; the reference's
+ * get_neighbor_strategy takes any latent coordinates, magno.py:116-124): every point scans all tokens, staged through LDS
+ * -- O(N M) on the device, no N x M distance matrix.  Same order and tie rules as the grid forms. */
+int gaot_knn_brute(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens, int k, int32_t* out_idx,
+                   gaot_stream_t stream);
+int gaot_radius_brute_count(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens, float radius,
+                            int cap, int32_t* counts, gaot_stream_t stream);
+int gaot_radius_brute_fill(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens, float radius,
+                           int cap, const int32_t* offsets, int32_t* out_point, int32_t* out_token, gaot_stream_t stream);
 size_t gaot_exclusive_scan_workspace_bytes(int64_t n);
 int gaot_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* workspace, size_t workspace_bytes,
                             gaot_stream_t stream);

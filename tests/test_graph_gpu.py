@@ -271,3 +271,72 @@ def test_neural_field_training_step():
     for k, p in model.named_parameters():
         if p.requires_grad:
             assert torch.allclose(p.grad.cpu(), leaf[k].grad, rtol=1e-3, atol=1e-5), (k, (p.grad.cpu() - leaf[k].grad).abs().max().item())
+
+
+@pytest.mark.parametrize("strategy,is_decoder", [("knn", False), ("radius", False), ("bidirectional", False), ("knn", True),
+                                                 ("radius", True), ("bidirectional", True), ("reverse", True)])
+def test_arbitrary_token_sets_on_the_device(strategy, is_decoder):
+    """the reference's get_neighbor_strategy takes ANY latent coordinates (magno.py:116-124).  Token sets that are not a
+    regular grid (random tokens, different counts per graph of the batch) are searched by the brute-force device kernels:
+    identical edge lists to the host restatement; and on a regular grid the brute-force kernels return exactly what the
+    cell-lookup kernels return."""
+    from gaot_3d_amd import graph
+    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy as strategy_fn
+    g = torch.Generator().manual_seed(5)
+    lat = torch.cat([torch.rand(333, 3, generator=g) * 2 - 1, torch.rand(2500, 3, generator=g) * 2 - 1])
+    bl = torch.cat([torch.zeros(333, dtype=torch.long), torch.ones(2500, dtype=torch.long)])
+    pos = torch.cat([_points(700, 1, -1, 1), _points(450, 2, -1, 1)])
+    bp = torch.cat([torch.zeros(700, dtype=torch.long), torch.ones(450, dtype=torch.long)])
+    ref = strategy_fn(strategy, pos, bp, lat, bl, 0.3, 3, is_decoder)                      # CPU tensors: torch restatement
+    got = strategy_fn(strategy, pos.to(DEV), bp.to(DEV), lat.to(DEV), bl.to(DEV), 0.3, 3, is_decoder).cpu().long()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if strategy == "knn":
+        assert _as_set(got) == _as_set(ref)
+    else:
+        assert torch.equal(got, ref)
+    # a regular grid through both kernel families
+    dims = (6, 5, 4)
+    grid = _grid(dims).to(DEV)
+    p = _points(900, 7, -1.2, 1.2).to(DEV)
+    fn = graph._decoder_edges if is_decoder else graph._encoder_edges
+    a = fn(strategy, p, graph.as_latent_grid(grid, dims), 0.45, 3)
+    b = fn(strategy, p, graph.TokenSet(grid), 0.45, 3)
+    assert torch.equal(a, b)
+
+
+def test_model_with_custom_token_set_builds_its_graphs_on_the_device():
+    """precompute_edges=False with tokens that are a PERMUTED, jittered copy of the grid (so not a regular grid): the
+    forward runs on the device kernels and equals the forward on the same edges precomputed by the host restatement"""
+    import gaot_3d_amd
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy as strategy_fn
+    gaot_3d_amd.set_precision("fp32")
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
+    from gaot_3d_amd.model.layers.magno import MAGNOConfig
+    import types
+    cfg = types.SimpleNamespace(
+        magno=MAGNOConfig(gno_coord_dim=3, lifting_channels=32, encoder_feature_attr=["pos", "c"], mlp_type="linear",
+                          use_geoembed=[True, False], neighbor_strategy="bidirectional", k_neighbors=2, gno_radius=0.3,
+                          precompute_edges=False),
+        transformer=TransformerConfig(patch_size=2, hidden_size=256, num_layers=2, positional_embedding="absolute",
+                                      attn_config=AttentionConfig(atten_dropout=0.0), ffn_config=FFNConfig()),
+        latent_tokens=(4, 4, 4))
+    torch.manual_seed(0)
+    model = init_model(6, 1, "gaot_3d", cfg).to(DEV).eval()
+    batch, tokens = make_synthetic_sample(1500, cfg.latent_tokens, k=2, seed=0, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    tok = (tokens.cpu() + 0.05 * torch.randn(tokens.shape, generator=g)).to(DEV)    # jittered: no longer a grid
+    with torch.no_grad():
+        out = model(batch=batch, tokens_pos=tok)
+    zeros_p = torch.zeros(1500, dtype=torch.long)
+    zeros_l = torch.zeros(64, dtype=torch.long)
+    enc = strategy_fn("bidirectional", batch.pos.cpu(), zeros_p, tok.cpu(), zeros_l, 0.3, 2, False)
+    dec = strategy_fn("bidirectional", batch.pos.cpu(), zeros_p, tok.cpu(), zeros_l, 0.3, 2, True)
+    batch.encoder_edge_index_s0, batch.decoder_edge_index_s0 = enc.to(DEV), dec.to(DEV)
+    cfg.magno.precompute_edges = True
+    torch.manual_seed(0)
+    model2 = init_model(6, 1, "gaot_3d", cfg).to(DEV).eval()
+    with torch.no_grad():
+        ref = model2(batch=batch, tokens_pos=tok)
+    assert torch.equal(out, ref)
