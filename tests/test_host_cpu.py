@@ -258,3 +258,82 @@ def test_sample_reader_without_pyg(tmp_path):
     assert e.decoder_edge_index_s0.shape == (2, 80) and int(e.decoder_query_counts_s0.sum()) == 80
     assert torch.equal(e.encoder_query_counts_s0.long(), torch.bincount(e.encoder_edge_index_s0[1].long(), minlength=27))
     assert float(e.pos.min()) == float(s.pos.min())          # coordinates stay as stored; edges use the rescaled copy
+
+
+def test_dataset_transforms_stats_and_loader(tmp_path):
+    """reference data layer on plain files (no PyG): order-file split (incl. rand_dataset's default_rng(42) shuffle), the
+    three transforms, the normalisation-statistics file (keys, unbiased std, reload), and the loader's collation with the
+    EnrichedData.__inc__ offsets -- all against direct torch / numpy restatements of the reference lines"""
+    import types
+    import numpy as np
+    from gaot_3d_amd import dataset as D
+    from gaot_3d_amd.data import MeshBatch, knn_edges_bruteforce, latent_grid
+    from gaot_3d_amd.io import save_sample
+    root = tmp_path / "data"
+    (root / "processed").mkdir(parents=True)
+    g = torch.Generator().manual_seed(0)
+    lat = latent_grid((3, 3, 2))
+    names, samples = [], []
+    for i in range(7):
+        n = 40 + 5 * i
+        pos = torch.rand(n, 3, generator=g) * 3 - 1
+        enc = knn_edges_bruteforce(pos, lat, 2)
+        s = MeshBatch(pos=pos, x=torch.randn(n, 2, 1, generator=g) * (i + 1), c=torch.randn(n, 3, generator=g) + i,
+                      encoder_edge_index_s0=enc.to(torch.int32), decoder_edge_index_s0=enc.flip(0).to(torch.int32),
+                      num_latent_nodes=lat.shape[0], filename=f"s{i}")
+        save_sample(s, str(root / "processed" / f"s{i}.pt"))
+        names.append(f"s{i}")
+        samples.append(s)
+    order = tmp_path / "order.txt"
+    order.write_text("\n".join(names) + "\n")
+    cfg = types.SimpleNamespace(name="toy", base_path=str(root), processed_folder="processed", train_size=4, val_size=2,
+                                test_size=1, rand_dataset=False, active_variables=[1])
+    tr = D.VTKMeshDataset(str(root), str(order), cfg, "train")
+    va = D.VTKMeshDataset(str(root), str(order), cfg, "val")
+    te = D.VTKMeshDataset(str(root), str(order), cfg, "test")
+    assert tr.split_filenames == ["s0.pt", "s1.pt", "s2.pt", "s3.pt"] and va.split_filenames == ["s4.pt", "s5.pt"]
+    assert te.split_filenames == ["s6.pt"] and len(tr) == 4
+    s0 = tr[0]
+    assert s0.x.shape == (40, 1) and torch.equal(s0.x[:, 0], samples[0].x[:, 1, 0])      # active_variables + squeeze(-1)
+    cfg_r = types.SimpleNamespace(**{**cfg.__dict__, "rand_dataset": True})
+    idx = np.arange(7)
+    np.random.default_rng(seed=42).shuffle(idx)
+    assert D.VTKMeshDataset(str(root), str(order), cfg_r, "train").split_filenames == [f"s{i}.pt" for i in idx[:4]]
+    with pytest.raises(ValueError):
+        D.VTKMeshDataset(str(root), str(order), cfg, "bogus")
+    # transforms
+    p = samples[2].pos.clone()
+    want = (p - p.min()) / (p.max() - p.min()) * 2 - 1
+    assert torch.allclose(D.RescalePosition()(MeshBatch(pos=p.clone())).pos, want)
+    dom = ([-1.16, -1.2, 0.0], [4.21, 1.19, 1.77])
+    want = (p - (-1.2)) / (4.21 - (-1.2)) * 2 - 1
+    assert torch.allclose(D.RescalePositionNew(phy_domain=dom)(MeshBatch(pos=p.clone())).pos, want)
+    # statistics: all training points, unbiased std, positions irrelevant
+    stats = D.calculate_or_load_stats(cfg, str(order), str(root))
+    allx = torch.cat([samples[i].x[:, [1], 0] for i in range(4)])
+    allc = torch.cat([samples[i].c for i in range(4)])
+    assert torch.allclose(stats["mean"], allx.mean(0), atol=1e-6) and torch.allclose(stats["std"], allx.std(0), rtol=1e-5)
+    assert torch.allclose(stats["c_mean"], allc.mean(0), atol=1e-6) and torch.allclose(stats["c_std"], allc.std(0), rtol=1e-5)
+    assert os.path.exists(root / "toy_norm_stats.pt")
+    again = D.calculate_or_load_stats(cfg, str(order), str(root))            # loaded from the file
+    assert all(torch.equal(stats[k], again[k]) for k in stats)
+    norm = D.NormalizeFeatures(stats["mean"], stats["std"], stats["c_mean"], stats["c_std"])
+    b = norm(MeshBatch(x=allx.clone(), c=allc.clone()))
+    assert torch.allclose(b.x, (allx - stats["mean"]) / (stats["std"] + 1e-10)) and abs(float(b.c.mean())) < 1e-5
+    # loader: B = 2 batches carry the __inc__ offsets (encoder rows +[nodes, latent], decoder rows +[latent, nodes])
+    tf = D.Compose([D.RescalePosition(), norm])
+    ds = D.VTKMeshDataset(str(root), str(order), cfg, "train", transform=tf)
+    batches = list(D.SampleLoader(ds, batch_size=2, device="cpu", num_latent_nodes=lat.shape[0]))
+    assert len(batches) == 2 and batches[0].num_graphs == 2
+    b0 = batches[0]
+    n0 = samples[0].pos.shape[0]
+    e0, e1 = samples[0].encoder_edge_index_s0, samples[1].encoder_edge_index_s0
+    want = torch.cat([e0, e1 + torch.tensor([[n0], [lat.shape[0]]], dtype=torch.int32)], dim=1)
+    assert torch.equal(b0.encoder_edge_index_s0, want) and torch.equal(b0.decoder_edge_index_s0, want.flip(0))
+    assert torch.equal(b0.batch, torch.cat([torch.zeros(n0, dtype=torch.long), torch.ones(45, dtype=torch.long)]))
+    assert b0.ptr.tolist() == [0, 40, 85]
+    shuffled = D.SampleLoader(ds, batch_size=1, device="cpu", shuffle=True, seed=3)
+    a = [bb.pos.shape[0] for bb in shuffled]
+    shuffled.set_epoch(1)
+    c = [bb.pos.shape[0] for bb in shuffled]
+    assert sorted(a) == sorted(c) == [40, 45, 50, 55] and a != c
