@@ -6,7 +6,7 @@ endpoint (encoder: source, decoder: query), so edges, features, targets and pred
 ranks.  Latent coordinates, the latent Transformer and all parameters are replicated.
 
 Exchange steps (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
-  forward : encoder GNO   per-token SUM [M,C] and COUNT [M]  -> all_reduce(SUM) -> mean = sum / max(count,1)
+  forward : encoder GNO   per-token SUM [M,C] and COUNT [M], one fused [M,C+1] all_reduce(SUM) -> mean = sum / max(count,1)
   backward: decoder       partial d(loss)/d(latent) [M,C]    -> all_reduce(SUM) before the (replicated, hence
             identical) Transformer backward
   after backward: gradients of the per-point / per-edge parameters (encoder.lifting, encoder.gno, decoder.*)
@@ -90,13 +90,12 @@ class GlobalSegmentMeanFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local_mean: Tensor, local_deg: Tensor, group):
-        s = local_mean * local_deg[:, None]
-        d = local_deg.clone()
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
-        dg = d.clamp(min=1.0)
+        # ONE all-reduce of [M, C + 1]: the per-token sums (the kernel's mean times its own edge count) and the counts
+        buf = torch.cat([local_mean * local_deg[:, None], local_deg[:, None]], dim=1)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        dg = buf[:, -1].clamp(min=1.0)
         ctx.save_for_backward(local_deg / dg)
-        return s / dg[:, None]
+        return buf[:, :-1] / dg[:, None]
 
     @staticmethod
     def backward(ctx, g: Tensor):
