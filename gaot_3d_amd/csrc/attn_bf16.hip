@@ -932,8 +932,8 @@ __global__ void k_sum_parts(const float* __restrict__ parts, int P, int64_t part
 // number of range parts for a launch whose unsplit grid has `wgs` workgroups: aim at eight workgroups per CU,
 // keep at least 1024 streamed rows per part
 int split_parts(int64_t wgs, int S) {
-    constexpr int tgt = 2048;   // measured at S = 16384 with 1 / 2 / 4 heads: 2048 workgroups beat 512 and 1024
-    if (wgs >= tgt) return 1;
+    constexpr int tgt = 2048;   // measured at S = 16384 with 1 / 2 / 4 heads: 2048 workgroups beat 512 and 1024;
+    if (wgs >= tgt / 2) return 1;   // with 8 heads (1024 workgroups) the unsplit launch ties the split one + its combine pass
     int p = (int)std::min<int64_t>(8, ceil_div(tgt, wgs));
     p = std::min(p, std::max(1, S / 1024));
     return std::max(p, 1);

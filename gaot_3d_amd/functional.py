@@ -174,11 +174,14 @@ class RMSNormFn(Function):
         ctx.save_for_backward(xc, weight, rstd)
         yb = yb if yb is not None else torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(yb)
+        ctx.set_materialize_grads(False)   # no zero-filled [rows, d] gradient for the bf16 copy
         return y, yb
 
     @staticmethod
-    def backward(ctx, dy: Tensor, _dyb):
+    def backward(ctx, dy: Optional[Tensor], _dyb=None):
         x, w, rstd = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(x)
         d = dy if dy.is_contiguous() else dy.contiguous()
         dx, dw = ops.rmsnorm_bwd(x, w, d, rstd)
         return dx, dw, None
@@ -232,6 +235,7 @@ class RMSNormResFn(Function):
         ctx.save_for_backward(xc, weight, rstd)
         yb = yb if yb is not None else torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(yb)
+        ctx.set_materialize_grads(False)   # an unused output (the bf16 copy, the residual) gets None, not a zero fill
         return y, xc.detach(), yb
 
     @staticmethod

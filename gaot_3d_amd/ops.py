@@ -14,7 +14,13 @@ from ._lib import GaotError, MlpGradT, MlpT, check
 Tensor = torch.Tensor
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> C.c_void_p:
+    """the current stream's hipStream_t (the raw getter is ~20x cheaper than building a torch.cuda.Stream per launch)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
