@@ -206,7 +206,7 @@ def test_model_full_size_bidirectional_graph_built_on_device(sample):
 def test_configs4_size_eight_million_points_multi_field():
     """BASELINE configs[4] size on ONE GPU (what an 8-way point shard of a 64 M-point mesh would hand each rank, and
     the unsharded upper end of the path's index ranges): N = 8 000 000 points, E = 64 M edges per direction, 4 output
-    fields (pressure + 3 wall-shear components, metadata.py:145-161), L = 2 to bound the test time.  Size-independent
+    fields (pressure + 3 wall-shear components, metadata.py:145-161), L = 10 as in the shipped configs.  Size-independent
     checks: CSR invariants at E = 64 M, a finite loss near the variance of the N(0,1) target, finite gradients for
     every parameter, and bit-identical loss / gradients when the step is repeated (fixed-order reductions)."""
     import gaot_3d_amd
@@ -230,7 +230,7 @@ def test_configs4_size_eight_million_points_multi_field():
     torch.manual_seed(0)
     gaot_3d_amd.set_precision("bf16")
     try:
-        model = init_model(6, 4, "gaot_3d", _config(2)).to(DEV).train()
+        model = init_model(6, 4, "gaot_3d", _config(10)).to(DEV).train()
         runs = []
         for _ in range(2):
             gaot_3d_amd.clear_graph_cache(batch)
