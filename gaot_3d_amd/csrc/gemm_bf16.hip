@@ -404,6 +404,11 @@ int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t
 
 }  // namespace
 
+bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                               int64_t ldc, int c16);
+int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
+                          int c16, hipStream_t st);
+
 // called by gaot_gemm / gaot_gemm_ex (gemm.hip) for precision == 1 when the output is wide enough for the 128-wide tile.
 // dt: bit 0 = A is bf16 in memory, bit 1 = B, bit 2 = C (leading dimensions always in elements).
 int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact, const float* bias,
@@ -413,6 +418,11 @@ int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact
     GArgs g{A, B, C, preact, bias, residual, M, N, K, lda, ldb, ldc, ldr, act, splits, kps};
     const bool a_ks = a_trans != 0;   // A(m,k) = A[k*lda + m]
     const bool b_ks = b_trans == 0;   // B(k,n) = B[k*ldb + n]
+    // x W^T with K = 256, both operands bf16 in memory and a bare epilogue (q|k|v and w1|w3 forward): weights-in-registers kernel
+    static const bool k256_on = !(getenv("GAOT_GEMM_K256") && atoi(getenv("GAOT_GEMM_K256")) == 0);
+    if (k256_on && !a_ks && !b_ks && (dt & 3) == 3 && splits <= 1 && !bias && !residual && !preact && act == 0 &&
+        gaot_gemm_k256_applicable(A, B, C, M, N, K, lda, ldb, ldc, (dt & 4) != 0))
+        return gaot_gemm_k256_launch(A, B, C, M, N, lda, ldb, ldc, (dt & 4) != 0, st);
     if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, dt, st);
     if (!a_ks && b_ks) return launch<false, true>(g, a_vec, b_vec, splits, dt, st);
     if (a_ks && !b_ks) return launch<true, false>(g, a_vec, b_vec, splits, dt, st);

@@ -1,0 +1,168 @@
+// C[M,N] = A[M,256] . W[N,256]^T for the d_model = 256 projections of the latent Transformer whose operands already are
+// bf16 in memory (q|k|v and w1|w3 forward: x is the bf16 image RMSNorm wrote, W the per-forward bf16 weight copy;
+// reference attn.py:104-106,156 -> nn.Linear).  These GEMMs are output-write / latency bound (K = 256: four 64-deep
+// steps), so the design removes re-reads and staging work instead of chasing MFMA issue:
+//   * WEIGHTS IN REGISTERS: a wave keeps its 64 output columns x K = 256 of W as 128 VGPRs of ready MFMA fragments for the
+//     whole launch (the generic kernel re-reads the weight panel from L2 once per 64-row tile: 256 times at M = 16 384);
+//   * activation rows arrive as 64-row blocks by LDS-DMA (buffer_load ... lds, 1 KB per wave-instruction, no VGPR staging);
+//     the LDS image is lane-linear, the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied
+//     to the SOURCE address; two blocks in LDS, the next block's DMA is waited for AFTER this block's MFMAs;
+//   * the product is formed transposed (W fragment as the MFMA's A operand), so a lane owns one output ROW and stores
+//     16 bytes at a time (bf16 results: v_permlane32_swap pairs the two half-waves' 8-byte runs);
+//   * workgroup id -> (XCD, column panel, row chunk): the workgroups of one XCD share one 1/8 slice of the rows.
+// Measured (tools/lab/gemm_k256_lab.hip, M = 16 384): N = 2048 bf16 out 53.8 -> 32.0 us, N = 768 fp32 out 25.4 -> 22.5 us.
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KK = 256, RB = 64, STAGE = RB * KK * 2;   // one staged row block: 64 rows x 512 B = 32 KB
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(bf16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)b) << 16);
+}
+
+template <bool C16>
+__global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, void* __restrict__ C,
+                                                       int M, int N, int lda, int ldw, int ldc, int P, int subs) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, panel = j % P, sub = j / P;
+    const int nblk = (M + RB - 1) / RB, c = xcd * subs + sub, nch = 8 * subs;
+    const int t0 = (int)((int64_t)c * nblk / nch), t1 = (int)((int64_t)(c + 1) * nblk / nch);
+    if (t0 >= t1) return;                                    // uniform over the workgroup
+    const int n0 = panel * 256 + wave * 64;
+    const bool wave_ok = n0 < N;                             // N % 64 == 0: a wave's 64 columns are all inside or all outside
+
+    // the wave's weight slice as MFMA fragments: element (n = l31, k = 16 s + 8 hf + 0..7) of column tile jt
+    bf16x8 bw[2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        int n = n0 + 32 * jt + l31;
+        n = n < N ? n : N - 1;
+        const bf16_t* p = W + (int64_t)n * ldw + 8 * hf;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bw[jt][s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+    }
+
+    const int64_t abytes = (int64_t)M * lda * 2, cbytes = (int64_t)M * ldc * (C16 ? 2 : 4);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(abytes > 0x7fffffff ? 0x7fffffff : abytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(cbytes > 0x7fffffff ? 0x7fffffff : cbytes), 0x00020000);
+    auto stage = [&](int t, int buf) {
+        const int lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // DMA piece q = wave*8 + i fills tile rows 2q, 2q+1: lane>>5 picks the row, lane&31 the 16-byte slot of the row;
+            // slot s of row r holds source chunk s ^ (r & 15)  (rows past M read as zero through the buffer bounds)
+            const int x = 2 * i + lh;                                    // == row & 15
+            const int voff = (wave * 16 + x) * lda * 2 + (((lane & 31) ^ x) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (wave * 8 + i) * 1024), 16, voff,
+                                                     t * RB * lda * 2, 0, 0);
+        }
+    };
+
+    stage(t0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        __builtin_amdgcn_s_barrier();            // block t has landed for every wave; nobody still reads the other buffer
+        if (t + 1 < t1) stage(t + 1, buf ^ 1);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+        const char* base = lds + buf * STAGE + l31 * 512;
+        const int sw = l31 & 15;
+        bf16x8 a0 = *reinterpret_cast<const bf16x8*>(base + ((hf ^ sw) << 4));
+        bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + 32 * 512 + ((hf ^ sw) << 4));
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8 b0 = a0, b1 = a1;
+            if (s + 1 < 16) {
+                a0 = *reinterpret_cast<const bf16x8*>(base + (((2 * s + 2 + hf) ^ sw) << 4));
+                a1 = *reinterpret_cast<const bf16x8*>(base + 32 * 512 + (((2 * s + 2 + hf) ^ sw) << 4));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][s], b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[1][s], b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[0][s], b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[1][s], b1, acc[1][1], 0, 0, 0);
+        }
+        // the next block's DMA (and the previous block's stores) have had the whole MFMA phase to complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // acc[jt][i][r]: column n = n0 + 32 jt + mfma32_row(r, hf), row m = 64 t + 32 i + l31
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = t * RB + 32 * i + l31;
+            const unsigned rowoff = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * (C16 ? 2u : 4u) : 0x80000000u;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                if constexpr (C16) {
+                    unsigned pk[4][2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pk[q][0] = pack2(acc[jt][i][4 * q], acc[jt][i][4 * q + 1]);
+                        pk[q][1] = pack2(acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {   // runs (q, q+2): lower lanes end with columns 8q..8q+7, upper lanes with 16+8q..
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 2][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 2][1], false, false);
+                        const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                        const int n = n0 + 32 * jt + 8 * q + 16 * hf;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, crs, rowoff + n * 2, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + 32 * jt + 8 * q + 4 * hf;
+                        const f32x4 v = {acc[jt][i][4 * q], acc[jt][i][4 * q + 1], acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs, rowoff + n * 4, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool C16>
+int launch_k256(const void* A, const void* W, void* C, int M, int N, int lda, int ldw, int ldc, hipStream_t st) {
+    auto kern = k_gemm_k256<C16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        if (e != hipSuccess) {
+            gaot_set_error("gemm_k256: cannot set dynamic LDS %d: %s", 2 * STAGE, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int P = (N + 255) / 256, nblk = (M + RB - 1) / RB;
+    // ~512 workgroups (two per CU), but never more row chunks than row blocks
+    int subs = std::max(1, 64 / P);
+    subs = std::max(1, std::min(subs, (nblk + 7) / 8));
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * P * subs)), dim3(256), 2 * STAGE, st, (const bf16_t*)A, (const bf16_t*)W, C, M, N, lda, ldw, ldc,
+                 P, subs);
+    return GAOT_OK;
+}
+
+}  // namespace
+
+// 1 if the shape / layout is one this kernel takes (checked by gaot_gemm_bf16_dispatch before it falls to the generic tile kernel)
+bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                               int64_t ldc, int c16) {
+    const int64_t esz = c16 ? 2 : 4;
+    return K == KK && M >= 1 && N >= 64 && N % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (ldc * esz) % 16 == 0 &&
+           ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0 && M * lda * 2 < 0x7fffffff &&
+           M * ldc * esz < 0x7fffffff && lda >= KK && ldw >= KK;
+}
+
+int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
+                          int c16, hipStream_t st) {
+    if (c16) return launch_k256<true>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, st);
+    return launch_k256<false>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, st);
+}

@@ -233,6 +233,11 @@ def test_multi_linear_colocated(m, k, ns, precision):
     (64, 128, 72, False, True, True, False, True),        # A and C bf16, ragged K tail (72 = 64 + 8)
     (500, 2048, 256, False, True, True, True, True),      # A, B and C bf16 (w1|w3 forward on the RMSNorm's bf16 image)
     (256, 768, 1000, True, False, False, True, False),    # dy^T x_bf16 (weight gradient of q|k|v on the bf16 image)
+    # K = 256 with bf16 A and B and a bare epilogue: the weights-in-registers kernel (gemm_k256.hip)
+    (4096, 768, 256, False, True, True, True, False),     # q|k|v forward shape, fp32 result
+    (130, 320, 256, False, True, True, True, True),       # ragged rows, N % 256 != 0 (idle waves in the last panel)
+    (1, 128, 256, False, True, True, True, False),        # one row
+    (9000, 128, 256, False, True, True, True, True),      # more row blocks than row chunks
 ])
 def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     """gaot_gemm_ex: operands / result that are bf16 in memory must give what the fp32-in-memory bf16 GEMM gives on the

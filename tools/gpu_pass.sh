@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box pass: parity tests, graph bench, eager rocprof kernel stats, PMC traffic passes.  usage: gpu_pass.sh <tag> [notests]
+# One GPU-box pass: parity tests, eager rocprof kernel stats, PMC traffic passes, then the graph bench (which reports the fresh traffic).  usage: gpu_pass.sh <tag> [notests]
 tag=${1:-pass}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
@@ -8,7 +8,6 @@ if [ "$2" != "notests" ]; then
   rm -f $out/${tag}_parity.txt
   GAOT_PARITY_LOG=$out/${tag}_parity.txt python -m pytest tests -q -m gpu --maxfail=12 2>&1 | tail -40 > $out/${tag}_tests.log
 fi
-python bench.py --steps 10 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $out/${tag}_prof --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-secondary > $out/${tag}_prof.log 2>&1
@@ -16,6 +15,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch --output-form
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-secondary > $out/${tag}_pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json $tag > /dev/null 2>$out/${tag}_pmc.err
+# the bench line reads the traffic file of THESE kernel sources (hash-stamped): refresh it before the timed run
+cp $out/${tag}_pmc_traffic.json profiles/pmc_traffic.json
+python bench.py --steps 10 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 # keep only the small summaries of the traces
 find $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*_kernel_trace.csv" -delete
 find $out/${tag}_pmc_fetch $out/${tag}_pmc_write -name "*_counter_collection.csv" -delete
