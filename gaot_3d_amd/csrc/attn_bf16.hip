@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
                             const int r = 4 * g4 + i;
                             const float p = __builtin_amdgcn_exp2f(sc[r]);
                             const bool keep = (ww[i] ^ bsel) >= a.drop.thr;
-                            sc[r] = keep ? p : 0.f;
+                            float pm = keep ? p : 0.f;
+                            asm volatile("" : "+v"(pm));   // select in fp32, then ONE cvt_pk per pair (see k_attn_bwd_dkv_kb)
+                            sc[r] = pm;
                             dp[r] = p * (keep ? dp[r] : dneg[r]);
                         }
                     }
@@ -646,7 +648,11 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
                                 const int r = 4 * g4 + i;
                                 const float p = __builtin_amdgcn_exp2f(sc[kb][r]);
                                 const bool keep = (ww[i] ^ bsel[kb]) >= a.drop.thr;
-                                sc[kb][r] = keep ? p : 0.f;
+                                float pm = keep ? p : 0.f;
+                                // keep the select on the fp32 value: without this the compiler rounds every p to bf16 on its own,
+                                // selects on the halves and re-packs them (2 cvt + 1 perm per pair instead of 1 cvt_pk)
+                                asm volatile("" : "+v"(pm));
+                                sc[kb][r] = pm;
                                 dp[kb][r] = p * (keep ? dp[kb][r] : dc[r]);
                             }
                     }
