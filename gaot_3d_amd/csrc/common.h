@@ -85,6 +85,40 @@ __device__ __forceinline__ float gelu_fast(float x) {   // same function, forwar
     return fmaf(-fabsf(x), t * p * e, fmaxf(x, 0.f));   // x Phi(x) = max(x, 0) - |x| Phi(-|x|)
 }
 
+// Two activations at a time on the packed-fp32 VALU forms (v_pk_fma_f32 / v_pk_mul_f32 run two lanes' worth of fp32 per
+// issue slot): the GNO kernels are bound by this arithmetic (192 activations per edge), and left to itself the compiler
+// packs only part of the scalar form.  Same approximation as gelu_fast / gelu_fast_pair, regrouped so that no select is
+// needed:  x Phi(x) = x/2 + |x| (1/2 - Phi(-|x|)),   Phi(x) = 1/2 + sign(x) (1/2 - Phi(-|x|)).
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32v2 gelu_half_minus_tail2(f32v2 x, f32v2 ax, f32v2& e) {   // 1/2 - Phi(-|x|), e = exp(-x^2/2)
+    const f32v2 d = __builtin_elementwise_fma(ax, (f32v2)(0.3275911f * 0.70710678118654752440f), (f32v2)(1.0f));
+    const f32v2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32v2 s = x * (f32v2)(0.84932180028801904272f);       // sqrt(log2(e) / 2): exp2(-(s*s)) = exp(-x^2/2)
+    const f32v2 q = s * s;
+    e = f32v2{__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    f32v2 p = __builtin_elementwise_fma(t, (f32v2)(0.5f * 1.061405429f), (f32v2)(0.5f * -1.453152027f));
+    p = __builtin_elementwise_fma(t, p, (f32v2)(0.5f * 1.421413741f));
+    p = __builtin_elementwise_fma(t, p, (f32v2)(0.5f * -0.284496736f));
+    p = __builtin_elementwise_fma(t, p, (f32v2)(0.5f * 0.254829592f));
+    const f32v2 tp = t * p;
+    return __builtin_elementwise_fma(-tp, e, (f32v2)(0.5f));
+}
+__device__ __forceinline__ f32v2 gelu_fast2(f32v2 x) {
+    const f32v2 ax = {fabsf(x[0]), fabsf(x[1])};
+    f32v2 e;
+    const f32v2 w = gelu_half_minus_tail2(x, ax, e);
+    return __builtin_elementwise_fma(ax, w, x * (f32v2)(0.5f));
+}
+__device__ __forceinline__ void gelu_fast_pair2(f32v2 x, f32v2& g, f32v2& dg) {
+    const f32v2 ax = {fabsf(x[0]), fabsf(x[1])};
+    f32v2 e;
+    const f32v2 w = gelu_half_minus_tail2(x, ax, e);
+    g = __builtin_elementwise_fma(ax, w, x * (f32v2)(0.5f));
+    const f32v2 sw = {copysignf(w[0], x[0]), copysignf(w[1], x[1])};
+    const f32v2 cdf = sw + (f32v2)(0.5f);
+    dg = __builtin_elementwise_fma(x * e, (f32v2)(0.39894228040143267794f), cdf);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[t][r] = gelu_fast(z[t][r]);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32v2 y = gelu_fast2(f32v2{z[t][r], z[t][r + 1]});
+                    z[t][r] = y[0]; z[t][r + 1] = y[1];
+                }
                 to_frags(z[t], hb[t][ob][0], hb[t][ob][1]);
             }
         }
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
 #pragma unroll
                 for (int ob = 0; ob < KB; ++ob) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) z[t][ob][r] = gelu_fast(z[t][ob][r]);
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32v2 y = gelu_fast2(f32v2{z[t][ob][r], z[t][ob][r + 1]});
+                        z[t][ob][r] = y[0]; z[t][ob][r + 1] = y[1];
+                    }
                     to_frags(z[t][ob], hb[t][ob][0], hb[t][ob][1]);
                 }
         }

@@ -246,12 +246,11 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
                 z = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(2 * i + hf) * H + 32 * ob + l31], bin[i], z, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float g0, d0, g1, d1;
-                gelu_fast_pair(z[r], g0, d0);
-                gelu_fast_pair(z[r + 1], g1, d1);
-                z[r] = g0;
-                z[r + 1] = g1;
-                gp[0][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+                f32v2 g, d;
+                gelu_fast_pair2(f32v2{z[r], z[r + 1]}, g, d);
+                z[r] = g[0];
+                z[r + 1] = g[1];
+                gp[0][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
             }
             const Packed16 pz = pack16(z);
             store_packed_rows(mine + L::h(0) + ob * TILE_BYTES, pz, l31, hf);
@@ -277,12 +276,11 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
             for (int ob = 0; ob < KB; ++ob) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    float g0, d0, g1, d1;
-                    gelu_fast_pair(z[ob][r], g0, d0);
-                    gelu_fast_pair(z[ob][r + 1], g1, d1);
-                    z[ob][r] = g0;
-                    z[ob][r + 1] = g1;
-                    gp[l][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+                    f32v2 g, d;
+                    gelu_fast_pair2(f32v2{z[ob][r], z[ob][r + 1]}, g, d);
+                    z[ob][r] = g[0];
+                    z[ob][r + 1] = g[1];
+                    gp[l][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
                 }
                 const Packed16 pz = pack16(z[ob]);
                 store_packed_rows(mine + L::h(l) + ob * TILE_BYTES, pz, l31, hf);
