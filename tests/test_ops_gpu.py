@@ -11,6 +11,8 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import gaot_oracle as orc  # noqa: E402  (checker only)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from parity import close_peak, cosine  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -324,6 +326,47 @@ def test_attention_spike_rows():
     out.sum().backward()
     close("attn_spike_out", out, ref, 1e-4, 1e-5)
     close("attn_spike_grad", qd.grad, qr.grad, 1e-3, 2e-5)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_bf16_deferred_rescale_branch(p_drop):
+    """The bf16 forward moves a row's reference value only when a score exceeds it by more than 2^6 (attn_bf16.hip:
+    RESCALE_THR); random scores never do, so the branch is forced here: key 150 is aligned with query 7 (its score jumps
+    by ~50 log2 units in a late tile: the rescale path), key 300 with query 9 just above that row's running maximum (growth
+    below the threshold: the path without rescale must cope with p > 1), and a third spike sits in the LAST, ragged tile.
+    Outputs and every gradient against the fp64 reference (dropout: given the kernel's own keep mask)."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    b, s, h = 1, 397, 2
+    qkv = gen(b * s, 6 * 32, seed=21)
+    qkv[150, 64:96] = qkv[7, 0:32] * 6.0          # head 0: k[150] ~ 6 q[7]
+    qkv[300, 64:96] = qkv[9, 0:32] * 0.6          # head 0: k[300] ~ 0.6 q[9]
+    qkv[390, 96:128] = qkv[11, 32:64] * 5.0       # head 1: k[390] ~ 5 q[11], in the last (13-key) tile
+    w = gen(b * s, h * 32, seed=22)
+    keep = None
+    if p_drop > 0:
+        keep = orc.dropout_keep_mask(777, b, h, s, p_drop)[0]          # [h, s, s]: the mask of the next call after set_dropout_seed(777)
+    qr = qkv.clone().double().requires_grad_(True)
+    q, k, v = [t.reshape(s, h, 32).transpose(0, 1) for t in (qr[:, :64], qr[:, 64:128], qr[:, 128:])]
+    pm = torch.softmax(q @ k.transpose(1, 2) / 32 ** 0.5, dim=-1)
+    if keep is not None:
+        pm = pm * keep.double() / (1.0 - round(p_drop * 65536) / 65536.0)
+    ref = (pm @ v).transpose(0, 1).reshape(s, h * 32)
+    (ref * w.double()).sum().backward()
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        if p_drop > 0:
+            GF.set_dropout_seed(777, DEV)
+        qd = qkv.to(DEV).requires_grad_(True)
+        out = GF.AttentionFn.apply(qd, None, b, s, h, h, p_drop)
+        (out * w.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    close_peak(f"attn_bf16_rescale_branch_p{p_drop}/out", out, ref, 2e-2, 1.5e-2)
+    cosine(f"attn_bf16_rescale_branch_p{p_drop}/dqkv", qd.grad, qr.grad, 0.999)
+    for row in (7, 9, 11):
+        close_peak(f"attn_bf16_rescale_branch_p{p_drop}/out_row{row}", out[row], ref[row], 3e-2)
 
 
 def test_rmsnorm_swiglu_rope_patchify_mse():
