@@ -197,12 +197,13 @@ __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf
 // ------------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 queries; K/V in 64-key stages (2 tiles each)
 // ------------------------------------------------------------------------------------------------
-// The running reference value m of a row need not be its exact maximum: p = exp2(S - m) only has to stay in range.  m moves
-// when some score of the tile exceeds it by more than RESCALE_THR (log2 units: p <= 64, row sums <= 64 S), otherwise the
-// tile takes the path without subtraction / rescale.  With the threshold at 0 every new row maximum in any of a wave's 32
-// rows sent the whole wave through the rescale path: ~40 % of the tiles at S = 16 384 on random scores.  o = acc / l and
-// lse = m ln2 + log l do not depend on where m sits.
-constexpr float RESCALE_THR = 6.0f;
+// The running reference value m of a row need not be its exact maximum: p = exp2(S - m) only has to stay in range.  A tile
+// first takes the optimistic path -- exp and row sums with NO maximum formed; m moves only when a lane's 16 values sum to more
+// than RESCALE_SUM = 2^6 (so no p above 64 is ever used; an overflowed exp shows up as an infinite sum), and then the
+// scores are recomputed (two MFMAs) and everything at the old scale is rescaled once.  With "rescale whenever a row maximum
+// grows" ~40 % of the tiles of a wave went through the rescale path at S = 16 384 on random scores; now a handful do.
+// o = acc / l and lse = m ln2 + log l do not depend on where m sits.
+constexpr float RESCALE_SUM = 64.0f;
 template <int OCC, int TPM, bool DROP>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
@@ -263,23 +264,48 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
             const char* kt = lds + t * TILE_BYTES;
             const char* vt = lds + (TPM + t) * TILE_BYTES;
             const bool first = (kb == lo);
-            f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
-            if (kb + 32 > a.S) {   // wave-uniform: only the last tile of the sequence
-                const int nv = (int)(a.S - kb);
+            f32x16 sc;
+            auto scores = [&]() {   // S - m for this tile (keys past the end of the sequence masked)
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], negm, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+                if (kb + 32 > a.S) {   // wave-uniform: only the last tile of the sequence
+                    const int nv = (int)(a.S - kb);
     #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+                    for (int r = 0; r < 16; ++r)
+                        if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+                }
+            };
+            float ps0 = 0.f, ps1 = 0.f;   // two scalar chains: packed-f32 adds cost more issue cycles beside MFMAs
+            auto exp_sum = [&]() {
+                ps0 = 0.f; ps1 = 0.f;
+    #pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                    sc[r + 1] = __builtin_amdgcn_exp2f(sc[r + 1]);
+                    ps0 += sc[r];
+                    ps1 += sc[r + 1];
+                }
+            };
+            scores();
+            bool slow = first;
+            if (!first) {
+                // optimistic path: no maximum is formed at all.  Every p is positive, so a lane whose 16 values sum to at most
+                // 2^RESCALE_THR holds no p above it; a larger (or infinite) sum sends the wave through the path below, which
+                // recomputes the scores (two MFMAs) and moves the reference values.
+                exp_sum();
+                if (__any(!(ps0 + ps1 <= RESCALE_SUM))) {
+                    scores();
+                    slow = true;
+                }
             }
-            float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+            if (slow) {
+                float mx = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
     #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
-            mx = fmaxf(mx, sc[15]);
-            mx = max_halves(mx);
-            if (first || __any(mx > RESCALE_THR)) {
-                // some row's score exceeds its reference value m by more than 2^RESCALE_THR: move the reference values (of
-                // every row of the wave whose maximum grew) and rescale everything that is at the old scale, in place
-                const float up = first ? mx : fmaxf(mx, 0.f);     // how far this lane's max moves (log2 units)
+                for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+                mx = fmaxf(mx, sc[15]);
+                mx = max_halves(mx);
+                // rescale everything that is at the old scale, in place
+                const float up = first ? mx : fmaxf(mx, 0.f);     // how far this lane's reference value moves (log2 units)
                 const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-up);
                 m += up;
                 l *= alpha;
@@ -289,14 +315,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                     acc[r] *= alpha;
                     negm[r] = -m;
                 }
-            }
-            float ps0 = 0.f, ps1 = 0.f;   // two scalar chains: packed-f32 adds cost more issue cycles beside MFMAs
-    #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                sc[r] = __builtin_amdgcn_exp2f(sc[r]);
-                sc[r + 1] = __builtin_amdgcn_exp2f(sc[r + 1]);
-                ps0 += sc[r];
-                ps1 += sc[r + 1];
+                exp_sum();
             }
             l += ps0 + ps1;   // per-half partial; the halves are added once, after the key loop
             bf16x8 p0, p1;
@@ -1001,12 +1020,18 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its max / exp / sum VALU work and loses more from the halved occupancy)
     static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;   // A/B switch (tools/microbench.py)
-    if (a.drop.thr && nt_env == 3)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true>), fgrid, dim3(256), 0, st, a);
+    // with the maximum-free tile path the kernels need ~150 registers: three waves per SIMD without scratch beat four with it
+    // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
+    if (a.drop.thr && nt_env == 4)
+        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);
     else if (a.drop.thr)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);   // 128-key stages: -2 % with the mask work
-    else
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true>), fgrid, dim3(256), 0, st, a);
+    else if (nt_env == 4)
         GAOT_KLAUNCH((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
+    else if (nt_env == 2)
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 2, false>), fgrid, dim3(256), 0, st, a);
+    else
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false>), fgrid, dim3(256), 0, st, a);
     if (P > 1)
         GAOT_KLAUNCH(k_attn_combine, dim3((unsigned)ceil_div(rows * H * 8, 256)), dim3(256), 0, st, o_parts, lse_parts,
                            (int)fgrid.y, o_part, lse_part, B, S, H, o, lse);
