@@ -234,7 +234,32 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
         // ---- recompute the MLP: gelu'(z) stays in registers (fp32), h_l goes to LDS as bf16 [edge][feature] ------------
         // gelu'(z) is kept as packed f16 pairs (in [-0.13, 1.13]: 11 significant bits against the 8 of the bf16 operands it
         // multiplies into): half the registers of the fp32 form, and the multiply reads the halves directly
-        unsigned gp[NH][KB][8];
+        // ... and, for the layers above the first, parked in LDS: gelu'(z_l) of this wave's tile waits in the slot its own
+        // dz_l tile will overwrite right after consuming it (same 4 KB, lane-linear 16-byte pieces).  Keeping 16 NH registers
+        // live across the whole MLP pushed every MFMA result into AGPRs: ~380 v_accvgpr_read per tile, a quarter of the
+        // VALU issue, plus 252 B of scratch for three hidden layers.  Layer 0 stays in registers: its slot dz(0) is the
+        // scratch of the segmented sums in between.
+        unsigned gp0[KB][8];
+        auto gp_store = [&](int l, int ob, const unsigned (&w)[8]) {
+            if (l == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gp0[ob][j] = w[j];
+                return;
+            }
+            char* p = mine + L::dz(l) + ob * 2048 + lane * 16;
+            *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(p + 1024) = make_uint4(w[4], w[5], w[6], w[7]);
+        };
+        auto gp_load = [&](int l, int kb, unsigned (&w)[8]) {
+            if (l == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = gp0[kb][j];
+                return;
+            }
+            const char* p = mine + L::dz(l) + kb * 2048 + lane * 16;
+            const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 1024);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
         bf16x8 hb[KB][2];
 #pragma unroll
         for (int ob = 0; ob < KB; ++ob) {
@@ -244,14 +269,16 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
 #pragma unroll
             for (int i = 0; i < IN0 / 2; ++i)
                 z = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(2 * i + hf) * H + 32 * ob + l31], bin[i], z, 0, 0, 0);
+            unsigned gw[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32v2 g, d;
                 gelu_fast_pair2(f32v2{z[r], z[r + 1]}, g, d);
                 z[r] = g[0];
                 z[r + 1] = g[1];
-                gp[0][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
+                gw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
             }
+            gp_store(0, ob, gw);
             const Packed16 pz = pack16(z);
             store_packed_rows(mine + L::h(0) + ob * TILE_BYTES, pz, l31, hf);
             frags_of(pz, hb[ob][0], hb[ob][1]);
@@ -274,14 +301,16 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
             }
 #pragma unroll
             for (int ob = 0; ob < KB; ++ob) {
+                unsigned gw[8];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     f32v2 g, d;
                     gelu_fast_pair2(f32v2{z[ob][r], z[ob][r + 1]}, g, d);
                     z[ob][r] = g[0];
                     z[ob][r + 1] = g[1];
-                    gp[l][ob][r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
+                    gw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
                 }
+                gp_store(l, ob, gw);
                 const Packed16 pz = pack16(z[ob]);
                 store_packed_rows(mine + L::h(l) + ob * TILE_BYTES, pz, l31, hf);
                 frags_of(pz, hb[ob][0], hb[ob][1]);
@@ -379,10 +408,12 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img(L::bw(NH), kb * 2 + 0), dk0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img(L::bw(NH), kb * 2 + 1), dk1, acc, 0, 0, 0);
+                unsigned gw[8];
+                gp_load(NH - 1, kb, gw);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    dz[kb][r] = mul_f16lo(acc[r], gp[NH - 1][kb][r >> 1]);
-                    dz[kb][r + 1] = mul_f16hi(acc[r + 1], gp[NH - 1][kb][r >> 1]);
+                    dz[kb][r] = mul_f16lo(acc[r], gw[r >> 1]);
+                    dz[kb][r + 1] = mul_f16hi(acc[r + 1], gw[r >> 1]);
                 }
             }
         }
@@ -408,12 +439,15 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
                         dn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img(L::bw(l), (kb * KB + jb) * 2 + s), dzb[jb][s], dn[kb], 0, 0, 0);
             }
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb) {
+                unsigned gw[8];
+                gp_load(l - 1, kb, gw);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    dz[kb][r] = mul_f16lo(dn[kb][r], gp[l - 1][kb][r >> 1]);
-                    dz[kb][r + 1] = mul_f16hi(dn[kb][r + 1], gp[l - 1][kb][r >> 1]);
+                    dz[kb][r] = mul_f16lo(dn[kb][r], gw[r >> 1]);
+                    dz[kb][r + 1] = mul_f16hi(dn[kb][r + 1], gw[r >> 1]);
                 }
+            }
         }
 #pragma unroll
         for (int jb = 0; jb < KB; ++jb) store_acc_rows(mine + L::dz(0) + jb * TILE_BYTES, dz[jb], l31, hf);
