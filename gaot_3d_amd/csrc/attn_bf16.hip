@@ -1016,9 +1016,8 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     FwdArgs a{(const bf16_t*)qkv_image, P > 1 ? o_parts : o, P > 1 ? lse_parts : lse, ld, B, S, H, HKV,
               gdrop::make_drop(dropout_seed, dropout_p), P > 1 ? split_chunk(S, P) : S, o_part, lse_part};
     const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), (unsigned)(P > 1 ? ceil_div(S, a.chunk) : 1), (unsigned)B);
-    // 4 waves/SIMD, 64-key stages (measured: a rolled 5-waves/SIMD variant and 128-key stages were both slower)
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
-    // its max / exp / sum VALU work and loses more from the halved occupancy)
+    // its exp / sum / mask VALU work and loses more from the halved occupancy; a rolled 5-waves/SIMD variant was slower too)
     static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;   // A/B switch (tools/microbench.py)
     // with the maximum-free tile path the kernels need ~150 registers: three waves per SIMD without scratch beat four with it
     // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
