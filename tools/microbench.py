@@ -62,6 +62,14 @@ elif what == "gemm":
         timeit(lambda: ops.gemm(xb, wb, m, n, k, k, k, False, True), f"fwd  (bf16 x, bf16 W)", fl)
         mb = (m * k + m * n + n * k) * 4 / 1e6
         print(f"     (operand + result bytes {mb:.0f} MB -> {mb / 5e3 * 1e3:.1f} us at 5 TB/s)")
+elif what == "gemm16":
+    # the bf16-in-memory GEMMs of one block at configs[1] (A and B bf16): dx of w1|w3, w2 forward
+    m = 16384
+    for (n, k, bt, name) in ((256, 2048, False, "dx_w13  dag[16384,2048] W13[2048,256]"), (256, 1024, True, "w2 fwd  u[16384,1024] W2[256,1024]^T")):
+        a = torch.randn(m, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) if bt else torch.randn(k, n, device=dev)).bfloat16()
+        fl = 2 * m * n * k
+        timeit(lambda: ops.gemm(a, w, m, n, k, k, w.shape[1], False, bt), name, fl)
 elif what == "graph":
     # device graph construction at configs[1]: 500 000 surface points against the 64x64x32 token grid
     from gaot_3d_amd import graph
