@@ -60,6 +60,8 @@ SIGNATURES = {
     "gaot_attn_dropout_mask": (_i, [_p, _f, _i, _i, _i, _p, _p]),
     "gaot_dropout_seed_next": (_i, [_p, C.c_uint64, _p, _p]),
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
+    "gaot_rope_table": (_i, [_p, _i, _i, _p, _p]),
+    "gaot_qkv_image": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _f, _p]),
     "gaot_attn_bwd_bf16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
@@ -126,7 +128,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 4:
+    if lib.gaot_abi_version() != 5:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -998,15 +998,16 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
         return GAOT_ERR_UNSUPPORTED;
     }
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
-    GAOT_CHECK_ARG(qkv && qkv_image && o && lse, "null pointer");
+    GAOT_CHECK_ARG(qkv_image && o && lse, "null pointer");   // qkv == NULL: the image is already there (gaot_qkv_image)
     GAOT_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_image | (uintptr_t)o) & 15) == 0, "buffers must be 16-byte aligned");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
     const int64_t rows = (int64_t)B * S;
     const int64_t n = rows * (ld / 2);
-    GAOT_KLAUNCH(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
-                       HKV, S, rope_freqs, scale * LOG2E);
+    if (qkv)
+        GAOT_KLAUNCH(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
+                     HKV, S, rope_freqs, scale * LOG2E);
     // few heads (head-parallel ranks): split the key range over blockIdx.y so that the launch still fills the chip;
     // every part writes a normalised O / lse of its keys into the scratch behind the image, combined below
     const int P = split_parts(ceil_div(S, 128) * H * B, S);

@@ -24,9 +24,19 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return (unsigned)__builtin_bit_cast(bf16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)b) << 16);
 }
 
-template <bool C16>
+// what the epilogue writes: fp32 C, bf16 C, or the attention kernels' bf16 image of a fused q|k|v projection (RoPE applied to
+// the q and k heads from a [S][16] (cos, sin) table, q pre-scaled): the fp32 projection then never exists in HBM
+enum { OUT_F32 = 0, OUT_BF16 = 1, OUT_QKV_IMAGE = 2 };
+struct ImageArgs {
+    const float* table;   // [S][16][2] = (cos, sin) of position * frequency, or null (no RoPE)
+    int S, nq, nk;        // rows per sequence, number of q heads, of k heads (32 columns each; the rest are v heads)
+    float qscale;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, void* __restrict__ C,
-                                                       int M, int N, int lda, int ldw, int ldc, int P, int subs) {
+                                                       int M, int N, int lda, int ldw, int ldc, int P, int subs, ImageArgs im) {
+    constexpr bool C16 = MODE != OUT_F32;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3, panel = j % P, sub = j / P;
@@ -101,6 +111,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
             const unsigned rowoff = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * (C16 ? 2u : 4u) : 0x80000000u;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
+                if constexpr (MODE == OUT_QKV_IMAGE) {
+                    // this wave's 32 columns of tile jt are exactly one head; the lane holds runs of 4 consecutive columns
+                    // 8q + 4hf .. +3 = two rotation pairs with frequency indices 4q + 2hf and 4q + 2hf + 1
+                    const int head = (n0 + 32 * jt) >> 5;
+                    const bool rope = im.table && head < im.nq + im.nk;
+                    const float sc = head < im.nq ? im.qscale : 1.0f;
+                    const int mm = m < M ? m : M - 1;
+                    const float* trow = im.table + (int64_t)(mm % im.S) * 32 + 4 * hf;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v0 = acc[jt][i][4 * q], v1 = acc[jt][i][4 * q + 1], v2 = acc[jt][i][4 * q + 2], v3 = acc[jt][i][4 * q + 3];
+                        if (rope) {
+                            const float4 t = *reinterpret_cast<const float4*>(trow + 8 * q);   // cos, sin, cos, sin
+                            const float r0 = v0 * t.x - v1 * t.y, r1 = v1 * t.x + v0 * t.y;
+                            const float r2 = v2 * t.z - v3 * t.w, r3 = v3 * t.z + v2 * t.w;
+                            v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+                        }
+                        acc[jt][i][4 * q] = v0 * sc; acc[jt][i][4 * q + 1] = v1 * sc;
+                        acc[jt][i][4 * q + 2] = v2 * sc; acc[jt][i][4 * q + 3] = v3 * sc;
+                    }
+                }
                 if constexpr (C16) {
                     unsigned pk[4][2];
 #pragma unroll
@@ -129,9 +160,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
     }
 }
 
-template <bool C16>
-int launch_k256(const void* A, const void* W, void* C, int M, int N, int lda, int ldw, int ldc, hipStream_t st) {
-    auto kern = k_gemm_k256<C16>;
+template <int MODE>
+int launch_k256(const void* A, const void* W, void* C, int M, int N, int lda, int ldw, int ldc, const ImageArgs& im, hipStream_t st) {
+    auto kern = k_gemm_k256<MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
@@ -146,8 +177,18 @@ int launch_k256(const void* A, const void* W, void* C, int M, int N, int lda, in
     int subs = std::max(1, 64 / P);
     subs = std::max(1, std::min(subs, (nblk + 7) / 8));
     GAOT_KLAUNCH(kern, dim3((unsigned)(8 * P * subs)), dim3(256), 2 * STAGE, st, (const bf16_t*)A, (const bf16_t*)W, C, M, N, lda, ldw, ldc,
-                 P, subs);
+                 P, subs, im);
     return GAOT_OK;
+}
+
+__global__ void k_rope_table(const float* __restrict__ freqs, int S, int half, float* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * half) return;
+    const int pos = i / half, j = i % half;
+    float sn, cs;
+    sincosf((float)pos * freqs[j], &sn, &cs);   // the arithmetic of k_prep_qkv (attn_bf16.hip): same angles, same values
+    table[2 * i] = cs;
+    table[2 * i + 1] = sn;
 }
 
 }  // namespace
@@ -163,6 +204,34 @@ bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int6
 
 int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
                           int c16, hipStream_t st) {
-    if (c16) return launch_k256<true>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, st);
-    return launch_k256<false>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, st);
+    const ImageArgs none{nullptr, 1, 0, 0, 1.0f};
+    if (c16) return launch_k256<OUT_BF16>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
+    return launch_k256<OUT_F32>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
+}
+
+// (cos, sin) of position * frequency for positions 0..S-1 and the 16 RoPE frequencies of a 32-wide head: [S][16][2] floats
+extern "C" int gaot_rope_table(const float* freqs, int S, int half_dim, float* table, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(freqs && table && S > 0 && half_dim == 16, "bad argument (half_dim must be 16)");
+    GAOT_KLAUNCH(k_rope_table, dim3((unsigned)ceil_div((int64_t)S * half_dim, 256)), dim3(256), 0, (hipStream_t)stream, freqs, S, half_dim, table);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// The fused q|k|v projection of one attention layer written straight as the attention kernels' bf16 image
+// (reference attn.py:104-109: q_proj / k_proj / v_proj, rotary embedding of q and k; the 1/sqrt(d) log2(e) factor of the
+// kernels folded into q): x [rows][256] bf16 (lda), w [(H + 2 HKV) * 32][256] bf16 (ldw), image [rows][(H + 2 HKV) * 32] bf16.
+// rope_table: gaot_rope_table's output for this S, or NULL.  Replaces gaot_gemm_ex + the preparation pass of
+// gaot_attn_fwd_bf16 (pass qkv = NULL there): the fp32 projection is never written.
+extern "C" int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* image, int64_t rows, int64_t lda, int64_t ldw, int S,
+                              int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream) {
+    GAOT_ENTER();
+    const int64_t N = (int64_t)(H + 2 * HKV) * 32;
+    GAOT_CHECK_ARG(x_bf16 && w_bf16 && image && rows > 0 && S > 0 && H > 0 && HKV > 0, "bad argument");
+    if (!gaot_gemm_k256_applicable(x_bf16, w_bf16, image, rows, N, KK, lda, ldw, N, 1)) {
+        gaot_set_error("gaot_qkv_image: needs d_model = 256, 16-byte aligned bf16 rows and a heads * 32 that is a multiple of 64");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const ImageArgs im{rope_table, S, H, HKV, qscale};
+    return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, image, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
 }

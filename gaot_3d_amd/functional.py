@@ -3,6 +3,8 @@ kernels through the C ABI (gaot_3d_amd.ops).  PyTorch only owns the device buffe
 Functions.  Nothing here falls back to ATen math or to the CPU."""
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -261,7 +263,11 @@ class AttentionFn(Function):
         all-gathered, so the attention work -- 60 % of a 500 K-point step -- is divided by G instead of repeated G times."""
         scale = 1.0 / (32 ** 0.5)
         bf16 = ops.get_precision() == "bf16"
-        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        pre_img = getattr(qkv, "_gaot_qkv_image", None)   # MultiLinearFn wrote the projection as the kernels' image
+        if pre_img is not None and not (bf16 and head_group is None):
+            raise GaotError("a q|k|v image placeholder reached an attention path that needs the fp32 projection")
+        if pre_img is None:
+            qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
         ctx.hp = None
         if head_group is not None:
             import torch.distributed as dist
@@ -277,7 +283,7 @@ class AttentionFn(Function):
             # of different ranks do not share masks (seed_rank: the rank of a sequence-parallel caller)
             seed = seed + (ctx.hp[2] if ctx.hp is not None else seed_rank) * 0x632BE59BD9B4E019 % (1 << 63)
         if bf16:
-            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed)
+            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed, image=pre_img)
             keep = img
         else:
             if freqs is not None:
@@ -632,7 +638,11 @@ class MultiLinearFn(Function):
     separate q/k/v (and w1/w3) parameters of the reference feed one fused downstream kernel."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, precision: Optional[int], *weights: Tensor):
+    def forward(ctx, x: Tensor, precision: Optional[int], image_spec, *weights: Tensor):
+        """``image_spec`` = (freqs or None, b, s, h, hkv, scale) (extension): the caller is the attention layer and will hand
+        the result to AttentionFn only.  When the bf16 fast path applies, the projection is written straight as the attention
+        kernels' bf16 image (csrc/gemm_k256.hip, OUT_QKV_IMAGE) and the returned tensor is a storage-less placeholder of the
+        right shape that carries the image (``_gaot_qkv_image``): the fp32 q|k|v never exists in HBM."""
         ws = [_w2d(w) for w in weights]
         k = ws[0].shape[1]
         x2 = x.reshape(-1, k)
@@ -640,15 +650,24 @@ class MultiLinearFn(Function):
             x2 = x2.contiguous()
         m = x2.shape[0]
         ntot = sum(w.shape[0] for w in ws)
-        out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
-        ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[2 + i] for i in range(len(ws)))
+        ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[3 + i] for i in range(len(ws)))
         if ctx.fused:   # the weights are slices of one buffer (colocate): one [ntot, k] matrix, one GEMM
             wcat = _wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), precision)
             xb = bf16_copy_of(x, (m, k)) if wcat.dtype == torch.bfloat16 else None
             xa = xb if xb is not None else x2      # bf16 image written by the producing RMSNorm: half the A traffic
+            if image_spec is not None and xb is not None and k == 256 and ntot % 64 == 0 and _QKV_IMAGE_FUSION:
+                freqs, b, s, h, hkv, scale = image_spec
+                img = ops.qkv_image(xb, wcat, m, b, s, h, hkv, freqs, scale)
+                out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only: no [m, ntot] buffer
+                out._gaot_qkv_image = img
+                ctx.save_for_backward(xa, wcat)
+                ctx.precision, ctx.xshape, ctx.wshapes = precision, x.shape, [w.shape for w in weights]
+                return out
+            out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
             ops.gemm(xa, wcat, m, ntot, k, k, k, False, True, out=out, ldc=ntot, precision=precision)
             ctx.save_for_backward(xa, wcat)
         else:
+            out = torch.empty(m, ntot, dtype=torch.float32, device=x.device)
             col = 0
             for w in ws:
                 n = w.shape[0]
@@ -676,20 +695,24 @@ class MultiLinearFn(Function):
                 n = shp[0]
                 dws.append(dwcat[col:col + n].view(shp))
                 col += n
-            return (dx.view(ctx.xshape) if dx is not None else None, None, *dws)
+            return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)
         for i, w in enumerate(ws):
             n = w.shape[0]
             blk = d[:, col:]
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(blk, w, m, k, n, ntot, k, False, False, residual=dx, ldr=k, precision=ctx.precision)
             dws.append(ops.gemm(blk, x2, n, k, m, ntot, k, True, False, precision=ctx.precision).view(ctx.wshapes[i])
-                       if ctx.needs_input_grad[2 + i] else None)
+                       if ctx.needs_input_grad[3 + i] else None)
             col += n
-        return (dx.view(ctx.xshape) if dx is not None else None, None, *dws)
+        return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)
 
 
-def multi_linear(x: Tensor, weights, precision: Optional[int] = None) -> Tensor:
-    return MultiLinearFn.apply(x, precision, *weights)
+# A/B switch for the projection-as-image path (tools/microbench.py, tests)
+_QKV_IMAGE_FUSION = os.environ.get("GAOT_QKV_IMAGE", "1") != "0"
+
+
+def multi_linear(x: Tensor, weights, precision: Optional[int] = None, image_spec=None) -> Tensor:
+    return MultiLinearFn.apply(x, precision, image_spec, *weights)
 
 
 class CatLinearFn(Function):

@@ -90,9 +90,14 @@ class GroupQueryFlashAttention(nn.Module):
             x = self.correction(c=condition, x=x)
         b, s, _ = x.shape
         GF.colocate([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])   # no-op once done
-        qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])  # [B*S, (h+2hkv)*32]
         freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
         seq_group = getattr(self, "_seq_group", None)
+        # unsharded bf16 path: the projection is written straight as the attention kernels' bf16 image (RoPE and the q scale
+        # in the GEMM epilogue), see MultiLinearFn
+        spec = None
+        if self.head_dim == 32 and seq_group is None and getattr(self, "_head_group", None) is None:
+            spec = (freqs, b, s, self.num_heads, self.num_kv_heads, 1.0 / (32 ** 0.5))
+        qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], image_spec=spec)  # [B*S, (h+2hkv)*32]
         if self.head_dim != 32:
             if seq_group is not None or getattr(self, "_head_group", None) is not None:
                 raise NotImplementedError("the sharded attention exchanges are written for head_dim 32")

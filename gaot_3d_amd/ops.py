@@ -391,19 +391,55 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     return dqkv
 
 
-def attn_fwd_bf16(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float,
-                  dropout_p: float = 0.0, seed: Optional[Tensor] = None):
-    """bf16 matrix-core attention on the fused fp32 projection; returns (o, lse, bf16 image kept for backward)"""
+def attn_fwd_bf16(qkv: Optional[Tensor], freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float,
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, image: Optional[Tensor] = None):
+    """bf16 matrix-core attention on the fused fp32 projection; returns (o, lse, bf16 image kept for backward).
+    ``image``: the projection already written as the kernels' image (qkv_image): qkv is then not read"""
     lib = _lib.load()
-    dev = qkv.device
+    dev = image.device if image is not None else qkv.device
     o = torch.empty(b * s, h * 32, dtype=torch.float32, device=dev)
     lse = torch.empty(b, h, s, dtype=torch.float32, device=dev)
-    img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), dev)
+    img = image if image is not None else _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), dev)
     with _timed("attn_fwd"):
         dp, sp = _drop_args(dropout_p, seed)
-        check(lib.gaot_attn_fwd_bf16(_ptr(qkv), _ptr(freqs), _ptr(img), _ptr(o), _ptr(lse), b, s, h, hkv, 32, float(scale),
-                                     dp, sp, _stream()), "gaot_attn_fwd_bf16")
+        check(lib.gaot_attn_fwd_bf16(_ptr(None if image is not None else qkv), _ptr(freqs), _ptr(img), _ptr(o), _ptr(lse), b, s,
+                                     h, hkv, 32, float(scale), dp, sp, _stream()), "gaot_attn_fwd_bf16")
     return o, lse, img
+
+
+_ROPE_TABLES: dict = {}
+
+
+def rope_table(freqs: Tensor, s: int) -> Tensor:
+    """[s, 16, 2] (cos, sin) of position * frequency for a 32-wide head, cached per (frequencies, s): the frequencies are a
+    frozen parameter, so the table is built once"""
+    key = (freqs.data_ptr(), freqs._version, int(s), freqs.device)
+    t = _ROPE_TABLES.get(key)
+    if t is None:
+        if freqs.numel() != 16 or freqs.dtype != torch.float32:
+            raise GaotError("rope_table: 16 fp32 frequencies (head_dim 32) expected")
+        if len(_ROPE_TABLES) > 16:
+            _ROPE_TABLES.clear()
+        t = torch.empty(s, 16, 2, dtype=torch.float32, device=freqs.device)
+        check(_lib.load().gaot_rope_table(_ptr(freqs), int(s), 16, _ptr(t), _stream()), "gaot_rope_table")
+        _ROPE_TABLES[key] = t
+    return t
+
+
+def qkv_image(xb: Tensor, wcat: Tensor, rows: int, b: int, s: int, h: int, hkv: int, freqs: Optional[Tensor],
+              scale: float) -> Tensor:
+    """x [rows, 256] bf16 times the co-located q|k|v weights [(h + 2 hkv) * 32, 256] bf16, written straight as the attention
+    kernels' bf16 image (RoPE on q and k, q pre-scaled): the fp32 projection never exists (csrc/gemm_k256.hip)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or wcat.dtype != torch.bfloat16 or not (xb.is_contiguous() and wcat.is_contiguous()):
+        raise GaotError("qkv_image: contiguous bf16 operands expected")
+    img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), xb.device)
+    table = rope_table(freqs, s) if freqs is not None else None
+    with _timed("qkv_image"):
+        check(lib.gaot_qkv_image(_ptr(xb), _ptr(wcat), _ptr(img), rows, xb.shape[1], wcat.shape[1], s, h, hkv, _ptr(table),
+                                 float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)),
+                                 _stream()), "gaot_qkv_image")
+    return img
 
 
 def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,

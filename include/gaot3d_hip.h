@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 4
+#define GAOT_ABI_VERSION 5
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -176,6 +176,15 @@ int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride,
  * per-range partial gradients).  When (S/128)*H*B is below two workgroups per CU the streamed range (keys for forward
  * and dQ, queries for dK/dV) is split over blockIdx.y and the parts are combined in a fixed order (forward: by their
  * log-sum-exp; backward: summed at the end of phase 4, so phases 2 and 4 must both be issued). */
+/* The fused q|k|v projection written straight as that image (reference attn.py:104-109: q_proj / k_proj / v_proj + rotary
+ * embedding of q and k; stands in for gaot_gemm_ex followed by the preparation pass of gaot_attn_fwd_bf16, so the fp32
+ * projection never exists in HBM): x [rows][256] bf16, w [(H+2*HKV)*32][256] bf16 (the co-located q/k/v weights), image
+ * as sized by gaot_attn_bf16_image_bytes.  rope_table = gaot_rope_table's [S][16][2] (cos, sin) for the layer's RoPE
+ * frequencies, or NULL; qscale = scale * log2(e) (what the kernels expect folded into q).  Afterwards call
+ * gaot_attn_fwd_bf16 with qkv = NULL. */
+int gaot_rope_table(const float* freqs, int S, int half_dim, float* table, gaot_stream_t stream);
+int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* image, int64_t rows, int64_t lda, int64_t ldw, int S, int H,
+                   int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
 size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
 size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
