@@ -652,6 +652,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
                 const bf16x8 qa0 = frag_rows(qt, l31, hf, 0), da0 = frag_rows(dt, l31, hf, 0);
                 const bf16x8 qa1 = frag_rows(qt, l31, hf, 1), da1 = frag_rows(dt, l31, hf, 1);
                 f32x16 sc[KB], dp[KB];
+                // the eight score / dP MFMAs issue at raised priority: the other wave of the SIMD is then in its (longer) VALU
+                // phase and fills the gaps (-1.3 %; the same around the dV / dK MFMAs, in dQ and in the forward: nothing or worse)
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[kb][0], lc, 0, 0, 0);
@@ -659,6 +662,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[kb][1], sc[kb], 0, 0, 0);
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
                 }
+                __builtin_amdgcn_s_setprio(0);
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
                 if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them
