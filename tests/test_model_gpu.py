@@ -217,9 +217,11 @@ dist.destroy_process_group()
 """
 
 
-def small_config(dec_geo=None):
+def small_config(dec_geo=None, heads=None):
     if dec_geo is None:
         dec_geo = os.environ.get("GAOT_TEST_DEC_GEO", "0") == "1"
+    if heads is None:
+        heads = int(os.environ.get("GAOT_TEST_HEADS", "2"))
     from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
     from gaot_3d_amd.model.layers.magno import MAGNOConfig
     return types.SimpleNamespace(
@@ -227,16 +229,19 @@ def small_config(dec_geo=None):
                           in_gno_channel_mlp_hidden_layers=[64, 64], out_gno_channel_mlp_hidden_layers=[64, 64],
                           lifting_channels=32, gno_radius=0.1, use_geoembed=[True, bool(dec_geo)], embedding_method="statistical",
                           encoder_feature_attr=["pos", "c"], mlp_type="linear", precompute_edges=True),
-        transformer=TransformerConfig(patch_size=2, hidden_size=64, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
+        transformer=TransformerConfig(patch_size=2, hidden_size=32 * heads, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
                                       num_layers=2, positional_embedding="rope", use_long_range_skip=True,
-                                      attn_config=AttentionConfig(hidden_size=64, num_heads=2, num_kv_heads=2,
+                                      attn_config=AttentionConfig(hidden_size=32 * heads, num_heads=heads, num_kv_heads=heads,
                                                                   atten_dropout=0.0),
                                       ffn_config=FFNConfig(hidden_size=128)),
         latent_tokens=(8, 8, 4))
 
 
-@pytest.mark.parametrize("dec_geo,parallel", [(False, "seq"), (True, "seq"), (False, "head"), (True, "replicated")])
-def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel):
+@pytest.mark.parametrize("dec_geo,parallel,world", [(False, "seq", 2), (True, "seq", 2), (False, "head", 2), (True, "replicated", 2),
+                                                    # four ranks, one head each: an exchange that orders its chunks wrongly is
+                                                    # invisible with two ranks (every permutation of two is a swap)
+                                                    (False, "seq", 4), (False, "head", 4)])
+def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world):
     """The N>1 path end to end on the real kernels: two processes (both on cuda:0, gloo) each take half of the points
     of one sample; loss and every parameter gradient must equal the unsharded step on the same model and sample.
     parallel = "seq": the latent Transformer runs on half of the token rows per rank with one of the two heads per rank
@@ -250,7 +255,8 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel):
     from gaot_3d_amd.model import init_model
     gaot_3d_amd.set_precision("fp32")
     torch.manual_seed(0)
-    model = init_model(6, 1, "gaot_3d", small_config(dec_geo)).to(DEV).train()
+    heads = 2 if world == 2 else 4
+    model = init_model(6, 1, "gaot_3d", small_config(dec_geo, heads)).to(DEV).train()
     batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device=str(DEV))
     pred = model(batch=batch, tokens_pos=tokens.to(DEV))
     loss = GF.mse_loss(pred, batch.x)
@@ -260,9 +266,9 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel):
     script.write_text(_WORKER)
     out = tmp_path / "out.json"
     env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", GAOT_TEST_DEC_GEO="1" if dec_geo else "0",
-               GAOT_TEST_PARALLEL=parallel)
-    port = 29533 + ["seq", "head", "replicated"].index(parallel) * 2 + int(dec_geo)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               GAOT_TEST_PARALLEL=parallel, GAOT_TEST_HEADS=str(heads))
+    port = 29533 + ["seq", "head", "replicated"].index(parallel) * 2 + int(dec_geo) + 10 * (world - 2)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))

@@ -3,6 +3,8 @@ encoder's per-token sums/counts, backward all-reduce of the decoder's latent gra
 per-point parameter gradients) reproduce the unsharded result.  The per-rank compute in this test is the CPU
 oracle (test infrastructure); on the GPU the same host logic wraps the HIP kernels (tests/test_model_gpu.py)."""
 import os
+
+import pytest
 import sys
 
 import torch
@@ -160,7 +162,7 @@ def _hp_worker(rank, world, port, ret):
     try:
         torch.set_num_threads(1)
         g = torch.Generator().manual_seed(3)
-        s, h, hkv = 24, 4, 2
+        s, h, hkv = 24, 4, (2 if world == 2 else 4)
         qkv = torch.randn(2 * s, (h + 2 * hkv) * 32, generator=g).requires_grad_(True)
         w = torch.randn(2 * s, h * 32, generator=g)
         out = _HeadParallelAttn.apply(qkv, s, h, hkv, dist.group.WORLD, rank, world)
@@ -170,17 +172,17 @@ def _hp_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_head_parallel_exchange_two_ranks_matches_full_attention():
-    """world 2 over gloo: every rank computes half of the (grouped-query) heads; gathered outputs and gathered
-    q|k|v gradients equal full attention on every rank"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_head_parallel_exchange_two_ranks_matches_full_attention(world):
+    """world 2 and 4 over gloo: every rank computes its share of the (grouped-query) heads; gathered outputs and gathered
+    q|k|v gradients equal full attention on every rank (four ranks: a wrong chunk ORDER in a gather is invisible with two)"""
     from gaot_3d_amd.sharding import head_slices
     assert head_slices(1, 2, 4, 2) == ((64, 128), (160, 192), (224, 256))
-    world = 2
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + (os.getpid() % 2000) + world
     ret = mp.Manager().dict()
     mp.spawn(_hp_worker, args=(world, port, ret), nprocs=world, join=True)
     g = torch.Generator().manual_seed(3)
-    s, h, hkv = 24, 4, 2
+    s, h, hkv = 24, 4, (2 if world == 2 else 4)
     qkv = torch.randn(2 * s, (h + 2 * hkv) * 32, generator=g).requires_grad_(True)
     w = torch.randn(2 * s, h * 32, generator=g)
     ref = _attn_math(qkv, s, h, hkv)
@@ -205,9 +207,9 @@ def _seq_layer(x, wqkv, wo, s_total, h, hkv, group=None):
     return x + o @ wo.t()
 
 
-def _seq_problem():
+def _seq_problem(world=2):
     g = torch.Generator().manual_seed(11)
-    s, h, hkv, d = 24, 4, 2, 48
+    s, h, hkv, d = 24, 4, (2 if world == 2 else 4), 48
     x = torch.randn(s, d, generator=g)
     wqkv = torch.randn((h + 2 * hkv) * 32, d, generator=g) * 0.2
     wo = torch.randn(d, h * 32, generator=g) * 0.2
@@ -221,7 +223,7 @@ def _seq_worker(rank, world, port, ret):
     try:
         from gaot_3d_amd import sharding as sh
         torch.set_num_threads(1)
-        s, h, hkv, x, wqkv, wo, wdec = _seq_problem()
+        s, h, hkv, x, wqkv, wo, wdec = _seq_problem(world)
         x = x.requires_grad_(True)
         wqkv, wo = wqkv.clone().requires_grad_(True), wo.clone().requires_grad_(True)
         grp = dist.group.WORLD
@@ -238,17 +240,17 @@ def _seq_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_sequence_parallel_exchange_two_ranks_matches_unsharded():
-    """world 2 over gloo: token rows split over the ranks, heads split inside attention (all-to-all both ways), rows
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_exchange_two_ranks_matches_unsharded(world):
+    """world 2 and 4 over gloo: token rows split over the ranks, heads split inside attention (all-to-all both ways), rows
     all-gathered for the replicated consumer; output, input gradient and weight gradients equal the unsharded layer"""
     from gaot_3d_amd import sharding as sh
     q = torch.arange(5 * 8 * 32, dtype=torch.float32).view(5, 8 * 32)
     assert torch.equal(sh._unpack_heads(sh._pack_heads(q, 2, 4, 2), 2, 4, 2), q)
-    world = 2
-    port = 33500 + (os.getpid() % 2000)
+    port = 33500 + (os.getpid() % 2000) + world
     ret = mp.Manager().dict()
     mp.spawn(_seq_worker, args=(world, port, ret), nprocs=world, join=True)
-    s, h, hkv, x, wqkv, wo, wdec = _seq_problem()
+    s, h, hkv, x, wqkv, wo, wdec = _seq_problem(world)
     x = x.requires_grad_(True)
     wqkv, wo = wqkv.requires_grad_(True), wo.requires_grad_(True)
     y = _seq_layer(_seq_layer(x, wqkv, wo, s, h, hkv), wqkv, wo, s, h, hkv)
@@ -256,9 +258,8 @@ def test_sequence_parallel_exchange_two_ranks_matches_unsharded():
     for r in range(world):
         full, gx, gq, go = ret[r]
         assert torch.allclose(full, y.detach(), rtol=1e-5, atol=1e-5)
-        assert torch.allclose(gx, x.grad, rtol=1e-4, atol=1e-5)
-        assert torch.allclose(gq, wqkv.grad, rtol=1e-4, atol=1e-5)
-        assert torch.allclose(go, wo.grad, rtol=1e-4, atol=1e-5)
+        for got, ref in ((gx, x.grad), (gq, wqkv.grad), (go, wo.grad)):   # fp32 sums in another order: bound relative to the peak
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, float((got - ref).abs().max())
 
 
 def test_bench_spawns_its_ranks_from_a_plain_shell():
