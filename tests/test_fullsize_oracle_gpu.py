@@ -204,3 +204,58 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
             else:
                 PAR.cosine(f"{tag}/grad_{nm}{i}", got, r, 0.999)
                 PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 5e-2)
+
+
+@pytest.mark.skipif(os.environ.get("GAOT_FULLSIZE_ORACLE", "0") != "1",
+                    reason="opt-in (GAOT_FULLSIZE_ORACLE=1): one oracle step at 500 000 points takes ~2 minutes of 64 host threads "
+                           "and ~90 GB of host memory; its recorded result is profiles/r2_l_parity_fullsize_model_vs_oracle.txt")
+def test_model_full_size_vs_oracle():
+    """The WHOLE configs[1] step -- 500 000 points, 4 M edges per direction, 16 384 tokens, L = 10, RoPE, attention dropout
+    off -- against the oracle (CPU restatement of the reference, fp32) on the same sample and weights: predictions, loss and
+    every parameter gradient, for the fp32 kernels (tight) and the bf16 kernels (bf16 bar).  The last projection is scaled
+    so that predictions are O(1) and the loss depends on them."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    import bench
+    import parity as PAR
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    latent, n, k, layers = (64, 64, 32), 500000, 8, 10
+    cfg = bench.model_config(latent, layers, k, 0.0)
+    torch.manual_seed(0)
+    model = init_model(6, 1, "gaot_3d", cfg)
+    batch, tokens = make_synthetic_sample(n, latent, k=k, seed=0)
+    sd = {kk: v.clone() for kk, v in model.state_dict().items()}
+    with torch.no_grad():
+        p0 = orc.gaot3d_forward(sd, cfg, batch, tokens)
+    last = model.decoder.projection.fcs[-1]
+    PAR.unit_scale_last_layer(last.weight, last.bias, float(p0.std()))
+    sd = {kk: v.clone() for kk, v in model.state_dict().items()}
+    pred_r, loss_r, grads_r = orc.train_step_grads(sd, cfg, batch, tokens)
+    print(f"[parity] full-size oracle: loss={float(loss_r):.6f} pred std={float(pred_r.std()):.4f}")
+    bd, tk = batch.to(DEV), tokens.to(DEV)
+    for precision in ("fp32", "bf16"):
+        gaot_3d_amd.set_precision(precision)
+        try:
+            m = init_model(6, 1, "gaot_3d", cfg)
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval().train()
+            gaot_3d_amd.clear_graph_cache(bd)
+            pred = m(batch=bd, tokens_pos=tk)
+            loss = GF.mse_loss(pred, bd.x)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            gaot_3d_amd.set_precision("fp32")
+        grads = {kk: p.grad for kk, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+        if precision == "fp32":
+            PAR.close_peak("fullsize_vs_oracle_fp32/pred", pred, pred_r, 2e-4, rel_l2=1e-4)
+            PAR.close("fullsize_vs_oracle_fp32/loss", loss, loss_r, 1e-5, 0.0)
+            PAR.grads_cosine("fullsize_vs_oracle_fp32/grads", grads, grads_r, 0.99999, per_tensor=0.9999)
+        else:
+            PAR.close_peak("fullsize_vs_oracle_bf16/pred", pred, pred_r, 3e-2, rel_l2=2e-2)
+            PAR.close("fullsize_vs_oracle_bf16/loss", loss, loss_r, 1e-2, 0.0)
+            PAR.grads_cosine("fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.999, per_tensor=0.99)
+        del m, pred, loss, grads
+        torch.cuda.empty_cache()
