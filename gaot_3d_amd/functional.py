@@ -495,8 +495,16 @@ class FFNFn(Function):
         dy2 = dy.reshape(m, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
-        dw2 = ops.gemm(dy2, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
+        if _DY_BF16 and d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:
+            # dy W2 as x W^T with both operands bf16 in memory and K = 256 -> the weights-in-registers kernel
+            # (csrc/gemm_k256.hip: 41 -> 18 us at configs[1]) for one rounding pass over dy and a 0.5 MB weight transpose;
+            # the weight-gradient GEMM reads the same bf16 rows (half the A traffic)
+            dyb = ops.cast_bf16(dy2)
+            du = ops.gemm(dyb, w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+            dw2 = ops.gemm(dyb, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
+        else:
+            du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
+            dw2 = ops.gemm(dy2, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
         dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -707,8 +715,9 @@ class MultiLinearFn(Function):
         return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)
 
 
-# A/B switch for the projection-as-image path (tools/microbench.py, tests)
+# A/B switches (tools/microbench.py, tests): the projection-as-image path; bf16 copies of the RMSNorm input gradients
 _QKV_IMAGE_FUSION = os.environ.get("GAOT_QKV_IMAGE", "1") != "0"
+_DY_BF16 = os.environ.get("GAOT_DY_BF16", "1") != "0"
 
 
 def multi_linear(x: Tensor, weights, precision: Optional[int] = None, image_spec=None) -> Tensor:
