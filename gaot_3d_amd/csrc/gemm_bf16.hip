@@ -408,6 +408,10 @@ bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int6
                                int64_t ldc, int c16);
 int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
                           int c16, hipStream_t st);
+bool gaot_gemm_tn_n256_applicable(const void* A, const void* W, const void* C, const void* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                  int64_t ldw, int64_t ldc, int64_t ldr);
+int gaot_gemm_tn_n256_launch(const void* A, const void* W, float* C, const float* R, int64_t M, int64_t K, int64_t lda, int64_t ldw,
+                             int64_t ldc, int64_t ldr, hipStream_t st);
 
 // called by gaot_gemm / gaot_gemm_ex (gemm.hip) for precision == 1 when the output is wide enough for the 128-wide tile.
 // dt: bit 0 = A is bf16 in memory, bit 1 = B, bit 2 = C (leading dimensions always in elements).
@@ -423,6 +427,11 @@ int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact
     if (k256_on && !a_ks && !b_ks && (dt & 3) == 3 && splits <= 1 && !bias && !residual && !preact && act == 0 &&
         gaot_gemm_k256_applicable(A, B, C, M, N, K, lda, ldb, ldc, (dt & 4) != 0))
         return gaot_gemm_k256_launch(A, B, C, M, N, lda, ldb, ldc, (dt & 4) != 0, st);
+    // x W^T with N = 256 and a long K, both operands bf16 in memory, fp32 result (+ residual): streamed-weight kernel
+    static const bool tn_on = !(getenv("GAOT_GEMM_TN256") && atoi(getenv("GAOT_GEMM_TN256")) == 0);
+    if (tn_on && !a_ks && !b_ks && dt == 3 && splits <= 1 && !bias && !preact && act == 0 &&
+        gaot_gemm_tn_n256_applicable(A, B, C, residual, M, N, K, lda, ldb, ldc, ldr))
+        return gaot_gemm_tn_n256_launch(A, B, (float*)C, residual, M, K, lda, ldb, ldc, ldr, st);
     if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, dt, st);
     if (!a_ks && b_ks) return launch<false, true>(g, a_vec, b_vec, splits, dt, st);
     if (a_ks && !b_ks) return launch<true, false>(g, a_vec, b_vec, splits, dt, st);

@@ -235,3 +235,133 @@ extern "C" int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* imag
     const ImageArgs im{rope_table, S, H, HKV, qscale};
     return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, image, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// C[M,256] = A[M,K] . W[256,K]^T (+ residual), fp32 result, both operands bf16 in memory and k-contiguous, K a multiple of 64:
+// the d_model-wide outputs of the FFN (w2 forward, K = F; input gradient of w1|w3 on the transposed weight, K = 2F).  Same
+// skeleton as k_gemm_k256 -- LDS-DMA, source-side swizzle, one barrier per step, transposed product so that a lane owns a
+// row and stores 16 bytes -- but K is long, so the weight tile streams too: per 64-deep step a workgroup (64 rows x all 256
+// columns) DMAs 8 KB of A and 32 KB of W into one of two LDS buffers while the MFMAs of the previous step run.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int TB_A = 64 * 128, TB_W = 256 * 128, TB_STAGE = TB_A + TB_W;   // 40 KB per step
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                          const float* __restrict__ R, int M, int K, int lda, int ldw, int ldc, int ldr) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    // consecutive workgroup ids go to consecutive XCDs: give each XCD a contiguous range of row blocks
+    const int nblk = (M + 63) / 64;
+    const int per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * 64;
+    const int64_t abytes = (int64_t)M * lda * 2, wbytes = (int64_t)256 * ldw * 2, cbytes = (int64_t)M * ldc * 4;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(abytes > 0x7fffffff ? 0x7fffffff : abytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(wbytes > 0x7fffffff ? 0x7fffffff : wbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(cbytes > 0x7fffffff ? 0x7fffffff : cbytes), 0x00020000);
+    // one DMA piece = 1 KB = 8 tile rows of 128 B (64 k); lane -> (row = lane >> 3, slot = lane & 7); slot s of row r holds
+    // source chunk s ^ (r & 7), so a fragment read of chunk c goes to slot c ^ (r & 7): conflict-free ds_read_b128
+    const int prow = lane >> 3, pslot = lane & 7;
+    auto stage = [&](int k0, int buf) {
+        char* base = lds + buf * TB_STAGE;
+        // A: 8 pieces (64 rows), wave w takes pieces 2w, 2w+1; W: 32 pieces (256 rows), wave w takes 8w .. 8w+7
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i, row = piece * 8 + prow;
+            const int voff = (m0 + row) * lda * 2 + ((pslot ^ (row & 7)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, voff, k0 * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = wave * 8 + i, row = piece * 8 + prow;
+            const int voff = row * ldw * 2 + ((pslot ^ (row & 7)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(base + TB_A + piece * 1024), 16, voff, k0 * 2, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+    const int nsteps = K / 64;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int sw = l31 & 7;
+    for (int kt = 0; kt < nsteps; ++kt) {
+        const int buf = kt & 1;
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nsteps) stage((kt + 1) * 64, buf ^ 1);
+        const char* ab = lds + buf * TB_STAGE + l31 * 128;                       // activation rows 0..31 (+32 rows: + 4096)
+        const char* wb = lds + buf * TB_STAGE + TB_A + (wave * 64 + l31) * 128;    // this wave's 64 weight rows (+32 rows: + 4096)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = ((2 * s + hf) ^ sw) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + slot), a1 = *reinterpret_cast<const bf16x8*>(ab + 4096 + slot);
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wb + slot), w1 = *reinterpret_cast<const bf16x8*>(wb + 4096 + slot);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // acc[jt][i][r]: column n = 64 wave + 32 jt + mfma32_row(r, hf), row m = m0 + 32 i + l31
+    const int n0 = wave * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const bool ok = m < M;
+        const unsigned rowoff = ok ? (unsigned)m * (unsigned)ldc * 4u : 0x80000000u;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 32 * jt + 8 * q + 4 * hf;
+                f32x4 v = {acc[jt][i][4 * q], acc[jt][i][4 * q + 1], acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]};
+                if constexpr (HAS_RES) {
+                    if (ok) {
+                        const float4 rr = *reinterpret_cast<const float4*>(R + (int64_t)m * ldr + n);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs, rowoff + n * 4, 0, 0);
+            }
+    }
+}
+
+template <bool HAS_RES>
+int launch_tn_n256(const void* A, const void* W, float* C, const float* R, int M, int K, int lda, int ldw, int ldc, int ldr, hipStream_t st) {
+    auto kern = k_gemm_tn_n256<HAS_RES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_STAGE);
+        if (e != hipSuccess) {
+            gaot_set_error("gemm_tn_n256: cannot set dynamic LDS %d: %s", 2 * TB_STAGE, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int nblk = (M + 63) / 64, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), 2 * TB_STAGE, st, (const bf16_t*)A, (const bf16_t*)W, C, R, M, K, lda, ldw, ldc, ldr);
+    return GAOT_OK;
+}
+
+}  // namespace
+
+bool gaot_gemm_tn_n256_applicable(const void* A, const void* W, const void* C, const void* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                  int64_t ldw, int64_t ldc, int64_t ldr) {
+    return N == 256 && K >= 512 && K % 64 == 0 && M >= 1 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0) &&
+           ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)R % 16) == 0 &&
+           M * lda * 2 < 0x7fffffff && 256 * ldw * 2 < 0x7fffffff && M * ldc * 4 < 0x7fffffff && lda >= K && ldw >= K;
+}
+
+int gaot_gemm_tn_n256_launch(const void* A, const void* W, float* C, const float* R, int64_t M, int64_t K, int64_t lda, int64_t ldw,
+                             int64_t ldc, int64_t ldr, hipStream_t st) {
+    if (R) return launch_tn_n256<true>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+    return launch_tn_n256<false>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+}

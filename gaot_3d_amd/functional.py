@@ -508,8 +508,14 @@ class FFNFn(Function):
         dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,
-                          precision=1).view(xshape)
+            if _DY_BF16 and d == 256 and wcat.dtype == torch.bfloat16 and (2 * f) % 64 == 0 and 2 * f >= 512:
+                # dag W13 as x W^T on the transposed bf16 weight [d, 2f]: both operands k-contiguous -> the streamed-weight
+                # kernel (csrc/gemm_k256.hip: k_gemm_tn_n256) instead of the generic tile kernel with transposed reads
+                dx = ops.gemm(dag, wcat.t().contiguous(), m, d, 2 * f, 2 * f, 2 * f, False, True,
+                              residual=dy2 if ctx.res_is_x else None, ldr=d, precision=1).view(xshape)
+            else:
+                dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,
+                              precision=1).view(xshape)
         dwcat = ops.gemm(dag, x2, 2 * f, d, m, 2 * f, d, True, False, precision=1)
         dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
         return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None

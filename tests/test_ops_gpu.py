@@ -240,6 +240,10 @@ def test_multi_linear_colocated(m, k, ns, precision):
     (130, 320, 256, False, True, True, True, True),       # ragged rows, N % 256 != 0 (idle waves in the last panel)
     (1, 128, 256, False, True, True, True, False),        # one row
     (9000, 128, 256, False, True, True, True, True),      # more row blocks than row chunks
+    # N = 256, long K, bf16 A and B, fp32 result: the streamed-weight kernel (k_gemm_tn_n256)
+    (4096, 256, 1024, False, True, True, True, False),    # w2 forward shape
+    (333, 256, 2048, False, True, True, True, False),     # input gradient of w1|w3 on the transposed weight, ragged rows
+    (70, 256, 512, False, True, True, True, False),
 ])
 def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     """gaot_gemm_ex: operands / result that are bf16 in memory must give what the fp32-in-memory bf16 GEMM gives on the
@@ -261,6 +265,19 @@ def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     err = float((out.double().cpu() - ref).abs().max())
     print(f"[parity] gemm_ex m={m} n={n} k={k} a16={a16} b16={b16} c16={c16}: max_abs={err:.3e} tol={tol:.3e}")
     assert err <= tol
+
+
+def test_gemm_tn_n256_with_residual():
+    """the streamed-weight kernel's residual epilogue (w2 forward: h + ffn(h)) against fp64"""
+    from gaot_3d_amd import ops
+    m, n, k = 1000, 256, 1024
+    A, B, R = gen(m, k, seed=5).bfloat16(), gen(n, k, seed=6).bfloat16(), gen(m, n, seed=7)
+    ref = A.double() @ B.double().t() + R.double()
+    out = ops.gemm(A.to(DEV), B.to(DEV), m, n, k, k, k, False, True, residual=R.to(DEV), ldr=n, precision=1)
+    torch.cuda.synchronize()
+    err = float((out.double().cpu() - ref).abs().max())
+    print(f"[parity] gemm_tn_n256 residual: max_abs={err:.3e} ref_peak={float(ref.abs().max()):.3e}")
+    assert err <= 1e-5 * float(ref.abs().max()) + 1e-6
 
 
 def test_gemm_bf16_in_memory_rejects_unsupported():
