@@ -93,6 +93,7 @@ SIGNATURES = {
     "gaot_compact_pairs": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p]),
     "gaot_cast_bf16": (_i, [_p, _p, _i64, _p]),
     "gaot_cast_bf16_multi": (_i, [_p, _i, _p]),
+    "gaot_cast_bf16_transpose_multi": (_i, [_p, _p, _p, _i, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
@@ -128,7 +129,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 5:
+    if lib.gaot_abi_version() != 6:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

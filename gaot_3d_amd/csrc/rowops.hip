@@ -598,6 +598,64 @@ extern "C" int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_t
     return GAOT_OK;
 }
 
+// fp32 [rows][cols] -> bf16 [cols][rows] for many matrices in ONE launch (32 x 32 tiles through LDS)
+struct TransTable {
+    const float* src[CM_MAX];
+    unsigned short* dst[CM_MAX];
+    int rows[CM_MAX], cols[CM_MAX];
+    int first_block[CM_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_cast_bf16_transpose_multi(TransTable t) {
+    __shared__ float tile[32][33];
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+    const int b = (int)blockIdx.x - t.first_block[ti];
+    const int R = t.rows[ti], Cc = t.cols[ti], tc = (Cc + 31) / 32;
+    const int r0 = (b / tc) * 32, c0 = (b % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float* src = t.src[ti];
+    unsigned short* dst = t.dst[ti];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        tile[ty + 8 * j][tx] = (r < R && c < Cc) ? src[(int64_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (c < Cc && r < R) dst[(int64_t)c * R + r] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][ty + 8 * j]);
+    }
+}
+
+extern "C" int gaot_cast_bf16_transpose_multi(const gaot_cast_tensor_t* tensors, const int* rows, const int* cols, int num_tensors,
+                                              gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(num_tensors >= 0, "negative tensor count");
+    GAOT_CHECK_ARG(num_tensors == 0 || (tensors && rows && cols), "null tensor table");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < num_tensors; base += CM_MAX) {
+        TransTable tb;
+        tb.count = 0;
+        int blocks = 0;
+        for (int i = base; i < num_tensors && i < base + CM_MAX; ++i) {
+            const gaot_cast_tensor_t& e = tensors[i];
+            GAOT_CHECK_ARG(rows[i] >= 0 && cols[i] >= 0 && e.numel == (int64_t)rows[i] * cols[i], "rows * cols must equal numel");
+            if (e.numel == 0) continue;
+            GAOT_CHECK_ARG(e.src && e.dst, "null pointer in tensor table");
+            const int c = tb.count++;
+            tb.src[c] = e.src; tb.dst[c] = (unsigned short*)e.dst; tb.rows[c] = rows[i]; tb.cols[c] = cols[i];
+            tb.first_block[c] = blocks;
+            blocks += (int)(ceil_div(rows[i], 32) * ceil_div(cols[i], 32));
+        }
+        tb.first_block[tb.count] = blocks;
+        if (tb.count) GAOT_KLAUNCH(k_cast_bf16_transpose_multi, dim3(blocks), dim3(256), 0, st, tb);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
 extern "C" int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(rows >= 0 && F > 0 && F % 8 == 0, "F must be a positive multiple of 8");

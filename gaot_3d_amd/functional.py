@@ -40,17 +40,33 @@ def fused_view(ws) -> Tensor:
                                 (w0.shape[1], 1))
 
 
-def precast_weights(mats) -> None:
+_WBT_CACHE: dict = {}
+
+
+def precast_weights(mats, transposed=()) -> None:
+    """``transposed``: matrices whose bf16 TRANSPOSE is wanted as well (the FFN's w2 and w1|w3: their input-gradient GEMMs run
+    as x W^T on it, see FFNFn.backward) -- one more launch for all of them"""
     _WB_CACHE.clear()
+    _WBT_CACHE.clear()
     if ops.get_precision() != "bf16":
         return
     todo = [m for m in (_w2d(m) for m in mats) if _wb_eligible(m, 1)]
     for m, c in zip(todo, ops.cast_bf16_multi(todo)):
         _WB_CACHE[(m.data_ptr(), tuple(m.shape))] = c
+    if transposed and torch.is_grad_enabled():
+        todo = [m for m in (_w2d(m) for m in transposed) if _wb_eligible(m, 1) and m.is_contiguous()]
+        for m, c in zip(todo, ops.cast_bf16_transpose_multi(todo)):
+            _WBT_CACHE[(m.data_ptr(), tuple(m.shape))] = c
 
 
 def release_precast() -> None:
     _WB_CACHE.clear()
+    _WBT_CACHE.clear()
+
+
+def _wbt(w: Tensor) -> Optional[Tensor]:
+    """the bf16 transpose of a weight prepared by precast_weights, if any"""
+    return _WBT_CACHE.get((w.data_ptr(), tuple(w.shape)))
 
 
 def _wb(w: Tensor, precision: Optional[int]) -> Tensor:
@@ -468,8 +484,10 @@ class FFNFn(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         m = x2.shape[0]
-        wcat = _wb(w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1)), 1)
+        wcat32 = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1))
+        wcat = _wb(wcat32, 1)
         w2c = _wb(_w2d(w2), 1)
+        wcat_t, w2t = _wbt(wcat32), _wbt(_w2d(w2))   # bf16 transposes from the per-forward cast pass, or None
         xb = bf16_copy_of(x, (m, d))
         xa = xb if xb is not None else x2          # bf16 image written by the producing RMSNorm
         ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
@@ -482,14 +500,15 @@ class FFNFn(Function):
             if not res.is_contiguous():
                 res = res.contiguous()
         y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
-        ctx.save_for_backward(xa, wcat, w2c, ag, u)
+        empty = w2c.new_empty(0)
+        ctx.save_for_backward(xa, wcat, w2c, ag, u, wcat_t if wcat_t is not None else empty, w2t if w2t is not None else empty)
         ctx.res_is_x = res_is_x
         ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
         return y.view(*x.shape[:-1], d)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
-        x2, wcat, w2c, ag, u = ctx.saved_tensors
+        x2, wcat, w2c, ag, u, wcat_t, w2t = ctx.saved_tensors
         f, d, xshape, rshape, w1shape, w2shape = ctx.meta
         m = x2.shape[0]
         dy2 = dy.reshape(m, d)
@@ -500,7 +519,8 @@ class FFNFn(Function):
             # (csrc/gemm_k256.hip: 41 -> 18 us at configs[1]) for one rounding pass over dy and a 0.5 MB weight transpose;
             # the weight-gradient GEMM reads the same bf16 rows (half the A traffic)
             dyb = ops.cast_bf16(dy2)
-            du = ops.gemm(dyb, w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+            du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,
+                          out_dtype=torch.bfloat16)
             dw2 = ops.gemm(dyb, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
         else:
             du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
@@ -511,7 +531,7 @@ class FFNFn(Function):
             if _DY_BF16 and d == 256 and wcat.dtype == torch.bfloat16 and (2 * f) % 64 == 0 and 2 * f >= 512:
                 # dag W13 as x W^T on the transposed bf16 weight [d, 2f]: both operands k-contiguous -> the streamed-weight
                 # kernel (csrc/gemm_k256.hip: k_gemm_tn_n256) instead of the generic tile kernel with transposed reads
-                dx = ops.gemm(dag, wcat.t().contiguous(), m, d, 2 * f, 2 * f, 2 * f, False, True,
+                dx = ops.gemm(dag, wcat_t if wcat_t.numel() else wcat.t().contiguous(), m, d, 2 * f, 2 * f, 2 * f, False, True,
                               residual=dy2 if ctx.res_is_x else None, ldr=d, precision=1).view(xshape)
             else:
                 dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,

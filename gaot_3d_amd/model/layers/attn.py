@@ -249,9 +249,19 @@ class Transformer(nn.Module):
                 mats.append(proj.weight)
         return mats
 
+    def _ffn_matrices(self):
+        """the FFN weights whose bf16 transposes the backward wants (FFNFn.backward)"""
+        blocks = list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
+        mats = []
+        for blk in blocks:
+            f = blk.ffn
+            mats += [GF.fused_view([f.w1.weight, f.w3.weight]), f.w2.weight]
+        return mats
+
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
         if x.is_cuda:    # bf16 mode: ONE launch rounds all weight matrices of the blocks (46 separate casts otherwise)
-            GF.precast_weights(self._matrices())
+            mats = self._matrices()   # co-locates w1|w3 first
+            GF.precast_weights(mats, self._ffn_matrices() if self.training else ())
         try:
             return self._forward(x, condition, relative_positions)
         finally:

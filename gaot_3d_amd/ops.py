@@ -505,6 +505,29 @@ def cast_bf16_multi(xs: Sequence[Tensor]) -> List[Tensor]:
     return outs
 
 
+def cast_bf16_transpose_multi(xs: Sequence[Tensor]) -> List[Tensor]:
+    """bf16 TRANSPOSED copies ([cols, rows]) of many contiguous fp32 matrices in ONE launch"""
+    lib = _lib.load()
+    if not xs:
+        return []
+    offs, total = [], 0
+    for x in xs:
+        offs.append(total)
+        total += (x.numel() + 7) // 8 * 8
+    buf = torch.empty(total, dtype=torch.bfloat16, device=xs[0].device)
+    outs = [buf[o:o + x.numel()].view(x.shape[1], x.shape[0]) for o, x in zip(offs, xs)]
+    entries = (_CastEntry * len(xs))()
+    rows, cols = (C.c_int * len(xs))(), (C.c_int * len(xs))()
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        x = _req(x, torch.float32, "x")
+        if x.dim() != 2 or not x.is_contiguous():
+            raise GaotError("cast_bf16_transpose_multi: contiguous 2-D tensors expected")
+        entries[i] = _CastEntry(x.data_ptr(), o.data_ptr(), x.numel())
+        rows[i], cols[i] = x.shape[0], x.shape[1]
+    check(lib.gaot_cast_bf16_transpose_multi(entries, rows, cols, len(xs), _stream()), "gaot_cast_bf16_transpose_multi")
+    return outs
+
+
 def swiglu_fwd_bf16(ag: Tensor, f: int) -> Tensor:
     """bf16 [rows, 2F] -> bf16 [rows, F]"""
     lib = _lib.load()

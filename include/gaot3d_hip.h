@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 5
+#define GAOT_ABI_VERSION 6
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -233,6 +233,10 @@ typedef struct {
     int64_t numel;
 } gaot_cast_tensor_t;
 int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_tensors, gaot_stream_t stream);
+/* the same with a transpose: fp32 [rows[i]][cols[i]] -> bf16 [cols[i]][rows[i]] (numel = rows * cols): the weights of the FFN
+ * whose input-gradient GEMMs run as x W^T on the transposed copy (gaot_gemm_ex with K = 256 / N = 256, reference attn.py:156) */
+int gaot_cast_bf16_transpose_multi(const gaot_cast_tensor_t* tensors, const int* rows, const int* cols, int num_tensors,
+                                   gaot_stream_t stream);
 /* the same with every buffer bf16 in memory (fp32 arithmetic); F % 8 == 0, 16-byte aligned buffers */
 int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);

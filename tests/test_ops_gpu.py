@@ -267,6 +267,17 @@ def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     assert err <= tol
 
 
+def test_cast_bf16_transpose_multi():
+    """fp32 [r, c] -> bf16 [c, r] for several matrices in one launch: bit-exact against torch's own rounding"""
+    from gaot_3d_amd import ops
+    xs = [gen(256, 1024, seed=1), gen(2048, 256, seed=2), gen(33, 70, seed=3), gen(1, 5, seed=4)]
+    outs = ops.cast_bf16_transpose_multi([x.to(DEV) for x in xs])
+    torch.cuda.synchronize()
+    for x, o in zip(xs, outs):
+        assert o.shape == (x.shape[1], x.shape[0]) and o.dtype == torch.bfloat16
+        assert torch.equal(o.cpu(), x.t().contiguous().bfloat16())
+
+
 def test_gemm_tn_n256_with_residual():
     """the streamed-weight kernel's residual epilogue (w2 forward: h + ffn(h)) against fp64"""
     from gaot_3d_amd import ops
