@@ -245,19 +245,23 @@ extern "C" int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* imag
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int TB_A = 64 * 128, TB_W = 256 * 128, TB_STAGE = TB_A + TB_W;   // 40 KB per step
+constexpr int TB_W = 256 * 128;   // weight tile of one step: 256 rows x 64 k bf16 = 32 KB
 
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
-                                                          const float* __restrict__ R, int M, int K, int lda, int ldw, int ldc, int ldr) {
+// MT = 32-row tiles per workgroup along M (2: 64 rows, 4: 128 rows -- half as many weight bytes per output row, half as many
+// workgroups)
+template <bool HAS_RES, int MT>
+__global__ __launch_bounds__(256, MT == 2 ? 2 : 1) void k_gemm_tn_n256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                        float* __restrict__ C, const float* __restrict__ R, int M, int K,
+                                                                        int lda, int ldw, int ldc, int ldr) {
+    constexpr int BM = 32 * MT, TB_A = BM * 128, TB_STAGE = TB_A + TB_W;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     // consecutive workgroup ids go to consecutive XCDs: give each XCD a contiguous range of row blocks
-    const int nblk = (M + 63) / 64;
+    const int nblk = (M + BM - 1) / BM;
     const int per = (nblk + 7) / 8;
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
-    const int m0 = t * 64;
+    const int m0 = t * BM;
     const int64_t abytes = (int64_t)M * lda * 2, wbytes = (int64_t)256 * ldw * 2, cbytes = (int64_t)M * ldc * 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(abytes > 0x7fffffff ? 0x7fffffff : abytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(wbytes > 0x7fffffff ? 0x7fffffff : wbytes), 0x00020000);
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restric
     const int prow = lane >> 3, pslot = lane & 7;
     auto stage = [&](int k0, int buf) {
         char* base = lds + buf * TB_STAGE;
-        // A: 8 pieces (64 rows), wave w takes pieces 2w, 2w+1; W: 32 pieces (256 rows), wave w takes 8w .. 8w+7
+        // A: BM / 8 pieces, wave w takes MT of them; W: 32 pieces (256 rows), wave w takes 8w .. 8w+7
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wave * 2 + i, row = piece * 8 + prow;
+        for (int i = 0; i < MT; ++i) {
+            const int piece = wave * MT + i, row = piece * 8 + prow;
             const int voff = (m0 + row) * lda * 2 + ((pslot ^ (row & 7)) << 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, voff, k0 * 2, 0, 0);
         }
@@ -281,11 +285,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restric
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(base + TB_A + piece * 1024), 16, voff, k0 * 2, 0, 0);
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
     const int nsteps = K / 64;
@@ -296,24 +300,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restric
         const int buf = kt & 1;
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < nsteps) stage((kt + 1) * 64, buf ^ 1);
-        const char* ab = lds + buf * TB_STAGE + l31 * 128;                       // activation rows 0..31 (+32 rows: + 4096)
+        const char* ab = lds + buf * TB_STAGE + l31 * 128;                       // activation rows 0..31 (tile i: + 4096 i)
         const char* wb = lds + buf * TB_STAGE + TB_A + (wave * 64 + l31) * 128;    // this wave's 64 weight rows (+32 rows: + 4096)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int slot = ((2 * s + hf) ^ sw) << 4;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + slot), a1 = *reinterpret_cast<const bf16x8*>(ab + 4096 + slot);
             const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wb + slot), w1 = *reinterpret_cast<const bf16x8*>(wb + 4096 + slot);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ab + 4096 * i + slot);
+                acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a, acc[1][i], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // acc[jt][i][r]: column n = 64 wave + 32 jt + mfma32_row(r, hf), row m = m0 + 32 i + l31
     const int n0 = wave * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
         const int m = m0 + 32 * i + l31;
         const bool ok = m < M;
         const unsigned rowoff = ok ? (unsigned)m * (unsigned)ldc * 4u : 0x80000000u;
@@ -334,20 +339,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_n256(const bf16_t* __restric
     }
 }
 
-template <bool HAS_RES>
+template <bool HAS_RES, int MT>
 int launch_tn_n256(const void* A, const void* W, float* C, const float* R, int M, int K, int lda, int ldw, int ldc, int ldr, hipStream_t st) {
-    auto kern = k_gemm_tn_n256<HAS_RES>;
+    constexpr int BM = 32 * MT, LDS = 2 * (BM * 128 + TB_W);
+    auto kern = k_gemm_tn_n256<HAS_RES, MT>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_STAGE);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
-            gaot_set_error("gemm_tn_n256: cannot set dynamic LDS %d: %s", 2 * TB_STAGE, hipGetErrorString(e));
+            gaot_set_error("gemm_tn_n256: cannot set dynamic LDS %d: %s", LDS, hipGetErrorString(e));
             return GAOT_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    const int nblk = (M + 63) / 64, per = (nblk + 7) / 8;
-    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), 2 * TB_STAGE, st, (const bf16_t*)A, (const bf16_t*)W, C, R, M, K, lda, ldw, ldc, ldr);
+    const int nblk = (M + BM - 1) / BM, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), LDS, st, (const bf16_t*)A, (const bf16_t*)W, C, R, M, K, lda, ldw, ldc, ldr);
     return GAOT_OK;
 }
 
@@ -362,6 +368,11 @@ bool gaot_gemm_tn_n256_applicable(const void* A, const void* W, const void* C, c
 
 int gaot_gemm_tn_n256_launch(const void* A, const void* W, float* C, const float* R, int64_t M, int64_t K, int64_t lda, int64_t ldw,
                              int64_t ldc, int64_t ldr, hipStream_t st) {
-    if (R) return launch_tn_n256<true>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
-    return launch_tn_n256<false>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+    static const int bm_env = getenv("GAOT_GEMM_TN_BM") ? atoi(getenv("GAOT_GEMM_TN_BM")) : 64;   // A/B switch
+    if (bm_env == 128) {
+        if (R) return launch_tn_n256<true, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+        return launch_tn_n256<false, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+    }
+    if (R) return launch_tn_n256<true, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+    return launch_tn_n256<false, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
 }
