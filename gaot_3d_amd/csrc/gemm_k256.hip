@@ -247,10 +247,10 @@ namespace {
 
 constexpr int TB_W = 256 * 128;   // weight tile of one step: 256 rows x 64 k bf16 = 32 KB
 
-// MT = 32-row tiles per workgroup along M (2: 64 rows, 4: 128 rows -- half as many weight bytes per output row, half as many
-// workgroups)
-template <bool HAS_RES, int MT>
-__global__ __launch_bounds__(256, MT == 2 ? 2 : 1) void k_gemm_tn_n256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+// MT = 32-row tiles per workgroup along M (2: 64 rows; 4: 128 rows -- half as many weight bytes per output row but half as many
+// workgroups: measured slower, the kernel is bound by the DMA latency of each CU, not by the aggregate L2 traffic)
+template <bool HAS_RES, int MT, int NB>
+__global__ __launch_bounds__(256, 1) void k_gemm_tn_n256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                         float* __restrict__ C, const float* __restrict__ R, int M, int K,
                                                                         int lda, int ldw, int ldc, int ldr) {
     constexpr int BM = 32 * MT, TB_A = BM * 128, TB_STAGE = TB_A + TB_W;
@@ -293,13 +293,19 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 1) void k_gemm_tn_n256(const bf1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
     const int nsteps = K / 64;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NB LDS buffers: NB - 1 steps of DMA in flight (each wave issues MT + 8 pieces per step; the kernel is bound by the latency
+    // of these loads -- ~12 B/clk per CU with one step in flight -- so depth pays: 2 -> 3 buffers -0.18 ms per step)
+    constexpr int PIECES = MT + 8;
+#pragma unroll
+    for (int p = 0; p < NB - 1; ++p)
+        if (p < nsteps) stage(p * 64, p);
+    if (nsteps >= NB - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int sw = l31 & 7;
     for (int kt = 0; kt < nsteps; ++kt) {
-        const int buf = kt & 1;
+        const int buf = kt % NB;
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nsteps) stage((kt + 1) * 64, buf ^ 1);
+        if (kt + NB - 1 < nsteps) stage((kt + NB - 1) * 64, (kt + NB - 1) % NB);
         const char* ab = lds + buf * TB_STAGE + l31 * 128;                       // activation rows 0..31 (tile i: + 4096 i)
         const char* wb = lds + buf * TB_STAGE + TB_A + (wave * 64 + l31) * 128;    // this wave's 64 weight rows (+32 rows: + 4096)
 #pragma unroll
@@ -313,7 +319,9 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 1) void k_gemm_tn_n256(const bf1
                 acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a, acc[1][i], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // step kt + 1 must have landed before the next barrier; the NB - 2 steps issued after it may stay in flight
+        if (kt + NB - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // acc[jt][i][r]: column n = 64 wave + 32 jt + mfma32_row(r, hf), row m = m0 + 32 i + l31
     const int n0 = wave * 64;
@@ -339,10 +347,10 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 1) void k_gemm_tn_n256(const bf1
     }
 }
 
-template <bool HAS_RES, int MT>
+template <bool HAS_RES, int MT, int NB>
 int launch_tn_n256(const void* A, const void* W, float* C, const float* R, int M, int K, int lda, int ldw, int ldc, int ldr, hipStream_t st) {
-    constexpr int BM = 32 * MT, LDS = 2 * (BM * 128 + TB_W);
-    auto kern = k_gemm_tn_n256<HAS_RES, MT>;
+    constexpr int BM = 32 * MT, LDS = NB * (BM * 128 + TB_W);
+    auto kern = k_gemm_tn_n256<HAS_RES, MT, NB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -368,11 +376,15 @@ bool gaot_gemm_tn_n256_applicable(const void* A, const void* W, const void* C, c
 
 int gaot_gemm_tn_n256_launch(const void* A, const void* W, float* C, const float* R, int64_t M, int64_t K, int64_t lda, int64_t ldw,
                              int64_t ldc, int64_t ldr, hipStream_t st) {
-    static const int bm_env = getenv("GAOT_GEMM_TN_BM") ? atoi(getenv("GAOT_GEMM_TN_BM")) : 64;   // A/B switch
-    if (bm_env == 128) {
-        if (R) return launch_tn_n256<true, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
-        return launch_tn_n256<false, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+    static const int nb_env = getenv("GAOT_GEMM_TN_NB") ? atoi(getenv("GAOT_GEMM_TN_NB")) : 3;   // A/B switch: LDS ring depth
+    if (nb_env == 2) {
+        if (R) return launch_tn_n256<true, 2, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+        return launch_tn_n256<false, 2, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
     }
-    if (R) return launch_tn_n256<true, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
-    return launch_tn_n256<false, 2>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+    if (nb_env == 4) {
+        if (R) return launch_tn_n256<true, 2, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+        return launch_tn_n256<false, 2, 4>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
+    }
+    if (R) return launch_tn_n256<true, 2, 3>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, (int)ldr, st);
+    return launch_tn_n256<false, 2, 3>(A, W, C, R, (int)M, (int)K, (int)lda, (int)ldw, (int)ldc, 0, st);
 }
