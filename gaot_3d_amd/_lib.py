@@ -46,7 +46,6 @@ SIGNATURES = {
     "gaot_gno_bwd": (_i, [C.POINTER(MlpT), _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p,
                           C.POINTER(MlpGradT), _i, _p, _sz, _p]),
     "gaot_geoembed_stats_workspace_bytes": (_sz, []),
-    "gaot_geoembed_stats": (_i, [_p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "gaot_geoembed_moments": (_i, [_p, _p, _p, _p, _i64, _p, _p]),
     "gaot_geoembed_from_moments": (_i, [_p, _i64, _p, _p, _sz, _p]),
     "gaot_geoembed_raw": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _sz, _p]),
@@ -129,7 +128,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 6:
+    if lib.gaot_abi_version() != 7:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

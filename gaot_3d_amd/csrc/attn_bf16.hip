@@ -1023,17 +1023,10 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), (unsigned)(P > 1 ? ceil_div(S, a.chunk) : 1), (unsigned)B);
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its exp / sum / mask VALU work and loses more from the halved occupancy; a rolled 5-waves/SIMD variant was slower too)
-    static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;   // A/B switch (tools/microbench.py)
     // with the maximum-free tile path the kernels need ~150 registers: three waves per SIMD without scratch beat four with it
     // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
-    if (a.drop.thr && nt_env == 4)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true>), fgrid, dim3(256), 0, st, a);
-    else if (a.drop.thr)
+    if (a.drop.thr)
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true>), fgrid, dim3(256), 0, st, a);
-    else if (nt_env == 4)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 2, false>), fgrid, dim3(256), 0, st, a);
-    else if (nt_env == 2)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 2, false>), fgrid, dim3(256), 0, st, a);
     else
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false>), fgrid, dim3(256), 0, st, a);
     if (P > 1)
@@ -1080,12 +1073,10 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         // one key block per wave: 2 workgroups per CU (256 registers) when the grid is small or the dropout words are
         // live (at 4 per CU the dropout variant spills: 0.83 -> 0.49 ms at S = 16384, H = 4)
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
-        static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;
         if (kb_dkv) {
             // dropout: 64-query stages (NT = 2) keep the kernel free of scratch spills (237 registers; the 128-query
             // form spilled 25) and measure 3 % faster: 0.848 -> 0.823 ms at S = 16384, H = 8
-            if (drop && nt_env == 4) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
-            else if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
             else GAOT_KLAUNCH((k_attn_bwd_dkv_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
             if (drop) GAOT_KLAUNCH((k_attn_bwd_dkv_bf16<2, true>), g1, dim3(256), 0, st, a);
@@ -1098,11 +1089,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     if (phase_mask & 4) {
         const dim3 gkb((unsigned)(ceil_div(S, 256) * H), 1, (unsigned)B), g1((unsigned)(ceil_div(S, 128) * H), ny, (unsigned)B);
         const bool occ2 = drop || (int64_t)g1.x * ny * B <= 512;
-        static const int nt_env = getenv("GAOT_ATTN_NT") ? atoi(getenv("GAOT_ATTN_NT")) : 0;
         if (kb_dq) {   // two query blocks per wave: 0.50 -> 0.43 ms at S = 16384, H = 8
             // dropout: 64-key stages, no scratch spills (the 128-key form spilled 11 registers), same time
-            if (drop && nt_env == 4) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, true>), gkb, dim3(256), 0, st, a);
-            else if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
+            if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 2, 2, true>), gkb, dim3(256), 0, st, a);
             else GAOT_KLAUNCH((k_attn_bwd_dq_kb<2, 4, 2, false>), gkb, dim3(256), 0, st, a);
         } else if (occ2) {
             if (drop) GAOT_KLAUNCH((k_attn_bwd_dq_bf16<2, true>), g1, dim3(256), 0, st, a);

@@ -423,13 +423,11 @@ int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact
     const bool a_ks = a_trans != 0;   // A(m,k) = A[k*lda + m]
     const bool b_ks = b_trans == 0;   // B(k,n) = B[k*ldb + n]
     // x W^T with K = 256, both operands bf16 in memory and a bare epilogue (q|k|v and w1|w3 forward): weights-in-registers kernel
-    static const bool k256_on = !(getenv("GAOT_GEMM_K256") && atoi(getenv("GAOT_GEMM_K256")) == 0);
-    if (k256_on && !a_ks && !b_ks && (dt & 3) == 3 && splits <= 1 && !bias && !residual && !preact && act == 0 &&
+    if (!a_ks && !b_ks && (dt & 3) == 3 && splits <= 1 && !bias && !residual && !preact && act == 0 &&
         gaot_gemm_k256_applicable(A, B, C, M, N, K, lda, ldb, ldc, (dt & 4) != 0))
         return gaot_gemm_k256_launch(A, B, C, M, N, lda, ldb, ldc, (dt & 4) != 0, st);
     // x W^T with N = 256 and a long K, both operands bf16 in memory, fp32 result (+ residual): streamed-weight kernel
-    static const bool tn_on = !(getenv("GAOT_GEMM_TN256") && atoi(getenv("GAOT_GEMM_TN256")) == 0);
-    if (tn_on && !a_ks && !b_ks && dt == 3 && splits <= 1 && !bias && !preact && act == 0 &&
+    if (!a_ks && !b_ks && dt == 3 && splits <= 1 && !bias && !preact && act == 0 &&
         gaot_gemm_tn_n256_applicable(A, B, C, residual, M, N, K, lda, ldb, ldc, ldr))
         return gaot_gemm_tn_n256_launch(A, B, (float*)C, residual, M, K, lda, ldb, ldc, ldr, st);
     if (!a_ks && !b_ks) return launch<false, false>(g, a_vec, b_vec, splits, dt, st);

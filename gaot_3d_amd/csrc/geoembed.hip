@@ -256,29 +256,6 @@ __global__ void k_geo_normalize(float* __restrict__ feat, int64_t Q, const float
 
 extern "C" size_t gaot_geoembed_stats_workspace_bytes(void) { return sizeof(double) * 256 * 2 * NF + sizeof(float) * 2 * NF + 64; }
 
-extern "C" int gaot_geoembed_stats(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
-                                   const int32_t* src_sorted, int64_t num_queries, float* features, void* workspace,
-                                   size_t workspace_bytes, gaot_stream_t stream) {
-    GAOT_ENTER();
-    GAOT_CHECK_ARG(num_queries >= 0, "negative size");
-    if (num_queries == 0) return GAOT_OK;
-    GAOT_CHECK_ARG(source_pos && query_pos && rowptr_dst && features && workspace, "null pointer");
-    GAOT_CHECK_ARG(workspace_bytes >= gaot_geoembed_stats_workspace_bytes(), "workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    double* part = (double*)workspace;
-    float* stats = (float*)(part + 256 * 2 * NF);
-    const int64_t threads = num_queries * G;
-    GAOT_KLAUNCH(k_geo_raw, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, source_pos, query_pos,
-                       rowptr_dst, src_sorted, num_queries, features);
-    const int nb = (int)std::min<int64_t>(256, ceil_div(num_queries, 256));
-    GAOT_KLAUNCH(k_geo_colpart, dim3(nb), dim3(256), 0, st, features, num_queries, part);
-    GAOT_KLAUNCH(k_geo_colfinal, dim3(1), dim3(256), 0, st, part, nb, num_queries, stats);
-    GAOT_KLAUNCH(k_geo_normalize, dim3((unsigned)ceil_div(num_queries * NF, 256)), dim3(256), 0, st, features,
-                       num_queries, stats);
-    GAOT_LAUNCH_CHECK();
-    return GAOT_OK;
-}
-
 extern "C" int gaot_geoembed_moments(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
                                      const int32_t* src_sorted, int64_t num_queries, double* moments, gaot_stream_t stream) {
     GAOT_ENTER();
@@ -311,7 +288,7 @@ extern "C" int gaot_geoembed_from_moments(const double* moments, int64_t num_que
     return GAOT_OK;
 }
 
-// Split form of gaot_geoembed_stats for queries that are spread over several ranks (decoder side of a point-sharded
+// Two-sweep form (centroid first, then centred second moments) for queries that are spread over several ranks (decoder side of a point-sharded
 // sample: every rank owns all edges of ITS queries, only the column z-score runs over all queries):
 //   raw      : un-normalised features of the local queries + their column sums / sums of squares (18 doubles)
 //   finalize : z-score with the (all-reduced) sums over num_queries_total rows

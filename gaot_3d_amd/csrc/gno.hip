@@ -771,6 +771,9 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         return GAOT_ERR_UNSUPPORTED;
     }
     GAOT_CHECK_ARG(num_edges >= 0 && num_sources >= 0 && num_queries >= 0, "negative size");
+    // the bf16 kernel gathers its 128-byte rows through 2 GB buffer resources: 2^24 rows per table
+    GAOT_CHECK_ARG(precision != 1 || (num_sources <= (1 << 24) && num_queries <= (1 << 24)),
+                   "bf16 GNO backward: more than 2^24 source or query rows (run the mesh point-sharded or in fp32 mode)");
     GAOT_CHECK_ARG(workspace_bytes >= gaot_gno_bwd_workspace_bytes(mlp, num_edges, num_queries), "workspace too small");
     GAOT_CHECK_ARG(rowptr_src && rowptr_dst, "null rowptr");
     hipStream_t st = (hipStream_t)stream;

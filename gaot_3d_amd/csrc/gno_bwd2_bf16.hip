@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_gno_bwd2_bf16(
         return f;
     };
 
-    // the gathered tables as buffer resources (rows are 128 B: tables of up to 2^25 rows)
+    // the gathered tables as buffer resources (rows are 128 B, 2 GB per resource: tables of up to 2^24 rows; gaot_gno_bwd checks)
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gs, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)f_y, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rgf = __builtin_amdgcn_make_buffer_rsrc((void*)grad_f, 0, 0x7fffffff, 0x00020000);

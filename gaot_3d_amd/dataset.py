@@ -162,7 +162,7 @@ def calculate_or_load_stats(dataset_config, order_file_path: str, data_root: str
     reference concatenates all samples before torch.mean / torch.std; here the sums run sample by sample in fp64."""
     stats_file = os.path.join(data_root, f"{dataset_config.name}_norm_stats.pt")
     if os.path.exists(stats_file) and not getattr(dataset_config, "force_recompute_stats", False):
-        stats = torch.load(stats_file, weights_only=False)
+        stats = torch.load(stats_file, weights_only=True)   # the file holds tensors only
         out = {"mean": stats["mean"].to(dtype), "std": stats["std"].to(dtype)}
         if "c_mean" in stats and "c_std" in stats:
             out["c_mean"], out["c_std"] = stats["c_mean"].to(dtype), stats["c_std"].to(dtype)
@@ -278,7 +278,13 @@ class SampleLoader:
             dev, ev, host = pending
             pending = fetch(groups[gi + 1]) if gi + 1 < len(groups) else None    # overlaps the consumer's step on `dev`
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                # the tensors were allocated on the upload stream's pool: tell the allocator that the consumer stream uses
+                # them, or a dropped batch's blocks could be handed to the next upload while this step's kernels still run
+                for v in dev.__dict__.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
             if self.device_cache > 0:
                 self._cache[key] = dev
                 self._cache.move_to_end(key)

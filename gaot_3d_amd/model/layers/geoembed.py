@@ -55,7 +55,7 @@ class GeometricEmbedding(nn.Module):
         else:
             # geometry only: no autograd through it.  One sweep over the neighbour lists (additive fp64 moments about the
             # query position, then centroid / covariance / eigenvalues per row): 0.22 ms at configs[1] against 0.37 ms
-            # for the two-sweep kernel (gaot_geoembed_stats: centroid first, then centred second moments); same features.
+            # for the two-sweep kernel (gaot_geoembed_raw: centroid first, then centred second moments); same features.
             # A per-sample constant: kept on the neighbour-list object (which the batch caches per edge tensor) for as long
             # as the very same coordinate tensors are passed again (identity + in-place version, references held)
             ent = graph.__dict__.get("_geo_feats")

@@ -413,16 +413,21 @@ _ROPE_TABLES: dict = {}
 def rope_table(freqs: Tensor, s: int) -> Tensor:
     """[s, 16, 2] (cos, sin) of position * frequency for a 32-wide head, cached per (frequencies, s): the frequencies are a
     frozen parameter, so the table is built once"""
-    key = (freqs.data_ptr(), freqs._version, int(s), freqs.device)
-    t = _ROPE_TABLES.get(key)
-    if t is None:
-        if freqs.numel() != 16 or freqs.dtype != torch.float32:
-            raise GaotError("rope_table: 16 fp32 frequencies (head_dim 32) expected")
-        if len(_ROPE_TABLES) > 16:
-            _ROPE_TABLES.clear()
-        t = torch.empty(s, 16, 2, dtype=torch.float32, device=freqs.device)
-        check(_lib.load().gaot_rope_table(_ptr(freqs), int(s), 16, _ptr(t), _stream()), "gaot_rope_table")
-        _ROPE_TABLES[key] = t
+    key = (id(freqs), int(s))
+    ent = _ROPE_TABLES.get(key)
+    # the entry holds the frequencies tensor itself: validated by identity + in-place version, never by address (an
+    # address can be re-used by another model's frequencies)
+    if ent is not None and ent[0] is freqs and ent[1] == freqs._version:
+        _ROPE_TABLES[key] = _ROPE_TABLES.pop(key)     # most recently used last
+        return ent[2]
+    if freqs.numel() != 16 or freqs.dtype != torch.float32:
+        raise GaotError("rope_table: 16 fp32 frequencies (head_dim 32) expected")
+    t = torch.empty(s, 16, 2, dtype=torch.float32, device=freqs.device)
+    check(_lib.load().gaot_rope_table(_ptr(freqs), int(s), 16, _ptr(t), _stream()), "gaot_rope_table")
+    _ROPE_TABLES.pop(key, None)
+    _ROPE_TABLES[key] = (freqs, freqs._version, t)
+    while len(_ROPE_TABLES) > 64:                     # evict the least recently used entry only (a captured graph may
+        _ROPE_TABLES.pop(next(iter(_ROPE_TABLES)))    # still reference the tables of the live models)
     return t
 
 
@@ -566,23 +571,10 @@ def mse_bwd(pred: Tensor, target: Tensor, grad_loss: Tensor) -> Tensor:
     return dp
 
 
-def geoembed_stats(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph) -> Tensor:
-    lib = _lib.load()
-    source_pos = _req(source_pos, torch.float32, "source_pos")
-    query_pos = _req(query_pos, torch.float32, "query_pos")
-    if source_pos.shape[1] != 3:
-        raise GaotError("geoembed statistical features: coord_dim must be 3 on the HIP path")
-    q = g.num_dst
-    feat = torch.empty(q, 9, dtype=torch.float32, device=query_pos.device)
-    ws = _ws(lib.gaot_geoembed_stats_workspace_bytes(), query_pos.device)
-    check(lib.gaot_geoembed_stats(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), q,
-                                  _ptr(feat), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_stats")
-    return feat
-
-
 def geoembed_stats_sharded_queries(source_pos: Tensor, query_pos: Tensor, g: BipartiteGraph, group, num_queries_total: int) -> Tensor:
     """statistical features when the QUERY rows are spread over the ranks of ``group`` (each rank holds all edges of its
-    queries): local raw features, one fp64 SUM all-reduce of the 18 column sums, z-score over all rows"""
+    queries): local raw features (two sweeps per row: centroid, then centred second moments), one fp64 SUM all-reduce of
+    the 18 column sums, z-score over all rows.  ``group=None``: no exchange (all rows are local)"""
     import torch.distributed as dist
     lib = _lib.load()
     source_pos = _req(source_pos, torch.float32, "source_pos")
@@ -595,7 +587,8 @@ def geoembed_stats_sharded_queries(source_pos: Tensor, query_pos: Tensor, g: Bip
     ws = _ws(lib.gaot_geoembed_stats_workspace_bytes(), query_pos.device)
     check(lib.gaot_geoembed_raw(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), q, _ptr(feat),
                                 _ptr(sums), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_raw")
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    if group is not None:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     check(lib.gaot_geoembed_finalize(_ptr(feat), q, _ptr(sums), int(num_queries_total), _ptr(ws), ws.numel(), _stream()),
           "gaot_geoembed_finalize")
     return feat

@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 6
+#define GAOT_ABI_VERSION 7
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -97,12 +97,9 @@ int gaot_gno_bwd(const gaot_mlp_t* mlp /* host */, const float* y_pos, const flo
  * by-query neighbour list.  features: [num_queries, 9].
  * ------------------------------------------------------------------------------------------- */
 size_t gaot_geoembed_stats_workspace_bytes(void);
-int gaot_geoembed_stats(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
-                        const int32_t* src_sorted, int64_t num_queries, float* features, void* workspace,
-                        size_t workspace_bytes, gaot_stream_t stream);
-/* The same features for a point-sharded sample: moments[row][12] = {N, sum d, sum d^2, sum u (3), sum u u^T (6)}, u = x - q
- * (fp64) are plain sums over the row's edges -> SUM all-reduce them across the ranks that hold the edges, then
- * gaot_geoembed_from_moments finishes (variance, centred covariance, eigenvalues, column z-score) on every rank. */
+/* One sweep over the neighbour list: moments[row][12] = {N, sum d, sum d^2, sum u (3), sum u u^T (6)}, u = x - q
+ * (fp64) are plain sums over the row's edges -> (point-sharded sample: SUM all-reduce them across the ranks that hold the
+ * edges, then) gaot_geoembed_from_moments finishes (variance, centred covariance, eigenvalues, column z-score) on every rank. */
 int gaot_geoembed_moments(const float* source_pos, const float* query_pos, const int32_t* rowptr_dst,
                           const int32_t* src_sorted, int64_t num_queries, double* moments, gaot_stream_t stream);
 int gaot_geoembed_from_moments(const double* moments, int64_t num_queries, float* features, void* workspace,

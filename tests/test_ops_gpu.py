@@ -508,8 +508,10 @@ def test_geoembed_stats_and_scale_mix():
     meta, g = gio.load("ops")
     pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
     gr = ops.build_graph(ei.to(DEV), pos.shape[0], lat.shape[0])
-    feats = ops.geoembed_stats(pos.to(DEV), lat.to(DEV), gr)
+    feats = ops.geoembed_from_moments(ops.geoembed_moments(pos.to(DEV), lat.to(DEV), gr))
     close("geo_stat_features_golden", feats, g["out"]["geo_stat_features"], 1e-3, 2e-4)
+    feats2 = ops.geoembed_stats_sharded_queries(pos.to(DEV), lat.to(DEV), gr, None, lat.shape[0])   # two-sweep form
+    close("geo_stat_features_golden_two_sweep", feats2, g["out"]["geo_stat_features"], 1e-3, 2e-4)
     # scale mix
     n = 500
     xs = [gen(n, 32, seed=i) for i in range(3)]
@@ -649,7 +651,7 @@ def test_geoembed_moments_match_two_pass_kernel():
     ei = torch.stack([torch.randint(0, n_src, (e,), generator=g_), torch.randint(0, n_q - 50, (e,), generator=g_)])  # 50 empty rows
     srcd, qd = src.to(DEV), qp.to(DEV)
     gfull = ops.build_graph(ei.to(DEV), n_src, n_q)
-    ref = ops.geoembed_stats(srcd, qd, gfull)
+    ref = ops.geoembed_stats_sharded_queries(srcd, qd, gfull, None, n_q)   # two sweeps per row, all rows local
     mom = ops.geoembed_moments(srcd, qd, gfull)
     got = ops.geoembed_from_moments(mom)
     half = e // 3
