@@ -46,11 +46,13 @@ def parse_args(argv=None):
                          "would be 8.6 GB per layer)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph", action="store_true",
-                    help="N>1: time ONLY the hipGraph replay (default at N>1: time eager launches first, then try capture + "
-                         "replay of the whole step, RCCL collectives included, under a watchdog, and report the faster)")
-    ap.add_argument("--no-graph-attempt", action="store_true", help="N>1: eager launches only, no guarded graph attempt")
+                    help="N>1: ALSO try capture + replay of the WHOLE step, RCCL collectives included, under a watchdog "
+                         "(default at N>1: eager launches are timed first, then the SEGMENTED replay -- hipGraph segments "
+                         "between eagerly issued collectives, gaot_3d_amd/comm.py -- which captures no collective)")
+    ap.add_argument("--no-segmented", action="store_true", help="N>1: eager launches only")
     ap.add_argument("--graph-attempt-timeout", type=float, default=150.0,
-                    help="N>1: seconds the guarded capture + replay may take before the eager result is printed instead")
+                    help="N>1 with --graph: seconds the guarded whole-step capture + replay may take; on a timeout the "
+                         "already measured result is printed and the process exits with status 3")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--atten-dropout", type=float, default=0.1,
                     help="attention dropout of the training step (reference default AttentionConfig.atten_dropout = 0.1, "
@@ -284,7 +286,7 @@ def main(argv=None):
             from gaot_3d_amd import sharding
             # every rank generates only ITS point range on the device (host RNG draws are the whole sample's: 7 floats/point)
             batch, tokens = make_synthetic_shard(n_total, latent, rank, world, k=args.knn, seed=args.seed, device=str(dev))
-            step_ctx = sharding.ShardedStep(model, dist.group.WORLD, n_total, parallel=parallel)
+            step_ctx = sharding.ShardedStep(model, dist.group.WORLD, n_total, parallel=parallel, grad_group=grad_group)
         else:
             batch, tokens = make_synthetic_sample(n_total, latent, k=args.knn, seed=args.seed, device=str(dev))
             step_ctx = None
@@ -367,7 +369,7 @@ def main(argv=None):
             try:
                 on_timeout()
             finally:
-                os._exit(0)
+                os._exit(3)     # the ranks are wedged in a capture / replay: not a clean run, say so
         timer = threading.Timer(timeout_s + (0.0 if rank == 0 else 15.0), fire)
         timer.daemon = True
         timer.start()
@@ -383,10 +385,57 @@ def main(argv=None):
             return None, "capture failed (see stderr); eager launches timed instead"
         return (e, g, l, th), "ok"
 
+    def measure_segmented(step, steps, warmup):
+        """N>1 default launch mode: the step recorded as hipGraph segments between eagerly issued exchange steps
+        (gaot_3d_amd/comm.py).  No collective is captured.  -> (elapsed, SegmentedGraph, loss, host seconds of the timed
+        region, host seconds of it spent inside the exchange closures)"""
+        from gaot_3d_amd import comm
+        for _ in range(max(warmup, 1)):
+            step()                              # eager: lazy initialisation, co-located weights
+        torch.cuda.synchronize()
+        sg = comm.SegmentedGraph()
+        sg.capture(step)
+        for _ in range(max(warmup, 1)):
+            sg.replay()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        sg.host_exchange_s = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sg.replay(timed=True)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.item(), sg, sg.result, t_host, sg.host_exchange_s
+
     n_total = args.points * world if args.scaling == "weak" else args.points
-    use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    use_graph = (not args.no_graph) and world == 1
+    # second process group over the same ranks: the bucketed weight-gradient all-reduce runs on its own RCCL stream
+    grad_group = dist.new_group(backend="gloo" if one_device else "nccl") if world > 1 else None
     model, step = build(n_total, args.atten_dropout, args.parallel)
     elapsed, graph, loss, t_host_main = measure(step, args.steps, args.warmup, use_graph)
+    eager_rec = seg_rec = None
+    if world > 1 and not args.no_graph and not args.no_segmented:
+        eager_rec = dict(ms_per_step=elapsed / args.steps * 1e3, value=n_total / (elapsed / args.steps),
+                         host_ms_per_step=round(t_host_main / args.steps * 1e3, 3))
+        try:
+            e_s, sg, loss_s, th_s, tx_s = measure_segmented(step, args.steps, args.warmup)
+            seg_rec = dict(ms_per_step=e_s / args.steps * 1e3, value=n_total / (e_s / args.steps),
+                           host_ms_per_step=round(th_s / args.steps * 1e3, 3),
+                           host_ms_per_step_outside_exchange=round((th_s - tx_s) / args.steps * 1e3, 3),
+                           graph_segments=sg.num_segments, exchanges=sg.num_exchanges,
+                           host_launches_plus_collectives=sg.num_segments + sg.num_exchanges)
+            if e_s < elapsed:
+                elapsed, loss, t_host_main, graph = e_s, loss_s, th_s, sg
+        except Exception as ex:
+            seg_rec = dict(error=f"{type(ex).__name__}: {ex}")
+            print(f"[bench] segmented capture failed ({type(ex).__name__}: {ex}); eager launches reported", file=sys.stderr)
+            torch.cuda.synchronize()
 
     secondary = None
     fp32_mode = None
@@ -546,10 +595,16 @@ def main(argv=None):
                         for kname, ent in per_kernel.items()},
         }
 
-    launch_txt = "hipGraph replay of one captured step" if graph is not None else "eager"
+    if world > 1 and graph is not None:
+        launch_txt = (f"segmented hipGraph replay: {graph.num_segments} graph launches + {graph.num_exchanges} eagerly issued "
+                      f"exchange steps per step, no collective captured")
+    else:
+        launch_txt = "hipGraph replay of one captured step" if graph is not None else "eager"
     out = make_out(elapsed, launch_txt, t_host_main) if rank == 0 else None
+    if rank == 0 and world > 1:
+        out["eager"], out["segmented"] = eager_rec, seg_rec
     attempted = False
-    if world > 1 and graph is None and not args.no_graph and not args.no_graph_attempt and not one_device:
+    if world > 1 and args.graph and not args.no_graph and not one_device:
         def on_timeout():
             if rank == 0:
                 out["graph_attempt"] = f"no result after {args.graph_attempt_timeout:.0f} s: eager result reported"
@@ -561,12 +616,11 @@ def main(argv=None):
             out["graph_attempt"] = note
             if res is not None:
                 eg, _, _, thg = res
-                out["eager"] = dict(ms_per_step=out["ms_per_step"], value=out["value"])
                 out["graph"] = dict(ms_per_step=eg / args.steps * 1e3, value=n_total / (eg / args.steps))
                 if eg < elapsed:
-                    eager_keep, attempt = out["eager"], out["graph_attempt"]
+                    keep = {kk: out[kk] for kk in ("eager", "segmented", "graph", "graph_attempt")}
                     out = make_out(eg, "hipGraph replay of one captured step (RCCL collectives captured)", thg)
-                    out["eager"], out["graph"], out["graph_attempt"] = eager_keep, dict(ms_per_step=out["ms_per_step"], value=out["value"]), attempt
+                    out.update(keep)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline, args.layers, args.knn, args.seed, args.atten_dropout,
@@ -574,7 +628,7 @@ def main(argv=None):
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
-        if attempted or graph is not None:
+        if attempted:
             # tearing the process group down after its collectives were captured into a hipGraph was seen to block
             # (1-rank RCCL group, tools/try_graph_rccl1.py): the result is out, leave without the teardown
             sys.stderr.flush()

@@ -61,6 +61,8 @@ SIGNATURES = {
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_rope_table": (_i, [_p, _i, _i, _p, _p]),
     "gaot_qkv_image": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _f, _p]),
+    "gaot_qkv_image_packed": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _p, _f, _i, _p]),
+    "gaot_pack_heads": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p, _i, _i, _i, _p]),
     "gaot_attn_bwd_bf16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),

@@ -135,6 +135,29 @@ __global__ void k_prep_do(const float* __restrict__ d_o, const float* __restrict
     delta[((row / S) * H + head) * S + (row % S)] = s;
 }
 
+// the same when dO already IS the bf16 image (sequence-parallel step: the gradient arrives as bf16 from the all-to-all):
+// only delta[b][h][s] = sum_d dO * O is left to do
+__global__ void k_delta_bf16(const bf16_t* __restrict__ dob, const float* __restrict__ o, float* __restrict__ delta, int B,
+                             int S, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, head)
+    const int64_t n = (int64_t)B * S * H;
+    if (i >= n) return;
+    const int head = (int)(i % H);
+    const int64_t row = i / H;
+    const bf16_t* dp = dob + row * H * D + head * D;
+    const float* op = o + row * H * D + head * D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) {
+        const uint4 a = *reinterpret_cast<const uint4*>(dp + 8 * c);
+        const float4 b0 = *reinterpret_cast<const float4*>(op + 8 * c), b1 = *reinterpret_cast<const float4*>(op + 8 * c + 4);
+        s += __uint_as_float(a.x << 16) * b0.x + __uint_as_float(a.x & 0xffff0000u) * b0.y + __uint_as_float(a.y << 16) * b0.z +
+             __uint_as_float(a.y & 0xffff0000u) * b0.w + __uint_as_float(a.z << 16) * b1.x + __uint_as_float(a.z & 0xffff0000u) * b1.y +
+             __uint_as_float(a.w << 16) * b1.z + __uint_as_float(a.w & 0xffff0000u) * b1.w;
+    }
+    delta[((row / S) * H + head) * S + (row % S)] = s;
+}
+
 struct FwdArgs {
     const bf16_t* qkv;   // bf16 image [B*S][ld]
     float* o;            // [B*S][H*32] fp32
@@ -1046,7 +1069,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         return GAOT_ERR_UNSUPPORTED;
     }
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
-    GAOT_CHECK_ARG(qkv_image && o && d_o && lse && do_image && delta && dqkv, "null pointer");
+    GAOT_CHECK_ARG(qkv_image && o && (d_o || (phase_mask & 8)) && lse && do_image && delta && dqkv, "null pointer");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
@@ -1063,7 +1086,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
               gdrop::make_drop(dropout_seed, dropout_p), rope_freqs, chunk, dqkv_part};
     const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
-    if (phase_mask & 1)
+    if (phase_mask & 8)        // do_image already holds the bf16 dO (sequence-parallel exchange): delta only
+        GAOT_KLAUNCH(k_delta_bf16, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const bf16_t*)do_image, o, delta, B, S, H);
+    else if (phase_mask & 1)
         GAOT_KLAUNCH(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
                            S, H);
     if (phase_mask & 2) {

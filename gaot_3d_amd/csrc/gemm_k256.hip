@@ -31,6 +31,9 @@ struct ImageArgs {
     const float* table;   // [S][16][2] = (cos, sin) of position * frequency, or null (no RoPE)
     int S, nq, nk;        // rows per sequence, number of q heads, of k heads (32 columns each; the rest are v heads)
     float qscale;
+    // pack_g > 1 (sequence-parallel exchange, gaot_qkv_image_packed): the image is written as pack_g blocks [M][lw], block j =
+    // q | k | v of rank j's heads (lw = (nq + 2 nk) / pack_g * 32) -- the send buffer of the all-to-all, no repacking pass
+    int pack_g;
 };
 
 template <int MODE>
@@ -109,9 +112,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = t * RB + 32 * i + l31;
-            const unsigned rowoff = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * (C16 ? 2u : 4u) : 0x80000000u;
+            unsigned rowoff = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * (C16 ? 2u : 4u) : 0x80000000u;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
+                int ncol = n0 + 32 * jt;        // first output column of this 32-wide tile
+                if constexpr (MODE == OUT_QKV_IMAGE) {
+                    if (im.pack_g > 1) {        // uniform: destination = block of the rank that owns this head
+                        const int head = ncol >> 5, hl = im.nq / im.pack_g, kl = im.nk / im.pack_g, lw = (hl + 2 * kl) * 32;
+                        int j, within;
+                        if (head < im.nq) { j = head / hl; within = (head % hl) * 32; }
+                        else if (head < im.nq + im.nk) { j = (head - im.nq) / kl; within = (hl + (head - im.nq) % kl) * 32; }
+                        else { j = (head - im.nq - im.nk) / kl; within = (hl + kl + (head - im.nq - im.nk) % kl) * 32; }
+                        rowoff = (m < M && wave_ok) ? ((unsigned)j * (unsigned)M + (unsigned)m) * (unsigned)lw * 2u : 0x80000000u;
+                        ncol = within;
+                    }
+                }
                 if constexpr (MODE == OUT_QKV_IMAGE) {
                     // this wave's 32 columns of tile jt are exactly one head; the lane holds runs of 4 consecutive columns
                     // 8q + 4hf .. +3 = two rotation pairs with frequency indices 4q + 2hf and 4q + 2hf + 1
@@ -145,13 +160,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 2][0], false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 2][1], false, false);
                         const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-                        const int n = n0 + 32 * jt + 8 * q + 16 * hf;
+                        const int n = ncol + 8 * q + 16 * hf;
                         __builtin_amdgcn_raw_buffer_store_b128(v, crs, rowoff + n * 2, 0, 0);
                     }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + 32 * jt + 8 * q + 4 * hf;
+                        const int n = ncol + 8 * q + 4 * hf;
                         const f32x4 v = {acc[jt][i][4 * q], acc[jt][i][4 * q + 1], acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs, rowoff + n * 4, 0, 0);
                     }
@@ -205,7 +220,7 @@ bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int6
 
 int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
                           int c16, hipStream_t st) {
-    const ImageArgs none{nullptr, 1, 0, 0, 1.0f};
+    const ImageArgs none{nullptr, 1, 0, 0, 1.0f, 1};
     if (c16) return launch_k256<OUT_BF16>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
     return launch_k256<OUT_F32>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
 }
@@ -233,8 +248,28 @@ extern "C" int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* imag
         gaot_set_error("gaot_qkv_image: needs d_model = 256, 16-byte aligned bf16 rows and a heads * 32 that is a multiple of 64");
         return GAOT_ERR_UNSUPPORTED;
     }
-    const ImageArgs im{rope_table, S, H, HKV, qscale};
+    const ImageArgs im{rope_table, S, H, HKV, qscale, 1};
     return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, image, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
+}
+
+// The same projection for the sequence-parallel step (gaot_3d_amd/sharding.py): x holds THIS rank's token rows (global
+// positions pos0 .. pos0 + rows - 1 of one sequence), and the image is written as `world` blocks [rows][(H + 2 HKV) / world * 32]
+// -- block j = q | k | v of the heads rank j owns -- i.e. directly as the send buffer of the all-to-all that hands every rank
+// all rows of its heads (what it receives IS its attention image).  rope_table: gaot_rope_table for the FULL sequence.
+extern "C" int gaot_qkv_image_packed(const void* x_bf16, const void* w_bf16, void* packed, int64_t rows, int64_t lda, int64_t ldw,
+                                     int64_t pos0, int H, int HKV, const float* rope_table, float qscale, int world,
+                                     gaot_stream_t stream) {
+    GAOT_ENTER();
+    const int64_t N = (int64_t)(H + 2 * HKV) * 32;
+    GAOT_CHECK_ARG(x_bf16 && w_bf16 && packed && rows > 0 && H > 0 && HKV > 0 && pos0 >= 0, "bad argument");
+    GAOT_CHECK_ARG(world >= 1 && H % world == 0 && HKV % world == 0, "heads must divide over the ranks");
+    if (!gaot_gemm_k256_applicable(x_bf16, w_bf16, packed, rows, N, KK, lda, ldw, N, 1)) {
+        gaot_set_error("gaot_qkv_image_packed: needs d_model = 256, 16-byte aligned bf16 rows and a heads * 32 that is a multiple of 64");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    // positions are pos0 + local row: the table pointer is advanced, S only has to exceed the local row count
+    const ImageArgs im{rope_table ? rope_table + pos0 * 32 : nullptr, (int)rows, H, HKV, qscale, world};
+    return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, packed, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -571,6 +571,76 @@ extern "C" int gaot_cast_bf16(const float* src, void* dst, int64_t n, gaot_strea
     return GAOT_OK;
 }
 
+// ---- head exchange layouts of the sequence-parallel step (gaot_3d_amd/sharding.py) ------------------------------------
+// "rows" layout [rows][ld]: column segments s = 0..nseg-1, each G consecutive groups of w columns starting at col0 (group j
+// belongs to rank j: the q, k and v heads of a fused projection; or all heads of an attention output);
+// "blocks" layout [G][rows][lw]: block j holds, for every row, the groups of rank j side by side (segment s at poff) -- the
+// send / receive buffer of all_to_all_single.  One thread moves 4 consecutive elements; fp32 / bf16 on either side.
+namespace {
+struct PackSegs { int col0[3], w[3], poff[3], nseg; };
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<unsigned short>(const unsigned short* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(unsigned short* p, float4 v) {
+    auto b = [](float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); };
+    *reinterpret_cast<uint2*>(p) = make_uint2(b(v.x) | (b(v.y) << 16), b(v.z) | (b(v.w) << 16));
+}
+template <typename TR, typename TB, bool TO_BLOCKS>
+__global__ void k_pack_heads(TR* __restrict__ rowsbuf, TB* __restrict__ blocks, int64_t rows, int ld, int lw, int G, PackSegs sg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (row, 4-column group of the packed width G * lw)
+    const int per_row = G * lw / 4;
+    if (i >= rows * per_row) return;
+    const int64_t row = i / per_row;
+    const int t = (int)(i % per_row), j = t / (lw / 4), c = (t % (lw / 4)) * 4;     // block j, column c of its row
+    int s = 0;
+    if (sg.nseg > 1 && c >= sg.poff[1]) s = 1;
+    if (sg.nseg > 2 && c >= sg.poff[2]) s = 2;
+    const int col = sg.col0[s] + j * sg.w[s] + (c - sg.poff[s]);
+    TR* rp = rowsbuf + row * ld + col;
+    TB* bp = blocks + ((int64_t)j * rows + row) * lw + c;
+    if constexpr (TO_BLOCKS) st4(bp, ld4(rp)); else st4(rp, ld4(bp));
+}
+}  // namespace
+
+// rows_dtype / blocks_dtype: 0 fp32, 1 bf16.  to_blocks 1: rows layout -> blocks; 0: blocks -> rows layout.
+extern "C" int gaot_pack_heads(void* rows_buf, void* blocks_buf, int64_t rows, int ld, int world, int nseg, const int* col0,
+                               const int* width, int rows_dtype, int blocks_dtype, int to_blocks, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(rows >= 0 && world >= 1 && nseg >= 1 && nseg <= 3 && col0 && width, "bad argument");
+    if (rows == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(rows_buf && blocks_buf, "null pointer");
+    PackSegs sg{};
+    sg.nseg = nseg;
+    int lw = 0;
+    for (int s = 0; s < nseg; ++s) {
+        GAOT_CHECK_ARG(width[s] > 0 && width[s] % 4 == 0 && col0[s] % 4 == 0 && col0[s] + world * width[s] <= ld, "segments: widths / offsets must be multiples of 4 inside the row");
+        sg.col0[s] = col0[s]; sg.w[s] = width[s]; sg.poff[s] = lw;
+        lw += width[s];
+    }
+    GAOT_CHECK_ARG(ld % 4 == 0 && (((uintptr_t)rows_buf | (uintptr_t)blocks_buf) & 15) == 0, "16-byte aligned buffers, ld % 4 == 0");
+    const int64_t n = rows * (world * lw / 4);
+    const dim3 grid((unsigned)ceil_div(n, 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    typedef unsigned short b16;
+#define GAOT_PACK(TR, TB)                                                                                                        \
+    do {                                                                                                                         \
+        if (to_blocks) GAOT_KLAUNCH((k_pack_heads<const TR, TB, true>), grid, blk, 0, st, (const TR*)rows_buf, (TB*)blocks_buf, rows, ld, lw, world, sg); \
+        else GAOT_KLAUNCH((k_pack_heads<TR, const TB, false>), grid, blk, 0, st, (TR*)rows_buf, (const TB*)blocks_buf, rows, ld, lw, world, sg);          \
+    } while (0)
+    if (rows_dtype == 0 && blocks_dtype == 0) GAOT_PACK(float, float);
+    else if (rows_dtype == 0 && blocks_dtype == 1) GAOT_PACK(float, b16);
+    else if (rows_dtype == 1 && blocks_dtype == 0) GAOT_PACK(b16, float);
+    else GAOT_PACK(b16, b16);
+#undef GAOT_PACK
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
 extern "C" int gaot_cast_bf16_multi(const gaot_cast_tensor_t* tensors, int num_tensors, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(num_tensors >= 0, "negative tensor count");

@@ -97,6 +97,17 @@ class GroupQueryFlashAttention(nn.Module):
         spec = None
         if self.head_dim == 32 and seq_group is None and getattr(self, "_head_group", None) is None:
             spec = (freqs, b, s, self.num_heads, self.num_kv_heads, 1.0 / (32 ** 0.5))
+        if seq_group is not None and self.head_dim == 32:
+            from ...sharding import SeqAttnFn, seq_attn_eligible
+            if seq_attn_eligible(x, self):
+                # sequence-parallel, bf16 mode: projection, both all-to-alls and the flash kernels as one autograd node; every
+                # exchanged tensor is bf16 and is written / read in the exchange layout by the producing / consuming kernel
+                assert b == 1, "sequence-parallel attention splits ONE sample"
+                o = SeqAttnFn.apply(x, seq_group, self.num_heads, self.num_kv_heads, freqs, dp, self.q_proj.weight,
+                                    self.k_proj.weight, self.v_proj.weight)
+                y = GF.linear(o.reshape(b * s, -1), self.o_proj.weight, None,
+                              residual=None if residual is None else residual.reshape(b * s, -1))
+                return y.view(b, s, -1)
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], image_spec=spec)  # [B*S, (h+2hkv)*32]
         if self.head_dim != 32:
             if seq_group is not None or getattr(self, "_head_group", None) is not None:

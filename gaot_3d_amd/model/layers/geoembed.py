@@ -50,7 +50,8 @@ class GeometricEmbedding(nn.Module):
         elif shard_group is not None:
             import torch.distributed as dist
             mom = ops.geoembed_moments(source_pos, query_pos, graph)
-            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group)
+            from ... import comm
+            comm.run(lambda: dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group), (mom,))
             feats = ops.geoembed_from_moments(mom)
         else:
             # geometry only: no autograd through it.  One sweep over the neighbour lists (additive fp64 moments about the

@@ -442,26 +442,71 @@ def qkv_image(xb: Tensor, wcat: Tensor, rows: int, b: int, s: int, h: int, hkv: 
     table = rope_table(freqs, s) if freqs is not None else None
     with _timed("qkv_image"):
         check(lib.gaot_qkv_image(_ptr(xb), _ptr(wcat), _ptr(img), rows, xb.shape[1], wcat.shape[1], s, h, hkv, _ptr(table),
-                                 float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)),
-                                 _stream()), "gaot_qkv_image")
+                                 _qscale(scale), _stream()), "gaot_qkv_image")
     return img
 
 
-def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
-                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None) -> Tensor:
-    """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection"""
+def attn_bwd_scratch(b: int, s: int, h: int, hkv: int, device) -> Tensor:
+    """the backward's scratch buffer; its first b*s*h*32 bf16 elements are the dO image"""
+    return _ws(_lib.load().gaot_attn_bwd_bf16_scratch_bytes(b, s, h, hkv), device)
+
+
+def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None,
+                  do_image: Optional[Tensor] = None) -> Tensor:
+    """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection.
+    ``do_image`` (instead of d_o): an attn_bwd_scratch buffer whose head already holds the bf16 dO (sequence-parallel
+    exchange): only delta is computed from it"""
     lib = _lib.load()
     dp, sp = _drop_args(dropout_p, seed)
     dev = o.device
     dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
-    doimg = _ws(lib.gaot_attn_bwd_bf16_scratch_bytes(b, s, h, hkv), dev)
-    for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
+    doimg = do_image if do_image is not None else attn_bwd_scratch(b, s, h, hkv, dev)
+    for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
                                          _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()),
                   "gaot_attn_bwd_bf16")
     return dqkv
+
+
+def _qscale(scale: float) -> float:
+    return float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
+
+
+def qkv_image_packed(xb: Tensor, wcat: Tensor, rows: int, pos0: int, s_total: int, h: int, hkv: int, freqs: Optional[Tensor],
+                     scale: float, world: int) -> Tensor:
+    """the q|k|v projection of this rank's token rows written as the send buffer of the sequence-parallel all-to-all:
+    bf16 [world, rows, (h + 2 hkv) / world * 32] (include/gaot3d_hip.h: gaot_qkv_image_packed)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or wcat.dtype != torch.bfloat16 or not (xb.is_contiguous() and wcat.is_contiguous()):
+        raise GaotError("qkv_image_packed: contiguous bf16 operands expected")
+    lw = (h + 2 * hkv) // world * 32
+    out = torch.empty(world, rows, lw, dtype=torch.bfloat16, device=xb.device)
+    table = rope_table(freqs, s_total) if freqs is not None else None
+    with _timed("qkv_image"):
+        check(lib.gaot_qkv_image_packed(_ptr(xb), _ptr(wcat), _ptr(out), rows, xb.shape[1], wcat.shape[1], int(pos0), h, hkv,
+                                        _ptr(table), _qscale(scale), world, _stream()), "gaot_qkv_image_packed")
+    return out
+
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def pack_heads(rows_buf: Tensor, blocks: Tensor, world: int, segs, to_blocks: bool) -> None:
+    """rows layout [rows, ld] <-> blocks layout [world, rows, sum(width)]; ``segs`` = [(col0, width), ...] (<= 3 column
+    segments, each `world` groups of `width` columns); fp32 or bf16 on either side (include/gaot3d_hip.h: gaot_pack_heads)"""
+    lib = _lib.load()
+    if not (rows_buf.is_contiguous() and blocks.is_contiguous() and rows_buf.is_cuda and blocks.is_cuda):
+        raise GaotError("pack_heads: contiguous device tensors expected")
+    rows, ld = rows_buf.shape
+    col0 = (C.c_int * len(segs))(*[int(c) for c, _ in segs])
+    wid = (C.c_int * len(segs))(*[int(w) for _, w in segs])
+    if tuple(blocks.shape) != (world, rows, sum(int(w) for _, w in segs)):
+        raise GaotError(f"pack_heads: blocks buffer has shape {tuple(blocks.shape)}")
+    check(lib.gaot_pack_heads(_ptr(rows_buf), _ptr(blocks), rows, ld, world, len(segs), col0, wid, _DT[rows_buf.dtype],
+                              _DT[blocks.dtype], int(to_blocks), _stream()), "gaot_pack_heads")
 
 
 def swiglu_fwd(ag: Tensor, f: int) -> Tensor:
@@ -588,7 +633,8 @@ def geoembed_stats_sharded_queries(source_pos: Tensor, query_pos: Tensor, g: Bip
     check(lib.gaot_geoembed_raw(_ptr(source_pos), _ptr(query_pos), _ptr(g.by_dst.rowptr), _ptr(g.by_dst.other), q, _ptr(feat),
                                 _ptr(sums), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_raw")
     if group is not None:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        from . import comm
+        comm.run(lambda: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), (sums,))
     check(lib.gaot_geoembed_finalize(_ptr(feat), q, _ptr(sums), int(num_queries_total), _ptr(ws), ws.numel(), _stream()),
           "gaot_geoembed_finalize")
     return feat

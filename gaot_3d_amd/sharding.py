@@ -37,6 +37,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import comm
 from .data import MeshBatch
 
 Tensor = torch.Tensor
@@ -92,7 +93,7 @@ class GlobalSegmentMeanFn(torch.autograd.Function):
     def forward(ctx, local_mean: Tensor, local_deg: Tensor, group):
         # ONE all-reduce of [M, C + 1]: the per-token sums (the kernel's mean times its own edge count) and the counts
         buf = torch.cat([local_mean * local_deg[:, None], local_deg[:, None]], dim=1)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        comm.run(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group), (buf,))
         dg = buf[:, -1].clamp(min=1.0)
         ctx.save_for_backward(local_deg / dg)
         return buf[:, :-1] / dg[:, None]
@@ -114,7 +115,8 @@ class AllReduceGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        group = ctx.group
+        comm.run(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group), (g,))
         return g, None
 
 
@@ -134,13 +136,13 @@ def local_qkv(qkv: Tensor, rank: int, world: int, h: int, hkv: int) -> Tensor:
 def all_gather_stack(t: Tensor, group, world: int) -> Tensor:
     """[world, *t.shape]: one all-gather (RCCL: all_gather_into_tensor; gloo, used by the tests: list form)"""
     t = t if t.is_contiguous() else t.contiguous()
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if dist.get_backend(group) == "nccl":
-        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=group)
-        return out
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t, group=group)
-    return torch.stack(parts)
+        comm.run(lambda: dist.all_gather_into_tensor(out, t, group=group), (out, t))
+    else:
+        parts = list(out.unbind(0))
+        comm.run(lambda: dist.all_gather(parts, t, group=group), (out, t))
+    return out
 
 
 def gather_head_outputs(o_local: Tensor, group, world: int) -> Tensor:
@@ -164,14 +166,22 @@ def _all_to_all(send: Tensor, group) -> Tensor:
     """block j of ``send`` [G, ...] goes to rank j; block i of the result came from rank i.  RCCL: all_to_all_single; the
     gloo group of the one-GPU tests cannot exchange device tensors this way, so they are staged through the host there"""
     send = send if send.is_contiguous() else send.contiguous()
-    if dist.get_backend(group) == "gloo" and send.is_cuda:
-        h = send.cpu()
-        r = torch.empty_like(h)
-        dist.all_to_all_single(r, h, group=group)
-        return r.to(send.device)
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all_into(recv, send, group)
     return recv
+
+
+def _all_to_all_into(recv: Tensor, send: Tensor, group) -> None:
+    """the same into an existing buffer (e.g. the head of an attention image)"""
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        def staged():
+            h = send.cpu()
+            r = torch.empty_like(h)
+            dist.all_to_all_single(r, h, group=group)
+            recv.copy_(r)
+        comm.run(staged, (recv, send))
+    else:
+        comm.run(lambda: dist.all_to_all_single(recv, send, group=group), (recv, send))
 
 
 def _reduce_scatter_rows(t: Tensor, group, world: int, rank: int) -> Tensor:
@@ -180,10 +190,10 @@ def _reduce_scatter_rows(t: Tensor, group, world: int, rank: int) -> Tensor:
     r = t.shape[0] // world
     if dist.get_backend(group) == "nccl":
         out = torch.empty((r,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+        comm.run(lambda: dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group), (out, t))
         return out
     full = t.clone()
-    dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    comm.run(lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group), (full,))
     return full[rank * r:(rank + 1) * r].clone()
 
 
@@ -223,11 +233,21 @@ class AllGatherRowsFn(torch.autograd.Function):
         return _reduce_scatter_rows(g, ctx.group, ctx.world, ctx.rank), None
 
 
+def qkv_segments(h: int, hkv: int, world: int):
+    """(first column, per-rank width) of the q, k and v head groups inside a fused [rows, (h + 2 hkv) * 32] projection"""
+    hl, kl = h // world * 32, hkv // world * 32
+    return [(0, hl), (h * 32, kl), ((h + hkv) * 32, kl)]
+
+
 def _pack_heads(qkv: Tensor, world: int, h: int, hkv: int) -> Tensor:
     """fused [rows, (h + 2 hkv) * 32] -> [world, rows, (hl + 2 kl) * 32]: block j = q | k | v of rank j's heads"""
     rows = qkv.shape[0]
     hl, kl = h // world * 32, hkv // world * 32
     out = torch.empty(world, rows, hl + 2 * kl, dtype=qkv.dtype, device=qkv.device)
+    if qkv.is_cuda:    # one HIP launch (csrc/rowops.hip: k_pack_heads); the index arithmetic below is the host restatement
+        from . import ops
+        ops.pack_heads(qkv if qkv.is_contiguous() else qkv.contiguous(), out, world, qkv_segments(h, hkv, world), True)
+        return out
     out[:, :, :hl] = qkv[:, :h * 32].view(rows, world, hl).permute(1, 0, 2)
     out[:, :, hl:hl + kl] = qkv[:, h * 32:(h + hkv) * 32].view(rows, world, kl).permute(1, 0, 2)
     out[:, :, hl + kl:] = qkv[:, (h + hkv) * 32:].view(rows, world, kl).permute(1, 0, 2)
@@ -239,6 +259,10 @@ def _unpack_heads(blocks: Tensor, world: int, h: int, hkv: int) -> Tensor:
     rows = blocks.shape[1]
     hl, kl = h // world * 32, hkv // world * 32
     out = torch.empty(rows, (h + 2 * hkv) * 32, dtype=blocks.dtype, device=blocks.device)
+    if blocks.is_cuda:
+        from . import ops
+        ops.pack_heads(out, blocks if blocks.is_contiguous() else blocks.contiguous(), world, qkv_segments(h, hkv, world), False)
+        return out
     out[:, :h * 32].view(rows, world, hl).copy_(blocks[:, :, :hl].permute(1, 0, 2))
     out[:, h * 32:(h + hkv) * 32].view(rows, world, kl).copy_(blocks[:, :, hl:hl + kl].permute(1, 0, 2))
     out[:, (h + hkv) * 32:].view(rows, world, kl).copy_(blocks[:, :, hl + kl:].permute(1, 0, 2))
@@ -276,18 +300,125 @@ class HeadsToSeqFn(torch.autograd.Function):
         o = o if o.is_contiguous() else o.contiguous()
         rows = o.shape[0] // world
         recv = _all_to_all(o.view(world, rows, o.shape[1]), group)          # block j = my rows, rank j's heads
+        if recv.is_cuda:
+            from . import ops
+            out = torch.empty(rows, world * o.shape[1], dtype=o.dtype, device=o.device)
+            ops.pack_heads(out, recv, world, [(0, o.shape[1])], False)
+            return out
         return recv.permute(1, 0, 2).reshape(rows, world * o.shape[1])
 
     @staticmethod
     def backward(ctx, g: Tensor):
         group, world = ctx.meta
         rows, hl = g.shape[0], g.shape[1] // world
-        recv = _all_to_all(g.view(rows, world, hl).permute(1, 0, 2).contiguous(), group)   # block i = rank i's rows, my heads
+        if g.is_cuda:
+            from . import ops
+            send = torch.empty(world, rows, hl, dtype=g.dtype, device=g.device)
+            ops.pack_heads(g if g.is_contiguous() else g.contiguous(), send, world, [(0, hl)], True)
+        else:
+            send = g.view(rows, world, hl).permute(1, 0, 2).contiguous()
+        recv = _all_to_all(send, group)                                     # block i = rank i's rows, my heads
         return recv.view(world * rows, hl), None
 
 
 PARTIAL_GRAD_PREFIXES = ("encoder.lifting.", "encoder.gno.", "decoder.")
 SEQ_PARTIAL_GRAD_PREFIXES = PARTIAL_GRAD_PREFIXES + ("patch_linear.", "processor.")
+
+
+class SeqAttnFn(torch.autograd.Function):
+    """The attention layer of the sequence-parallel step in bf16 mode, exchange included (functional.MultiLinearFn +
+    SeqToHeadsFn + AttentionFn + HeadsToSeqFn of the fp32 form as ONE node):
+
+      forward : q|k|v projection of MY rows written by the GEMM epilogue straight as the all-to-all's bf16 send buffer
+                (RoPE at the rows' global positions, q scale folded in: csrc/gemm_k256.hip, gaot_qkv_image_packed) -> all-to-all
+                -> what arrives IS my heads' attention image -> flash kernels -> O rounded to bf16 -> all-to-all -> my rows,
+                all heads, widened back to fp32 for o_proj (which rounds its A operand to bf16 anyway: no extra rounding)
+      backward: dO of my rows packed + rounded to bf16 in one pass -> all-to-all -> it IS the kernels' dO image (delta from it)
+                -> dK/dV, dQ -> d(q|k|v) rounded to bf16 -> all-to-all -> unpacked as the bf16 A operand of the two GEMMs
+                dx = d W and dW = d^T x.
+    Every exchanged tensor is bf16 (half the bytes of the fp32 form) and the only glue kernels are the two casts and three
+    pack / unpack launches; the roundings are the ones the consuming MFMA kernels apply to these operands in any case."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, group, h: int, hkv: int, freqs: Optional[Tensor], dropout_p: float, wq: Tensor, wk: Tensor,
+                wv: Tensor):
+        from . import functional as GF
+        from . import ops
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        r, k = x.shape[-2], x.shape[-1]
+        xb = GF.bf16_copy_of(x, (r, k))
+        ws = [GF._w2d(w) for w in (wq, wk, wv)]
+        ntot = (h + 2 * hkv) * 32
+        wcat = GF._wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), 1)
+        s_total = r * world
+        scale = 1.0 / (32 ** 0.5)
+        hl, kl = h // world, hkv // world
+        lw = (hl + 2 * kl) * 32
+        send = ops.qkv_image_packed(xb, wcat, r, rank * r, s_total, h, hkv, freqs, scale, world)
+        img = ops._ws(_lib_image_bytes(1, s_total, hl, kl), x.device)                 # image + the kernels' scratch behind it
+        recv = img[:s_total * lw * 2].view(torch.bfloat16).view(world, r, lw)
+        _all_to_all_into(recv, send, group)
+        seed = None
+        if dropout_p > 0.0:   # a head's mask is drawn by the rank that owns it: per-rank seed word from the common stream
+            seed = GF.next_dropout_seed(x.device) + rank * 0x632BE59BD9B4E019 % (1 << 63)
+        o, lse, _ = ops.attn_fwd_bf16(None, None, 1, s_total, hl, kl, scale, dropout_p, seed, image=img)
+        ob = ops.cast_bf16(o)                                                         # [S, hl*32] = [world, r, hl*32] blocks
+        orecv = torch.empty(world, r, hl * 32, dtype=torch.bfloat16, device=x.device)
+        _all_to_all_into(orecv, ob.view(world, r, hl * 32), group)
+        out = torch.empty(r, h * 32, dtype=torch.float32, device=x.device)
+        ops.pack_heads(out, orecv, world, [(0, hl * 32)], False)
+        empty = torch.empty(0, device=x.device)
+        ctx.save_for_backward(xb, wcat, img, o, lse, freqs if freqs is not None else empty, seed if seed is not None else empty)
+        ctx.meta = (group, world, rank, h, hkv, r, k, scale, dropout_p, x.shape, [w.shape for w in (wq, wk, wv)])
+        return out.view(*x.shape[:-1], h * 32)
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        from . import ops
+        xb, wcat, img, o, lse, freqs, seed = ctx.saved_tensors
+        group, world, rank, h, hkv, r, k, scale, dropout_p, xshape, wshapes = ctx.meta
+        hl, kl = h // world, hkv // world
+        lw = (hl + 2 * kl) * 32
+        s_total = r * world
+        d = d_out.reshape(r, h * 32)
+        d = d if d.is_contiguous() else d.contiguous()
+        dsend = torch.empty(world, r, hl * 32, dtype=torch.bfloat16, device=d.device)
+        ops.pack_heads(d, dsend, world, [(0, hl * 32)], True)                         # fp32 rows -> bf16 blocks, one pass
+        scratch = ops.attn_bwd_scratch(1, s_total, hl, kl, d.device)
+        dorecv = scratch[:s_total * hl * 32 * 2].view(torch.bfloat16).view(world, r, hl * 32)
+        _all_to_all_into(dorecv, dsend, group)                                        # = the kernels' dO image of my heads
+        dqkv = ops.attn_bwd_bf16(img, o, None, lse, 1, s_total, hl, kl, scale, dropout_p, seed if dropout_p > 0.0 else None,
+                                 freqs if freqs.numel() else None, do_image=scratch)
+        gsend = ops.cast_bf16(dqkv).view(world, r, lw)
+        grecv = torch.empty(world, r, lw, dtype=torch.bfloat16, device=d.device)
+        _all_to_all_into(grecv, gsend, group)
+        ntot = (h + 2 * hkv) * 32
+        dproj = torch.empty(r, ntot, dtype=torch.bfloat16, device=d.device)           # d(q|k|v) of my rows, fused layout
+        ops.pack_heads(dproj, grecv, world, qkv_segments(h, hkv, world), False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dproj, wcat, r, k, ntot, ntot, k, False, False, precision=1).view(xshape)
+        dwcat = ops.gemm(dproj, xb, ntot, k, r, ntot, k, True, False, precision=1)
+        dws, col = [], 0
+        for shp in wshapes:
+            dws.append(dwcat[col:col + shp[0]].view(shp))
+            col += shp[0]
+        return (dx, None, None, None, None, None, *dws)
+
+
+def _lib_image_bytes(b: int, s: int, h: int, hkv: int) -> int:
+    from . import _lib
+    return int(_lib.load().gaot_attn_bf16_image_bytes(b, s, h, hkv))
+
+
+def seq_attn_eligible(x: Tensor, module) -> bool:
+    """the bf16 sequence-parallel attention node applies: bf16 mode, head_dim 32, d_model 256, the producer's bf16 image"""
+    from . import functional as GF
+    from . import ops
+    return bool(ops.get_precision() == "bf16" and x.is_cuda and module.head_dim == 32 and x.shape[-1] == 256
+                and GF.bf16_copy_of(x, (x.shape[-2], x.shape[-1])) is not None
+                and ((module.num_heads + 2 * module.num_kv_heads) * 32) % 64 == 0
+                and all(w.requires_grad for w in (module.q_proj.weight, module.k_proj.weight, module.v_proj.weight)))
 
 
 def partial_grad_parameters(model, parallel: str = "head") -> List[torch.nn.Parameter]:
@@ -301,17 +432,99 @@ def allreduce_partial_grads(params: List[torch.nn.Parameter], group):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    comm.run(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group), (flat,))
     torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+class GradBuckets:
+    """SUM all-reduce of the partial parameter gradients in buckets, each launched (asynchronously, on its own process
+    group = its own RCCL stream) as soon as backward has produced the last gradient of the bucket, so that the exchange of
+    the 45 MB of Transformer weight gradients of the sequence-parallel step runs under the remaining backward instead of
+    after it.  Buckets follow the order in which backward finishes parameters (reverse registration order).  After
+    ``finish()`` every ``p.grad`` is a view into its bucket's flat buffer holding the summed gradient."""
+
+    def __init__(self, params: List[torch.nn.Parameter], group, bucket_bytes: int = 12 << 20):
+        self.group = group
+        self.buckets = []          # [params, flat, views, pending, handle, launched]
+        order = list(reversed(params))
+        cur, size = [], 0
+        for p in order:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self._add(cur)
+                cur, size = [], 0
+        if cur:
+            self._add(cur)
+        self._index = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._index[id(p)] = bi
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _add(self, ps):
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        self.buckets.append(dict(params=list(ps), flat=flat, views=views, pending=len(ps), handle=None, launched=False))
+
+    def _on_grad(self, p):
+        b = self.buckets[self._index[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
+        if len(have) < len(b["params"]):
+            b["flat"].zero_()      # parameters without a gradient this step contribute zeros
+        if have:
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+            for p, v in have:
+                p.grad = v
+        flat, group = b["flat"], self.group
+
+        def issue():
+            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        comm.run(issue, (flat,))
+        b["launched"] = True
+
+    def finish(self):
+        """launch what backward left incomplete (parameters that received no gradient), then wait for every bucket"""
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        buckets = self.buckets
+
+        def wait():
+            for b in buckets:
+                if b["handle"] is not None:
+                    b["handle"].wait()
+                    b["handle"] = None
+        comm.run(wait, ())
+        for b in self.buckets:
+            b["pending"], b["launched"] = len(b["params"]), False
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 class ShardedStep:
     """forward + MSE + backward of the drop-in model on a rank-local shard (see module docstring)."""
 
-    def __init__(self, model, group, n_total: int, head_parallel: bool = True, parallel: Optional[str] = None):
+    def __init__(self, model, group, n_total: int, head_parallel: bool = True, parallel: Optional[str] = None,
+                 grad_group=None, overlap_grads: bool = True):
         """``parallel``: how the latent Transformer is divided -- "seq" (token rows per rank, heads per rank inside
         attention), "head" (replicated except the attention heads), "replicated"; default "seq" when heads and token rows
-        divide over the ranks, else "head" (``head_parallel=False`` -> "replicated")"""
+        divide over the ranks, else "head" (``head_parallel=False`` -> "replicated").
+        ``grad_group``: a second process group over the same ranks for the bucketed weight-gradient all-reduce (its own RCCL
+        stream, so the buckets overlap the exchange steps of the remaining backward); default: ``group``.
+        ``overlap_grads=False``: one flat all-reduce after backward instead of buckets launched from gradient hooks."""
         self.model = model
         self.group = group
         self.n_total = n_total
@@ -327,13 +540,14 @@ class ShardedStep:
             raise ValueError(f"parallel='seq' needs heads and {s_tok} token rows to divide over {world} ranks")
         self.parallel = parallel
         self.partial = partial_grad_parameters(model, parallel)
+        self.buckets = GradBuckets(self.partial, grad_group if grad_group is not None else group) if overlap_grads else None
         model.encoder._shard_group = group
         model.decoder._shard_group = group
         model._shard_group = group
         model._seq_group = group if parallel == "seq" else None
         for mod in attn:
             # "head": the Transformer is replicated, every rank holds the same q|k|v, computes its share of the heads and
-            # the outputs / gradients are all-gathered; "seq": all-to-all around the kernels (functional.AttentionFn)
+            # the outputs / gradients are all-gathered; "seq": all-to-all around the kernels (SeqAttnFn / AttentionFn)
             mod._head_group = group if parallel == "head" else None
             mod._seq_group = group if parallel == "seq" else None
 
@@ -345,6 +559,8 @@ class ShardedStep:
             if hasattr(mod, "_head_group"):
                 mod._head_group = None
                 mod._seq_group = None
+        if self.buckets is not None:
+            self.buckets.remove()
 
     def forward_backward(self, batch: MeshBatch, tokens_pos: Optional[Tensor]):
         from . import functional as GF
@@ -353,7 +569,11 @@ class ShardedStep:
         # global MSE = sum over ranks of (local sum of squares) / (N_total * out)
         loss = GF.mse_loss(pred, batch.x) * (float(n_local) / float(self.n_total))
         loss.backward()
-        allreduce_partial_grads(self.partial, self.group)
+        if self.buckets is not None:
+            self.buckets.finish()
+        else:
+            allreduce_partial_grads(self.partial, self.group)
         total = loss.detach().clone()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        group = self.group
+        comm.run(lambda: dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group), (total,))
         return total

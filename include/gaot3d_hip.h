@@ -172,7 +172,9 @@ int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride,
  * do_image: scratch of gaot_attn_bwd_bf16_scratch_bytes (bf16 dO image; for launches with few heads also the
  * per-range partial gradients).  When (S/128)*H*B is below two workgroups per CU the streamed range (keys for forward
  * and dQ, queries for dK/dV) is split over blockIdx.y and the parts are combined in a fixed order (forward: by their
- * log-sum-exp; backward: summed at the end of phase 4, so phases 2 and 4 must both be issued). */
+ * log-sum-exp; backward: summed at the end of phase 4, so phases 2 and 4 must both be issued).
+ * phase_mask: 1 = dO image + delta from the fp32 d_o, 2 = dK/dV, 4 = dQ; 8 (instead of 1) = do_image ALREADY holds the bf16
+ * dO (it arrived as bf16 from the sequence-parallel exchange; d_o may be NULL): delta only. */
 /* The fused q|k|v projection written straight as that image (reference attn.py:104-109: q_proj / k_proj / v_proj + rotary
  * embedding of q and k; stands in for gaot_gemm_ex followed by the preparation pass of gaot_attn_fwd_bf16, so the fp32
  * projection never exists in HBM): x [rows][256] bf16, w [(H+2*HKV)*32][256] bf16 (the co-located q/k/v weights), image
@@ -182,6 +184,18 @@ int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride,
 int gaot_rope_table(const float* freqs, int S, int half_dim, float* table, gaot_stream_t stream);
 int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* image, int64_t rows, int64_t lda, int64_t ldw, int S, int H,
                    int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
+/* The same projection for a SEQUENCE-PARALLEL step (one sample's token rows split over `world` ranks, heads split inside
+ * attention; no reference counterpart -- src/trainer/stat.py:431-436 knows sample-level DDP only): x holds this rank's rows
+ * (positions pos0 .. pos0+rows-1), `packed` receives `world` blocks [rows][(H+2*HKV)/world*32], block j = q | k | v of rank j's
+ * heads = the send buffer of the all-to-all; what a rank receives is its attention image ([world*rows][...], its heads).
+ * rope_table: gaot_rope_table for the FULL sequence. */
+int gaot_qkv_image_packed(const void* x_bf16, const void* w_bf16, void* packed, int64_t rows, int64_t lda, int64_t ldw,
+                          int64_t pos0, int H, int HKV, const float* rope_table, float qscale, int world, gaot_stream_t stream);
+/* rows layout [rows][ld] (nseg <= 3 column segments, each `world` groups of width[s] columns from col0[s]; group j belongs to
+ * rank j) <-> blocks layout [world][rows][sum width] (the all_to_all_single buffers of that step); dtypes 0 = fp32, 1 = bf16
+ * on either side (the exchange travels as bf16 in bf16 mode). */
+int gaot_pack_heads(void* rows_buf, void* blocks_buf, int64_t rows, int ld, int world, int nseg, const int* col0,
+                    const int* width, int rows_dtype, int blocks_dtype, int to_blocks, gaot_stream_t stream);
 size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
 size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,

@@ -191,50 +191,75 @@ _WORKER = r"""
 import os, sys, json, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["GAOT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GAOT_ROOT"], "tests"))
 import gaot_3d_amd
-from gaot_3d_amd import functional as GF, sharding
+from gaot_3d_amd import functional as GF, sharding, comm
 from gaot_3d_amd.data import make_synthetic_sample
 from gaot_3d_amd.model import init_model
 import test_model_gpu as T
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="env://")
+grad_group = dist.new_group(backend="gloo")
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-cfg = T.small_config()
+E = os.environ.get
+gaot_3d_amd.set_precision(E("GAOT_TEST_PREC", "fp32"))
+npts, latent, k = int(E("GAOT_TEST_POINTS", "3001")), tuple(int(v) for v in E("GAOT_TEST_LATENT", "8,8,4").split(",")), int(E("GAOT_TEST_K", "4"))
+cfg = T.small_config(hidden=int(E("GAOT_TEST_HIDDEN", "0")) or None, layers=int(E("GAOT_TEST_LAYERS", "2")), latent=latent, k=k)
 model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
-batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device="cuda:0")
+batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=1, device="cuda:0")
 tokens = tokens.to(dev)
 local = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
-step = sharding.ShardedStep(model, dist.group.WORLD, 3001, parallel=os.environ.get("GAOT_TEST_PARALLEL") or None)
-assert step.parallel == (os.environ.get("GAOT_TEST_PARALLEL") or "seq")
-loss = step.forward_backward(local, tokens)
+del batch
+step = sharding.ShardedStep(model, dist.group.WORLD, npts, parallel=E("GAOT_TEST_PARALLEL") or None, grad_group=grad_group)
+assert step.parallel == (E("GAOT_TEST_PARALLEL") or "seq")
+def one():
+    gaot_3d_amd.clear_graph_cache(local)
+    model.zero_grad(set_to_none=True)
+    return step.forward_backward(local, tokens)
+loss = one()
 torch.cuda.synchronize()
+extra = {}
+if E("GAOT_TEST_SEGMENTED") == "1":
+    # the same step recorded as hipGraph segments between eagerly issued exchange steps, replayed twice: bit-identical
+    eager = {k_: p.grad.detach().clone() for k_, p in model.named_parameters() if p.grad is not None}
+    eager_loss = float(loss)
+    sg = comm.SegmentedGraph()
+    sg.capture(one)
+    for _ in range(2):
+        sg.replay()
+    torch.cuda.synchronize()
+    loss = sg.result
+    worst = max(float((p.grad - eager[k_]).abs().max()) for k_, p in model.named_parameters() if p.grad is not None)
+    extra = {"segments": sg.num_segments, "exchanges": sg.num_exchanges, "replay_vs_eager_max_abs": worst,
+             "replay_loss_minus_eager": float(loss) - eager_loss}
 if rank == 0:
-    out = {"loss": float(loss), "grads": {k: p.grad.detach().cpu().double().flatten()[:64].tolist() for k, p in model.named_parameters() if p.grad is not None},
-           "norms": {k: float(p.grad.detach().double().norm()) for k, p in model.named_parameters() if p.grad is not None}}
+    out = {"loss": float(loss), "grads": {k_: p.grad.detach().cpu().double().flatten()[:64].tolist() for k_, p in model.named_parameters() if p.grad is not None},
+           "norms": {k_: float(p.grad.detach().double().norm()) for k_, p in model.named_parameters() if p.grad is not None}, **extra}
     json.dump(out, open(os.environ["GAOT_OUT"], "w"))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-def small_config(dec_geo=None, heads=None):
+def small_config(dec_geo=None, heads=None, hidden=None, layers=2, latent=(8, 8, 4), k=4):
     if dec_geo is None:
         dec_geo = os.environ.get("GAOT_TEST_DEC_GEO", "0") == "1"
     if heads is None:
         heads = int(os.environ.get("GAOT_TEST_HEADS", "2"))
+    if hidden:
+        heads = hidden // 32
     from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerConfig
     from gaot_3d_amd.model.layers.magno import MAGNOConfig
     return types.SimpleNamespace(
-        magno=MAGNOConfig(use_gno=True, gno_coord_dim=3, neighbor_strategy="knn", k_neighbors=4, projection_channels=64,
+        magno=MAGNOConfig(use_gno=True, gno_coord_dim=3, neighbor_strategy="knn", k_neighbors=k, projection_channels=64,
                           in_gno_channel_mlp_hidden_layers=[64, 64], out_gno_channel_mlp_hidden_layers=[64, 64],
                           lifting_channels=32, gno_radius=0.1, use_geoembed=[True, bool(dec_geo)], embedding_method="statistical",
                           encoder_feature_attr=["pos", "c"], mlp_type="linear", precompute_edges=True),
         transformer=TransformerConfig(patch_size=2, hidden_size=32 * heads, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
-                                      num_layers=2, positional_embedding="rope", use_long_range_skip=True,
+                                      num_layers=layers, positional_embedding="rope", use_long_range_skip=True,
                                       attn_config=AttentionConfig(hidden_size=32 * heads, num_heads=heads, num_kv_heads=heads,
                                                                   atten_dropout=0.0),
                                       ffn_config=FFNConfig(hidden_size=128)),
-        latent_tokens=(8, 8, 4))
+        latent_tokens=tuple(latent))
 
 
 @pytest.mark.parametrize("dec_geo,parallel,world", [(False, "seq", 2), (True, "seq", 2), (False, "head", 2), (True, "replicated", 2),
@@ -286,6 +311,67 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world):
         assert torch.allclose(head, ref.flatten()[:64], rtol=1e-3, atol=1e-5 * max(1.0, float(ref.abs().max()))), k
         n += 1
     assert n > 20
+
+
+def _run_shard_workers(tmp_path, world, port, **env_extra):
+    import json, subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    out = tmp_path / "out.json"
+    env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", **{k: str(v) for k, v in env_extra.items()})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world):
+    """bf16 mode, d_model 256 (8 heads): the sequence-parallel attention node (sharding.SeqAttnFn) -- projection written as
+    the all-to-all's bf16 send buffer by the GEMM epilogue, every exchanged tensor bf16, bucketed gradient all-reduce from
+    hooks on a second process group -- against the UNSHARDED bf16 step on the same model and sample.  The roundings are those
+    the consuming MFMA kernels apply anyway (delta is formed from the rounded dO: the one numerical difference)."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        model = init_model(6, 1, "gaot_3d", small_config(False, hidden=256)).to(DEV).train()
+        batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device=str(DEV))
+        loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens.to(DEV)), batch.x)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    got = _run_shard_workers(tmp_path, world, 29561 + world, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq")
+    print(f"[parity] seq_bf16_w{world}/loss: {got['loss']:.8f} vs {float(loss):.8f}")
+    assert abs(got["loss"] - float(loss)) <= 2e-3 * abs(float(loss))
+    n = 0
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        ref = p.grad.detach().cpu().double()
+        assert k in got["norms"], k
+        assert abs(got["norms"][k] - float(ref.norm())) <= 2e-2 * float(ref.norm()) + 1e-6, (k, got["norms"][k], float(ref.norm()))
+        head = torch.tensor(got["grads"][k], dtype=torch.float64)
+        assert float((head - ref.flatten()[:64]).abs().max()) <= 3e-2 * float(ref.abs().max()) + 1e-7, k
+        n += 1
+    assert n > 20
+
+
+@pytest.mark.parametrize("prec,parallel", [("fp32", "seq"), ("bf16", "seq"), ("fp32", "head")])
+def test_segmented_graph_replay_equals_eager_one_gpu(tmp_path, prec, parallel):
+    """comm.SegmentedGraph: the sharded step recorded as hipGraph segments between eagerly issued exchange steps (boundaries
+    inside loss.backward() included: they are crossed on the autograd thread) and replayed twice gives bit-identical
+    gradients and loss to the eager step, with a bounded number of host-side launches"""
+    got = _run_shard_workers(tmp_path, 2, 29571 + (prec == "bf16") + 2 * (parallel == "head"), GAOT_TEST_PREC=prec,
+                             GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL=parallel, GAOT_TEST_SEGMENTED=1)
+    print(f"[parity] segmented_{prec}_{parallel}: segments {got['segments']} exchanges {got['exchanges']} "
+          f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
+    assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
+    assert got["segments"] == got["exchanges"] + 1 and got["segments"] + got["exchanges"] <= 60    # L = 2
 
 
 _DDP_WORKER = r"""

@@ -262,6 +262,47 @@ def test_sequence_parallel_exchange_two_ranks_matches_unsharded(world):
             assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6, float((got - ref).abs().max())
 
 
+# ---- bucketed gradient all-reduce launched from gradient hooks (sharding.GradBuckets) ----------------------------------
+def _bucket_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaot_3d_amd import comm
+        from gaot_3d_amd.sharding import GradBuckets
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(5)
+        ps = [torch.nn.Parameter(torch.randn(n, 7, generator=g)) for n in (3, 50, 11, 200, 5)]
+        unused = torch.nn.Parameter(torch.randn(4, 4, generator=g))            # never receives a gradient
+        gb = GradBuckets(ps + [unused], dist.new_group(backend="gloo"), bucket_bytes=1000)
+        assert len(gb.buckets) >= 3
+        x = torch.randn(7, generator=torch.Generator().manual_seed(100 + rank))
+        for it in range(2):                                                     # second pass: counters were re-armed
+            for p in ps + [unused]:
+                p.grad = None
+            n0 = comm.COUNTS["collectives"]
+            loss = sum(((p * (i + 1)) @ x).sum() for i, p in enumerate(ps))
+            loss.backward()
+            launched_in_backward = comm.COUNTS["collectives"] - n0
+            gb.finish()
+        ret[rank] = ([p.grad.clone() for p in ps], unused.grad is None, launched_in_backward)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_allreduce_from_hooks():
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
+    xs = [torch.randn(7, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    for r in range(world):
+        grads, unused_none, in_bwd = ret[r]
+        assert unused_none and in_bwd >= 2          # complete buckets were launched while backward was still running
+        for i, gsum in enumerate(grads):
+            ref = sum((i + 1) * x for x in xs)[None, :].expand_as(gsum)
+            assert torch.allclose(gsum, ref, rtol=1e-6, atol=1e-6), i
+
+
 def test_bench_spawns_its_ranks_from_a_plain_shell():
     """`python bench.py --gpus 2` outside torchrun must start the ranks as a fresh child (before any GPU call), relay the
     child's JSON line and exit 0; --dry-run keeps the ranks off the GPU (gloo rendezvous only)"""
