@@ -1069,7 +1069,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         return GAOT_ERR_UNSUPPORTED;
     }
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
-    GAOT_CHECK_ARG(qkv_image && o && (d_o || (phase_mask & 8)) && lse && do_image && delta && dqkv, "null pointer");
+    GAOT_CHECK_ARG(qkv_image && o && (d_o || !(phase_mask & 1)) && lse && do_image && delta && dqkv, "null pointer");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;

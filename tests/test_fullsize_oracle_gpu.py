@@ -206,9 +206,26 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
                 PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 5e-2)
 
 
-@pytest.mark.skipif(os.environ.get("GAOT_FULLSIZE_ORACLE", "0") != "1",
-                    reason="opt-in (GAOT_FULLSIZE_ORACLE=1): one oracle step at 500 000 points takes ~2 minutes of 64 host threads "
-                           "and ~90 GB of host memory; its recorded result is profiles/r2_l_parity_fullsize_model_vs_oracle.txt")
+def _fullsize_oracle_skip_reason():
+    """one oracle step at 500 000 points takes ~2 minutes of 64 host threads and ~90 GB of host memory: run by default on a
+    host that has them (GAOT_FULLSIZE_ORACLE=1 forces, =0 skips)"""
+    flag = os.environ.get("GAOT_FULLSIZE_ORACLE")
+    if flag == "1":
+        return None
+    if flag == "0":
+        return "GAOT_FULLSIZE_ORACLE=0"
+    try:
+        import psutil
+        ram = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        return "host memory unknown (psutil missing)"
+    cores = os.cpu_count() or 1
+    if ram < 110 or cores < 24:
+        return (f"whole-step oracle needs >= 110 GB of free host memory and >= 24 cores, this host has {ram:.0f} GB / {cores}; "
+                f"recorded result: profiles/r2_l_parity_fullsize_model_vs_oracle.txt")
+    return None
+
+
 def test_model_full_size_vs_oracle():
     """The WHOLE configs[1] step -- 500 000 points, 4 M edges per direction, 16 384 tokens, L = 10, RoPE, attention dropout
     off -- against the oracle (CPU restatement of the reference, fp32) on the same sample and weights: predictions, loss and
@@ -220,6 +237,10 @@ def test_model_full_size_vs_oracle():
     from gaot_3d_amd.model import init_model
     import bench
     import parity as PAR
+    why = _fullsize_oracle_skip_reason()
+    if why is not None:
+        print(f"[parity] test_model_full_size_vs_oracle skipped: {why}")
+        pytest.skip(why)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     latent, n, k, layers = (64, 64, 32), 500000, 8, 10
     cfg = bench.model_config(latent, layers, k, 0.0)

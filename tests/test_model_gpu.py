@@ -196,16 +196,21 @@ from gaot_3d_amd.data import make_synthetic_sample
 from gaot_3d_amd.model import init_model
 import test_model_gpu as T
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", init_method="env://")
-grad_group = dist.new_group(backend="gloo")
-dev = torch.device("cuda", 0)
-torch.manual_seed(0)
 E = os.environ.get
+dist.init_process_group(E("GAOT_TEST_BACKEND", "gloo"), init_method="env://")
+grad_group = dist.new_group(backend=E("GAOT_TEST_BACKEND", "gloo"))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+torch.manual_seed(0)
 gaot_3d_amd.set_precision(E("GAOT_TEST_PREC", "fp32"))
 npts, latent, k = int(E("GAOT_TEST_POINTS", "3001")), tuple(int(v) for v in E("GAOT_TEST_LATENT", "8,8,4").split(",")), int(E("GAOT_TEST_K", "4"))
-cfg = T.small_config(hidden=int(E("GAOT_TEST_HIDDEN", "0")) or None, layers=int(E("GAOT_TEST_LAYERS", "2")), latent=latent, k=k)
+if E("GAOT_TEST_CFG") == "bench":    # the benchmark's model section (pressure.yaml), dropout off
+    import bench
+    cfg = bench.model_config(latent, int(E("GAOT_TEST_LAYERS", "10")), k, 0.0)
+else:
+    cfg = T.small_config(hidden=int(E("GAOT_TEST_HIDDEN", "0")) or None, layers=int(E("GAOT_TEST_LAYERS", "2")), latent=latent, k=k)
 model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
-batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=1, device="cuda:0")
+batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=int(E("GAOT_TEST_SEED", "1")), device="cuda:0")
 tokens = tokens.to(dev)
 local = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
 del batch
@@ -372,6 +377,17 @@ def test_segmented_graph_replay_equals_eager_one_gpu(tmp_path, prec, parallel):
           f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
     assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
     assert got["segments"] == got["exchanges"] + 1 and got["segments"] + got["exchanges"] <= 60    # L = 2
+
+
+def test_segmented_graph_replay_over_rccl_one_rank(tmp_path):
+    """the same over RCCL ("nccl" backend) on a one-rank group: all_to_all_single / reduce_scatter_tensor / all_gather_into_tensor
+    and the asynchronous bucket all-reduces on a second communicator are issued between graph launches on pool-allocated
+    buffers; replay equals eager bit for bit (multi-rank RCCL needs a multi-GPU node: the driver's scaling run)"""
+    got = _run_shard_workers(tmp_path, 1, 29579, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq",
+                             GAOT_TEST_SEGMENTED=1, GAOT_TEST_BACKEND="nccl")
+    print(f"[parity] segmented_rccl1: segments {got['segments']} exchanges {got['exchanges']} "
+          f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
+    assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
 
 
 _DDP_WORKER = r"""
