@@ -64,6 +64,7 @@ SIGNATURES = {
     "gaot_qkv_image_packed": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _p, _f, _i, _p]),
     "gaot_pack_heads": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p, _i, _i, _i, _p]),
     "gaot_attn_bwd_bf16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "gaot_attn_bwd_bf16_fused_eligible": (_i, [_i, _i, _i, _i]),
     "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),

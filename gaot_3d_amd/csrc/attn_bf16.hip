@@ -951,6 +951,304 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FUSED backward: dK, dV AND dQ from ONE pass over the score tiles (round 3).  The two-pass form recomputes S, the exp and
+// the dropout mask in the dQ pass -- 3 MFMA units and a full softmax to deliver 1 unit of result.  Here a workgroup of
+// 8 waves owns 512 keys (wave: 2 key blocks, as k_attn_bwd_dkv_kb) and streams the queries; per (query tile, key block)
+// unit the wave forms S^T / dP^T, P and dS once, feeds dV / dK as before, and then
+//   * parks its bf16 dS tile [key][query] in a wave-private LDS tile (four 8-byte stores) and reads it back TRANSPOSED
+//     (ds_read_b64_tr_b16) as the B operand of  dQ^T[d][q] += K^T[d][key] dS^T[key][q]  -- K^T fragments come from a
+//     wave-private LDS copy of the wave's own K rows; both key blocks chain into one accumulator;
+//   * writes that 32 x 32 fp32 partial to its slot in LDS; between the two barriers of the NEXT stage the 512 threads sum
+//     the 8 waves' slots in wave order and store the slab's dQ partial to HBM, coalesced: dqpart[b][h][slab][S][32], rounded
+//     to bf16 (the fp32 sum over the slab's 512 keys is rounded once; the GEMMs that consume dq round it to bf16 again anyway).
+// k_attn_dq_reduce then sums the S/512 slabs in slab order in fp32, applies scale / (1-p), rotates back (inverse RoPE) and
+// writes the q columns of dqkv.  No atomics, fixed summation order: bit-reproducible.  The slab partials cost S/512 x the
+// bf16 dQ bytes of HBM writes inside this kernel (hidden: it is compute bound) and one streaming pass to reduce them
+// (256 MB per layer at S = 16 384, 8 heads: 0.07 ms).
+// LDS: stage tiles 8 KB + row constants + K tiles 32 KB + dS tiles 32 KB + dQ slots 64 KB = 137 KB -> one workgroup per CU,
+// two waves per SIMD (256 registers), grid = (S/512) * HKV workgroups: at S = 16 384, 8 heads exactly one per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int FB_KB = 2, FB_NT = 2, FB_QS = 32 * FB_NT;
+constexpr int FB_OFF_STAGE = 0;                                           // Q tiles, then dO tiles
+constexpr int FB_OFF_LSE = FB_OFF_STAGE + 2 * FB_NT * TILE_BYTES;         // float[QS]
+constexpr int FB_OFF_DEL = FB_OFF_LSE + FB_QS * 4;                        // float[QS]
+constexpr int FB_OFF_AW = FB_OFF_DEL + FB_QS * 4;                         // uint32[2 * QS + 4] (+ pad to 16 B)
+constexpr int FB_OFF_K = FB_OFF_AW + (2 * FB_QS + 8) * 4;                 // per wave KB K tiles
+constexpr int fb_off_ds(int W) { return FB_OFF_K + W * FB_KB * TILE_BYTES; }          // per wave KB dS tiles
+constexpr int fb_off_slot(int W) { return fb_off_ds(W) + W * FB_KB * TILE_BYTES; }    // [NT][wave][32 q][32 d] fp32
+constexpr int fb_lds(int W) { return fb_off_slot(W) + FB_NT * W * 4096; }
+constexpr int fb_keys(int W) { return W * FB_KB * 32; }
+
+struct FusedArgs {
+    BwdArgs a;
+    bf16_t* dqpart;       // [B][H][nslab][S][32] bf16 (fp32 sums over the slab's keys, rounded once: see k_attn_dq_reduce)
+    int nslab;
+};
+
+template <bool DROP, int FB_WAVES>
+__global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(FusedArgs fa) {
+    constexpr int FB_KEYS = fb_keys(FB_WAVES), FB_OFF_DS = fb_off_ds(FB_WAVES), FB_OFF_SLOT = fb_off_slot(FB_WAVES);
+    constexpr int NTHR = 64 * FB_WAVES;
+    const BwdArgs& a = fa.a;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    float* lse_s = reinterpret_cast<float*>(lds + FB_OFF_LSE);
+    float* del_s = reinterpret_cast<float*>(lds + FB_OFF_DEL);
+    uint32_t* aw_s = reinterpret_cast<uint32_t*>(lds + FB_OFF_AW);
+    const float dscale = DROP ? a.drop.keep : 1.f;   // see k_attn_bwd_dkv_bf16
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int hkv = blockIdx.x % a.HKV, b = blockIdx.z, slab = blockIdx.x / a.HKV;   // head-fastest: one (kv) head per XCD
+    const int rep = a.H / a.HKV;
+    const int64_t key0 = (int64_t)slab * FB_KEYS + wave * (32 * FB_KB);
+    const int64_t rowbase = (int64_t)b * a.S;
+    char* ktile = lds + FB_OFF_K + wave * FB_KB * TILE_BYTES;
+    char* dstile = lds + FB_OFF_DS + wave * FB_KB * TILE_BYTES;
+    bf16x8 kf[FB_KB][2], vf[FB_KB][2];
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb) {
+        const int64_t ki = key0 + 32 * kb + l31;
+        const bf16_t* kp = a.qkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+        const bf16_t* vp = a.qkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (ki < a.S) {
+                kf[kb][s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s + 8 * hf);
+                vf[kb][s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s + 8 * hf);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kf[kb][s][j] = 0; vf[kb][s][j] = 0; }
+            }
+            // wave-private [key][d] copy of the K rows: its transposed fragments are the A operand of the dQ product
+            *reinterpret_cast<bf16x8*>(ktile + kb * TILE_BYTES + tile_off(l31, 2 * s + hf)) = kf[kb][s];
+        }
+    }
+    f32x16 dkt[FB_KB], dvt[FB_KB];
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkt[kb][r] = 0.f; dvt[kb][r] = 0.f; }
+
+    // staging: 512 16-byte chunks per stage (tile t of Q0 Q1 dO0 dO1, row r, chunk c), NST per thread
+    constexpr int NST = 512 / NTHR;
+    // slot reduction: 512 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NST per thread
+
+    for (int hr = 0; hr < rep; ++hr) {
+        const int head = hkv * rep + hr;
+        const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
+        const bf16_t* dop = a.dob + rowbase * (a.H * D) + head * D;
+        const float* lsep = a.lse + ((int64_t)b * a.H + head) * a.S;
+        const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
+        bf16_t* part = fa.dqpart + (((int64_t)b * a.H + head) * fa.nslab + slab) * (int64_t)a.S * D;
+        auto stage_load = [&](uint4 (&rg)[NST], int64_t q0) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+                const int64_t row = q0 + 32 * (st_t & 1) + st_r;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (row < a.S) val = (st_t < 2) ? *reinterpret_cast<const uint4*>(qp + row * a.ld + 8 * st_c)
+                                                : *reinterpret_cast<const uint4*>(dop + row * (int64_t)(a.H * D) + 8 * st_c);
+                rg[it] = val;
+            }
+        };
+        auto stage_store = [&](const uint4 (&rg)[NST]) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+                *reinterpret_cast<uint4*>(lds + FB_OFF_STAGE + st_t * TILE_BYTES + tile_off(st_r, st_c)) = rg[it];
+            }
+        };
+        auto reduce_slots = [&](int64_t q0) {    // sum the waves' dQ^T partials of the stage that started at q0, wave order
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = threadIdx.x + it * NTHR, rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
+                const int64_t q = q0 + 32 * rt + rq;
+                const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
+                float4 acc = *reinterpret_cast<const float4*>(sp);
+#pragma unroll
+                for (int w = 1; w < FB_WAVES; ++w) {
+                    const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                if (q < a.S)
+                    *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
+                        make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
+            }
+        };
+        uint4 regs[NST];
+        stage_load(regs, 0);
+        float lt = 0.f, et = 0.f;
+        if (threadIdx.x < FB_QS) {
+            lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;
+            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;
+        }
+        uint32_t rk = 0, bsel[FB_KB];
+        if constexpr (DROP) {
+            const int bh = b * a.H + head;
+            rk = gdrop::row_key(seed, bh);
+            const uint32_t ck = gdrop::col_key(seed, bh);
+#pragma unroll
+            for (int kb = 0; kb < FB_KB; ++kb) {
+                const int64_t ki = key0 + 32 * kb + l31;
+                const uint32_t bw = gdrop::col_word(ck, (uint32_t)(ki >> 1));
+                bsel[kb] = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
+            }
+        }
+        for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
+            __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
+            if (q0 > 0) reduce_slots(q0 - FB_QS);
+            stage_store(regs);
+            if (threadIdx.x < FB_QS) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if constexpr (DROP) stage_row_words<FB_QS>(aw_s, rk, q0);
+            __syncthreads();     // B
+            if (q0 + FB_QS < a.S) {
+                stage_load(regs, q0 + FB_QS);
+                if (threadIdx.x < FB_QS) {
+                    const int64_t qq = q0 + FB_QS + threadIdx.x;
+                    lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
+                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < FB_NT; ++t) {
+                if (q0 + 32 * t >= a.S) break;
+                const char* qt = lds + FB_OFF_STAGE + t * TILE_BYTES;
+                const char* dt = lds + FB_OFF_STAGE + (FB_NT + t) * TILE_BYTES;
+                f32x16 lc, dc;
+                load_row_consts(lc, lse_s + 32 * t, hf);
+                load_row_consts(dc, del_s + 32 * t, hf);
+                const bf16x8 qa0 = frag_rows(qt, l31, hf, 0), da0 = frag_rows(dt, l31, hf, 0);
+                const bf16x8 qa1 = frag_rows(qt, l31, hf, 1), da1 = frag_rows(dt, l31, hf, 1);
+                f32x16 sc[FB_KB], dp[FB_KB];
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < FB_KB; ++kb) {
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[kb][0], lc, 0, 0, 0);
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, vf[kb][0], dc, 0, 0, 0);
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[kb][1], sc[kb], 0, 0, 0);
+                    dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
+                const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
+                if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
+                    // which would put block 0's MFMAs under block 1's mask work, is 7 % slower)
+                    const uint32_t* awp = aw_s + (l31 & 1) * (FB_QS + 4) + 32 * t + 4 * hf;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
+                        const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int kb = 0; kb < FB_KB; ++kb)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int r = 4 * g4 + i;
+                                const float p = __builtin_amdgcn_exp2f(sc[kb][r]);
+                                const bool keep = (ww[i] ^ bsel[kb]) >= a.drop.thr;
+                                float pm = keep ? p : 0.f;
+                                asm volatile("" : "+v"(pm));   // select on fp32, then ONE cvt_pk per pair (see k_attn_bwd_dkv_kb)
+                                sc[kb][r] = pm;
+                                dp[kb][r] = p * (keep ? dp[kb][r] : dc[r]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < FB_KB; ++kb) {
+                    if constexpr (!DROP) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(sc[kb][r]);   // rows beyond S carry lse = +inf -> p = 0
+                            sc[kb][r] = p;
+                            dp[kb][r] = p * dp[kb][r];
+                        }
+                    }
+                    bf16x8 p0, p1, d0, d1;
+                    acc_to_frags(sc[kb], p0, p1);
+                    acc_to_frags(dp[kb], d0, d1);
+                    dvt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dc0, p0, dvt[kb], 0, 0, 0);
+                    dkt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc0, d0, dkt[kb], 0, 0, 0);
+                    dvt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dc1, p1, dvt[kb], 0, 0, 0);
+                    dkt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc1, d1, dkt[kb], 0, 0, 0);
+                    // dS tile [key = l31][query]: the lane's 4 runs of 4 consecutive queries (8 g + 4 hf + 0..3) = 8-byte stores
+                    const uint4 lo = __builtin_bit_cast(uint4, d0), hi = __builtin_bit_cast(uint4, d1);
+                    char* dst = dstile + kb * TILE_BYTES;
+                    *reinterpret_cast<uint2*>(dst + tile_off(l31, 0) + 8 * hf) = make_uint2(lo.x, lo.y);
+                    *reinterpret_cast<uint2*>(dst + tile_off(l31, 1) + 8 * hf) = make_uint2(lo.z, lo.w);
+                    *reinterpret_cast<uint2*>(dst + tile_off(l31, 2) + 8 * hf) = make_uint2(hi.x, hi.y);
+                    *reinterpret_cast<uint2*>(dst + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
+                }
+                // dQ^T[d][q] of this wave's 64 keys: K^T (A, transposed read of the K tile) x dS^T (B, transposed read of
+                // the tile just written; LDS operations of one wave complete in order)
+                asm volatile("" ::: "memory");
+                f32x16 dq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < FB_KB; ++kb) {
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 0),
+                                                                 frag_cols(dstile + kb * TILE_BYTES, lane, 0), dq, 0, 0, 0);
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 1),
+                                                                 frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+                // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
+                char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
+                        make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+            }
+        }
+        __syncthreads();
+        reduce_slots(((a.S - 1) / FB_QS) * (int64_t)FB_QS);
+    }
+    const float vsc = DROP ? a.drop.inv_keep : 1.f;
+    const float ksc = vsc / LOG2E;
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb) {
+        const int64_t ki = key0 + 32 * kb + l31;
+        if (ki < a.S) {
+            float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+            float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t = make_float4(dkt[kb][4 * g] * ksc, dkt[kb][4 * g + 1] * ksc, dkt[kb][4 * g + 2] * ksc, dkt[kb][4 * g + 3] * ksc);
+                *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)ki, g, hf);
+                float4 u = make_float4(dvt[kb][4 * g] * vsc, dvt[kb][4 * g + 1] * vsc, dvt[kb][4 * g + 2] * vsc, dvt[kb][4 * g + 3] * vsc);
+                *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
+            }
+        }
+    }
+}
+
+// dq[b, q, head, :] = scale / (1-p) * sum over the key slabs (slab order) of the fused kernel's partials, rotated back
+__global__ void k_attn_dq_reduce(const bf16_t* __restrict__ part, int nslab, int B, int S, int H, int ld, float qsc,
+                                 const float* __restrict__ freqs, float* __restrict__ dqkv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (b, head, q, 4-column group)
+    const int64_t n = (int64_t)B * H * S * 8;
+    if (i >= n) return;
+    const int c = (int)(i & 7);
+    const int64_t q = (i >> 3) % S, bh = (i >> 3) / S;
+    const int head = (int)(bh % H);
+    const int64_t b = bh / H;
+    const bf16_t* p = part + (bh * nslab * (int64_t)S + q) * D + 4 * c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; ++s) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p + (int64_t)s * S * D);
+        acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
+        acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+    }
+    float4 t = make_float4(acc.x * qsc, acc.y * qsc, acc.z * qsc, acc.w * qsc);
+    if (freqs) {   // columns 4c .. 4c+3 = two rotation pairs, frequency indices 2c and 2c + 1
+        float s0, c0, s1, c1;
+        sincosf((float)q * freqs[2 * c], &s0, &c0);
+        sincosf((float)q * freqs[2 * c + 1], &s1, &c1);
+        t = make_float4(t.x * c0 + t.y * s0, t.y * c0 - t.x * s0, t.z * c1 + t.w * s1, t.w * c1 - t.z * s1);
+    }
+    *reinterpret_cast<float4*>(dqkv + (b * S + q) * ld + head * D + 4 * c) = t;
+}
+
 // combine the key-range parts of the forward: lse = log sum_p exp(lse_p), O = sum_p exp(lse_p - lse) O_p
 __global__ void k_attn_combine(const float* __restrict__ o_parts, const float* __restrict__ lse_parts, int P, int64_t o_part,
                                int64_t lse_part, int B, int S, int H, float* __restrict__ o, float* __restrict__ lse) {
@@ -1010,10 +1308,18 @@ extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
     size_t parts = P > 1 ? (size_t)P * ((size_t)B * S * H * D + (size_t)B * H * S) * sizeof(float) : 0;
     return image_only_bytes(B, S, H, HKV) + parts;
 }
-extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV) {
+// the fused backward (k_attn_bwd_fused) is taken when its grid -- one workgroup per 512 keys and kv head -- covers at least
+// half of the chip; smaller launches (few heads per rank of a sharded step) keep the two range-split passes
+static bool fused_bwd_ok(int B, int S, int H, int HKV) { return (int64_t)ceil_div(S, 512) * HKV * B >= 128; }
+extern "C" int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV) { return fused_bwd_ok(B, S, H, HKV) ? 1 : 0; }
+static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {
     const int P = split_parts(ceil_div(S, 128) * H * B, S);
-    size_t parts = P > 1 ? (size_t)P * (size_t)B * S * (H + 2 * HKV) * D * sizeof(float) : 0;
-    return align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64) + parts;
+    return P > 1 ? align256((size_t)P * (size_t)B * S * (H + 2 * HKV) * D * sizeof(float)) : 0;
+}
+extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV) {
+    // dO image | range-split partial gradients (small grids) | dQ slab partials of the fused pass [B][H][S/512][S][32] fp32
+    const size_t dqpart = fused_bwd_ok(B, S, H, HKV) ? (size_t)B * H * ceil_div(S, 512) * S * D * sizeof(bf16_t) : 0;
+    return align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64) + bwd_parts_bytes(B, S, H, HKV) + dqpart;
 }
 
 extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse,
@@ -1091,6 +1397,35 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     else if (phase_mask & 1)
         GAOT_KLAUNCH(k_prep_do, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_o, o, (bf16_t*)do_image, delta, B,
                            S, H);
+    if (phase_mask & (16 | 32)) {   // 16: dK / dV and dQ slab partials from one pass over the score tiles; 32: the slab reduction
+        if (!fused_bwd_ok(B, S, H, HKV)) {
+            gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need ceil(S/512)*HKV*B >= 128 workgroups; use phases 2 and 4");
+            return GAOT_ERR_UNSUPPORTED;
+        }
+        const int nslab = (int)ceil_div(S, fb_keys(8));
+        bf16_t* dqpart = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(parts) + bwd_parts_bytes(B, S, H, HKV));
+        BwdArgs af = a;
+        af.dqkv = dqkv;
+        FusedArgs fa{af, dqpart, nslab};
+        const dim3 gf((unsigned)(nslab * HKV), 1, (unsigned)B);
+        auto go = [&](auto kern, int lds_bytes, int nthr) -> int {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) {
+                gaot_set_error("gaot_attn_bwd_bf16: cannot set dynamic LDS %d for the fused backward", lds_bytes);
+                return GAOT_ERR_LAUNCH;
+            }
+            GAOT_KLAUNCH(kern, gf, dim3(nthr), lds_bytes, st, fa);
+            return GAOT_OK;
+        };
+        if (phase_mask & 16) {
+            const int rc = drop ? go(k_attn_bwd_fused<true, 8>, fb_lds(8), 512) : go(k_attn_bwd_fused<false, 8>, fb_lds(8), 512);
+            if (rc != GAOT_OK) return rc;
+        }
+        const float qsc = drop ? scale * a.drop.inv_keep : scale;
+        if (phase_mask & 32)
+            GAOT_KLAUNCH(k_attn_dq_reduce, dim3((unsigned)ceil_div((int64_t)B * H * S * 8, 256)), dim3(256), 0, st, dqpart, nslab, B, S, H,
+                     ld, qsc, rope_freqs, dqkv);
+    }
     if (phase_mask & 2) {
         // two key blocks per wave halve the LDS reads per (query tile, key block) unit; taken when its grid
         // (256 keys per workgroup) still gives every CU two workgroups

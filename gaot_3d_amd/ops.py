@@ -453,17 +453,24 @@ def attn_bwd_scratch(b: int, s: int, h: int, hkv: int, device) -> Tensor:
 
 def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
                   dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None,
-                  do_image: Optional[Tensor] = None) -> Tensor:
+                  do_image: Optional[Tensor] = None, fused: Optional[bool] = None) -> Tensor:
     """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection.
     ``do_image`` (instead of d_o): an attn_bwd_scratch buffer whose head already holds the bf16 dO (sequence-parallel
-    exchange): only delta is computed from it"""
+    exchange): only delta is computed from it.
+    ``fused``: dK / dV / dQ from one pass over the score tiles (csrc/attn_bf16.hip: k_attn_bwd_fused) instead of the dK/dV
+    pass + the dQ pass; default: whenever its grid fills the chip (gaot_attn_bwd_bf16_fused_eligible)"""
     lib = _lib.load()
     dp, sp = _drop_args(dropout_p, seed)
     dev = o.device
     dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     doimg = do_image if do_image is not None else attn_bwd_scratch(b, s, h, hkv, dev)
-    for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
+    can_fuse = bool(lib.gaot_attn_bwd_bf16_fused_eligible(b, s, h, hkv))
+    if fused and not can_fuse:
+        raise GaotError("attn_bwd_bf16: the fused backward needs ceil(S/512) * hkv * b >= 128 workgroups")
+    phases = ((("attn_bwd", 16), ("attn_bwd_dq_reduce", 32)) if (can_fuse if fused is None else fused)
+              else (("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)))
+    for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1),) + phases:
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
                                          _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()),

@@ -173,7 +173,7 @@ int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride,
  * per-range partial gradients).  When (S/128)*H*B is below two workgroups per CU the streamed range (keys for forward
  * and dQ, queries for dK/dV) is split over blockIdx.y and the parts are combined in a fixed order (forward: by their
  * log-sum-exp; backward: summed at the end of phase 4, so phases 2 and 4 must both be issued).
- * phase_mask: 1 = dO image + delta from the fp32 d_o, 2 = dK/dV, 4 = dQ; 8 (instead of 1) = do_image ALREADY holds the bf16
+ * phase_mask: 1 = dO image + delta from the fp32 d_o, 2 = dK/dV, 4 = dQ; 16 + 32 (instead of 2 and 4) = fused dK/dV/dQ pass + its slab reduction; 8 (instead of 1) = do_image ALREADY holds the bf16
  * dO (it arrived as bf16 from the sequence-parallel exchange; d_o may be NULL): delta only. */
 /* The fused q|k|v projection written straight as that image (reference attn.py:104-109: q_proj / k_proj / v_proj + rotary
  * embedding of q and k; stands in for gaot_gemm_ex followed by the preparation pass of gaot_attn_fwd_bf16, so the fp32
@@ -198,6 +198,9 @@ int gaot_pack_heads(void* rows_buf, void* blocks_buf, int64_t rows, int ld, int 
                     const int* width, int rows_dtype, int blocks_dtype, int to_blocks, gaot_stream_t stream);
 size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV);
 size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV);
+/* 1 when phases 16 + 32 of gaot_attn_bwd_bf16 (dK, dV and dQ from ONE pass over the score tiles, workgroups of 512 keys,
+ * bf16 dQ slab partials in the scratch; fixed-order slab reduction) can be used instead of phases 2 + 4: ceil(S/512)*HKV*B >= 128 */
+int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
                        int H, int HKV, int head_dim, float scale, float dropout_p,
                        const unsigned long long* dropout_seed, gaot_stream_t stream);

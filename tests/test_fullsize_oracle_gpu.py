@@ -98,6 +98,74 @@ def test_attention_full_sequence_vs_fp64_oracle(precision, p):
             PAR.close_peak(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 5e-2)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_fused_backward_vs_fp64_oracle(p):
+    """The FUSED backward (k_attn_bwd_fused: dK, dV and dQ from one pass, bf16 slab partials, fixed-order reduction) at
+    S = 16 384 with 4 heads (the grid at which it is dispatched), against the oracle's SDPA in fp64 for ONE of the heads
+    (head 2: mask keyed by the head index, per-head slices of lse / delta / partials), and against the two-pass kernels."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd import ops
+    s, h, hd = S_FULL, 4, 2
+    g = torch.Generator().manual_seed(4321)
+    qkv = torch.randn(s, 3 * h * 32, generator=g)
+    qkv[:, :2 * h * 32] *= 1.5
+    w = torch.randn(s, h * 32, generator=g)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    seed0 = 0xF05ED + int(p * 100)
+    scale = 32 ** -0.5
+    word = GF.dropout_seed_sequence(seed0, 1)[0]
+    st = torch.tensor([word - (1 << 64) if word >= (1 << 63) else word], dtype=torch.int64, device=DEV) if p > 0 else None
+    assert ops.get_precision() == "fp32"
+    qd, wd, fd = qkv.to(DEV), w.to(DEV), freqs.to(DEV)
+    o, lse, img = ops.attn_fwd_bf16(qd, fd, 1, s, h, h, scale, p, st)
+    g_fused = ops.attn_bwd_bf16(img, o, wd, lse, 1, s, h, h, scale, p, st, freqs=fd, fused=True)
+    g_fused2 = ops.attn_bwd_bf16(img, o, wd, lse, 1, s, h, h, scale, p, st, freqs=fd, fused=True)
+    g_two = ops.attn_bwd_bf16(img, o, wd, lse, 1, s, h, h, scale, p, st, freqs=fd, fused=False)
+    torch.cuda.synchronize()
+    assert torch.equal(g_fused, g_fused2)                       # fixed summation order: bit-reproducible
+    tag = f"attn_fused_S{s}_p{p}"
+    for nm, lo, hi in (("dq", 0, h * 32), ("dk", h * 32, 2 * h * 32), ("dv", 2 * h * 32, 3 * h * 32)):
+        PAR.cosine(f"{tag}/{nm} fused vs two-pass", g_fused[:, lo:hi], g_two[:, lo:hi], 0.99999)
+        PAR.close_peak(f"{tag}/{nm} fused vs two-pass", g_fused[:, lo:hi], g_two[:, lo:hi], 1e-2)
+    keep, p_eff = None, 0.0
+    if p > 0.0:
+        p_eff = orc.dropout_threshold(p) / 65536.0
+        keep = ops.attn_dropout_mask(st, p, 1, h, s)[0, hd].cpu().bool()
+        rows = [0, 31, 4096, s - 1] + torch.randint(0, s, (28,), generator=g).tolist()
+        assert torch.equal(keep[rows], orc.dropout_keep_rows(word, hd, rows, s, p))
+    cols = lambda blk: slice((blk * h + hd) * 32, (blk * h + hd + 1) * 32)
+    one = torch.cat([qkv[:, cols(0)], qkv[:, cols(1)], qkv[:, cols(2)]], dim=1)
+    ref, gref = _attention_fp64(one, w[:, hd * 32:(hd + 1) * 32], freqs, keep, p_eff)
+    PAR.close_peak(f"{tag}/out", o[:, hd * 32:(hd + 1) * 32], ref, 2e-2, rel_l2=1e-2)
+    # the kernels return dq / dk w.r.t. the UNrotated projection (freqs given), as the fp64 oracle does
+    for blk, nm in ((0, "dq"), (1, "dk"), (2, "dv")):
+        got, want = g_fused[:, cols(blk)], gref[:, 32 * blk:32 * (blk + 1)]
+        PAR.cosine(f"{tag}/{nm} vs fp64", got, want, 0.999)
+        PAR.close_peak(f"{tag}/{nm} vs fp64", got, want, 5e-2)
+
+
+@pytest.mark.parametrize("b,s,h,hkv,p", [(4, 2085, 8, 4, 0.1), (2, 4133, 8, 8, 0.0), (1, 16384 - 37, 8, 2, 0.1)])
+def test_attention_fused_backward_ragged_gqa_batches(b, s, h, hkv, p):
+    """ragged sequence lengths (keys and queries past S inside the last slab / stage), grouped-query heads (a workgroup loops
+    over the heads of its kv head) and batches: fused against the two-pass kernels on the same image"""
+    from gaot_3d_amd import ops
+    g = torch.Generator().manual_seed(s)
+    qkv = (torch.randn(b * s, (h + 2 * hkv) * 32, generator=g) * 0.7).to(DEV)
+    d_o = torch.randn(b * s, h * 32, generator=g).to(DEV)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(DEV)
+    st = torch.tensor([77 + s], dtype=torch.int64, device=DEV) if p > 0 else None
+    scale = 32 ** -0.5
+    o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, p, st)
+    a = ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, hkv, scale, p, st, freqs=freqs, fused=True)
+    r = ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, hkv, scale, p, st, freqs=freqs, fused=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    for nm, lo, hi in (("dq", 0, h * 32), ("dk", h * 32, (h + hkv) * 32), ("dv", (h + hkv) * 32, (h + 2 * hkv) * 32)):
+        PAR.cosine(f"attn_fused_ragged_b{b}_s{s}/{nm}", a[:, lo:hi], r[:, lo:hi], 0.99999)
+        PAR.close_peak(f"attn_fused_ragged_b{b}_s{s}/{nm}", a[:, lo:hi], r[:, lo:hi], 1e-2)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def sample():

@@ -30,14 +30,15 @@ if what == "attn":
     att = 2 * s * s * 32 * h
     pd = float(os.environ.get("MB_DROP", 0.0))     # attention dropout probability
     sd = torch.tensor([12345], dtype=torch.int64, device=dev) if pd > 0 else None
+    fused = {"0": False, "1": True}.get(os.environ.get("MB_FUSED"))     # None: the library's choice
     if ops.get_precision() == "bf16":
         o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd)
         timeit(lambda: ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd), "attn_fwd_bf16(+prep)", 2 * att)
-        timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd), "attn_bwd_bf16(all)", 4 * att)
+        timeit(lambda: ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd, fused=fused), "attn_bwd_bf16(all)", 4 * att)
         ops.timing_reset(True)
         for _ in range(reps):
             ops.attn_fwd_bf16(qkv, freqs, b, s, h, h, 32 ** -0.5, pd, sd)
-            ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd)
+            ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, h, 32 ** -0.5, pd, sd, fused=fused)
         torch.cuda.synchronize()
         for name, (calls, tot) in ops.timing_summary().items():
             print(f"  {name}: {tot / calls:.4f} ms")
