@@ -1179,8 +1179,8 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
                 }
                 // dQ^T[d][q] of this wave's 64 keys: K^T (A, transposed read of the K tile) x dS^T (B, transposed read of
-                // the tile just written; LDS operations of one wave complete in order)
-                asm volatile("" ::: "memory");
+                // the tile just written: same LDS object, so the compiler keeps the order, and LDS operations of one wave
+                // complete in order)
                 f32x16 dq;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -1191,7 +1191,6 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                     dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 1),
                                                                  frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
                 }
-                asm volatile("" ::: "memory");
                 // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
                 char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
 #pragma unroll

@@ -71,23 +71,69 @@ class IntegralTransform(nn.Module):
             return torch.zeros(x_pos.shape[0], fcs[-1].weight.shape[0], dtype=x_pos.dtype, device=x_pos.device)
         if graph is None:
             graph = graph_for(edge_index.to(x_pos.device), y_pos.shape[0], x_pos.shape[0])
-        if self._fused_eligible(fcs, f_y):
+        plan = self._fused_plan(fcs, f_y, y_pos)
+        if plan is not None:
+            return self._forward_fused(fcs, y_pos, x_pos, f_y, graph, *plan)
+        return self._forward_general(fcs, y_pos, x_pos, f_y, graph)
+
+    def _fused_plan(self, fcs, f_y, y_pos):
+        """(coord_dim, channels) when the fused kernels (csrc/gno*.hip: coordinates of dimension 3, hidden width 64, 32
+        channels per pass) can evaluate this transform EXACTLY, possibly through zero padding; None -> general path.
+        Kernel MLP coord-pair -> 64 (x 1..3, forward-only: 4) -> C with GELU, 'linear' transform, mean reduction:
+          * coord_dim 1 / 2 (the reference's default is 2, magno.py:28): coordinates padded with zeros to 3-D and the first
+            layer's weight given zero columns for them -- the products that are added are exactly 0;
+          * C != 32 (the reference's default is 16, magno.py:25): the last layer / f_y / the output are cut into blocks of 32
+            channels (the last one zero-padded); every block is one pass of the 32-channel kernels, so C = 16 costs what
+            C = 32 costs and C = 64 two passes (the hidden layers are recomputed), still without a per-edge tensor in HBM."""
+        if self.use_attn or self.transform_type != "linear" or f_y is None:
+            return None
+        # backward keeps the hidden activations of 128 edges in LDS: three hidden layers at most when gradients are needed
+        max_fcs = 4 if (torch.is_grad_enabled() and (f_y.requires_grad or any(fc.weight.requires_grad for fc in fcs))) else 5
+        if activation_name(getattr(self.channel_mlp, "non_linearity", "gelu")) != "gelu" or not (2 <= len(fcs) <= max_fcs):
+            return None
+        if self.training and getattr(self.channel_mlp, "dropout_p", 0.0) > 0.0:
+            return None
+        dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
+        cd = y_pos.shape[1]
+        c = dims[-1][0]
+        ok = (cd in (1, 2, 3) and dims[0] == (64, 2 * cd) and dims[-1][1] == 64 and all(d == (64, 64) for d in dims[1:-1])
+              and 1 <= c <= 256 and f_y.shape[1] == c and all(fc.bias is not None for fc in fcs))
+        return (cd, c) if ok else None
+
+    def _fused_eligible(self, fcs, f_y) -> bool:
+        """the transform runs on the fused kernels as it is (the shipped configuration): no padding, one pass"""
+        dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
+        return (not self.use_attn and self.transform_type == "linear" and f_y is not None and dims[0] == (64, 6)
+                and dims[-1] == (32, 64) and f_y.shape[1] == 32)
+
+    def _forward_fused(self, fcs, y_pos, x_pos, f_y, graph, cd: int, c: int):
+        w2 = lambda fc: fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight    # Conv1d(k=1) storage of mlp_type='channel'
+        if cd == 3 and c == 32:                                                       # the shipped shape: straight through
             params = []
             for fc in fcs:
                 params += [fc.weight, fc.bias]
             return GF.GnoFn.apply(f_y, y_pos, x_pos, graph, *params)
-        return self._forward_general(fcs, y_pos, x_pos, f_y, graph)
-
-    def _fused_eligible(self, fcs, f_y) -> bool:
-        if self.use_attn or self.transform_type != "linear" or f_y is None:
-            return False
-        if activation_name(getattr(self.channel_mlp, "non_linearity", "gelu")) != "gelu" or not (2 <= len(fcs) <= 5):
-            return False
-        if self.training and getattr(self.channel_mlp, "dropout_p", 0.0) > 0.0:
-            return False
-        dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
-        ok = dims[0] == (64, 6) and dims[-1] == (32, 64) and all(d == (64, 64) for d in dims[1:-1])
-        return ok and f_y.shape[1] == 32
+        y3, x3, w0 = y_pos, x_pos, w2(fcs[0])
+        if cd < 3:
+            y3 = torch.nn.functional.pad(y_pos, (0, 3 - cd))
+            x3 = torch.nn.functional.pad(x_pos, (0, 3 - cd))
+            cols = torch.tensor(list(range(cd)) + [3 + i for i in range(cd)], device=w0.device)
+            w0 = w0.new_zeros(64, 6).index_copy(1, cols, w0)       # [src coords | 0.. | query coords | 0..]
+        mid = []
+        for fc in fcs[1:-1]:
+            mid += [w2(fc), fc.bias]
+        wl, bl = w2(fcs[-1]), fcs[-1].bias
+        outs = []
+        for c0 in range(0, c, 32):
+            n = min(32, c - c0)
+            wb, bb, fb = wl[c0:c0 + n], bl[c0:c0 + n], f_y[:, c0:c0 + n]
+            if n < 32:
+                wb = torch.nn.functional.pad(wb, (0, 0, 0, 32 - n))
+                bb = torch.nn.functional.pad(bb, (0, 32 - n))
+                fb = torch.nn.functional.pad(fb, (0, 32 - n))
+            o = GF.GnoFn.apply(fb.contiguous(), y3, x3, graph, w0, fcs[0].bias, *mid, wb.contiguous(), bb.contiguous())
+            outs.append(o[:, :n] if n < 32 else o)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
     def _forward_general(self, fcs, y_pos, x_pos, f_y, g):
         """integral_transform.py:114-171 on per-edge tensors (dst-sorted order)"""

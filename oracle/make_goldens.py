@@ -352,6 +352,43 @@ def lr_schedule_case():
     save("lr_mix", dict(name="lr_mix", totals=cases, lr=3e-4, max_lr=1e-2, min_lr=1e-5, final_lr=2e-6), arrays)
 
 
+def gno_shapes_case():
+    """IntegralTransform at the shapes the reference's own defaults produce (MAGNOConfig: lifting_channels 16,
+    gno_coord_dim 2, magno.py:25,28) and at 64 channels / four hidden layers: linear transform, mean reduction, on a
+    variable-degree graph with empty rows and one heavy row"""
+    from src.model.layers.integral_transform import IntegralTransform
+
+    gen = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    lat3 = latent_grid((4, 4, 3))
+    pos3 = torch.rand(230, 3, generator=gen) * 2 - 1
+    pos3, enc = variable_degree_graph(pos3, lat3, 0.45, heavy_token=7, n_heavy=41, gen=gen)
+    arrays = {"in/pos3": pos3, "in/lat3": lat3, "in/edge_index": enc.to(torch.int32)}
+    variants = []
+    for tag, cd, layers in (("c16_cd2", 2, [4, 64, 64, 64, 16]), ("c64_cd3", 3, [6, 64, 64, 64]),
+                            ("c32_cd3_nh4", 3, [6, 64, 64, 64, 64, 32]), ("c48_cd1", 1, [2, 64, 48])):
+        it = IntegralTransform(channel_mlp_layers=layers, transform_type="linear", coord_dim=cd)
+        with torch.no_grad():
+            for p in it.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        y, x = pos3[:, :cd].contiguous(), lat3[:, :cd].contiguous()
+        f = torch.randn(pos3.shape[0], layers[-1], generator=gen).requires_grad_(True)
+        out = it(y_pos=y, x_pos=x, edge_index=enc, f_y=f)
+        w = torch.randn(out.shape, generator=gen)
+        (out * w).sum().backward()
+        arrays[f"in/{tag}/f_y"] = f.detach()
+        arrays[f"in/{tag}/w"] = w
+        arrays[f"out/{tag}/out"] = out
+        arrays[f"grad/{tag}/f_y"] = f.grad
+        for k, v in it.state_dict().items():
+            arrays[f"sd/{tag}/{k}"] = v
+        for k, g in grads_of(it).items():
+            arrays[f"grad/{tag}/{k}"] = g
+        variants.append(dict(tag=tag, coord_dim=cd, layers=layers))
+    save("gno_shapes", dict(name="gno_shapes", variants=variants), arrays)
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not present: goldens can only be regenerated in the authoring container"
     install_stubs()
@@ -366,7 +403,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lr_mix":
         lr_schedule_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "gno_shapes":
+        gno_shapes_case()
+        return
     ops_case()
+    gno_shapes_case()
     attn_dropout_case()
     lr_schedule_case()
     cond_norm_case()

@@ -280,3 +280,46 @@ def test_gno_bf16_backward(nh):
     for i in range(n):
         check(f"grad_w{i}", gw[i], sdr[f"channel_mlp.fcs.{i}.weight"].grad)
         check(f"grad_b{i}", gb[i], sdr[f"channel_mlp.fcs.{i}.bias"].grad)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_integral_transform_other_shapes_golden(precision):
+    """The reference's default shapes -- lifting_channels 16, gno_coord_dim 2 (magno.py:25,28) -- 64 and 48 channels, coord
+    dim 1 and a four-hidden-layer kernel MLP, against goldens captured from the reference's IntegralTransform
+    (tests/golden/gno_shapes.npz).  All but the four-hidden-layer case (general path when gradients are wanted) run the FUSED
+    kernels through exact zero padding / 32-channel passes (IntegralTransform._fused_plan)."""
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers.integral_transform import IntegralTransform
+    meta, g = gio.load("gno_shapes")
+    ei = g["in"]["edge_index"].to(DEV)
+    gaot_3d_amd.set_precision(precision)
+    try:
+        for v in meta["variants"]:
+            tag, cd, layers = v["tag"], v["coord_dim"], v["layers"]
+            it = IntegralTransform(channel_mlp_layers=layers, transform_type="linear", coord_dim=cd)
+            it.load_state_dict(gio.sub(g["sd"], tag), strict=True)
+            it = it.to(DEV).train()
+            y, x = g["in"]["pos3"][:, :cd].contiguous().to(DEV), g["in"]["lat3"][:, :cd].contiguous().to(DEV)
+            f = g["in"][f"{tag}/f_y"].to(DEV).requires_grad_(True)
+            plan = it._fused_plan(list(it.channel_mlp.fcs), f, y)
+            assert (plan is None) == (len(layers) == 6), (tag, plan)
+            out = it(y_pos=y, x_pos=x, edge_index=ei, f_y=f)
+            (out * g["in"][f"{tag}/w"].to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            ref = g["out"][f"{tag}/out"]
+            if precision == "fp32":
+                close(f"gno_shapes/{tag}/out", out, ref, 1e-4, 1e-5)
+                close(f"gno_shapes/{tag}/grad_f", f.grad, g["grad"][f"{tag}/f_y"], 1e-3, 1e-5)
+                for k, p in it.named_parameters():
+                    close(f"gno_shapes/{tag}/grad_{k}", p.grad, g["grad"][f"{tag}/{k}"], 1e-3, 2e-5)
+            else:
+                peak = float(ref.abs().max())
+                assert report(f"gno_shapes_bf16/{tag}/out", out.detach().cpu(), ref) <= 3e-2 * peak
+                a = torch.cat([p.grad.flatten().cpu().double() for _, p in it.named_parameters()] + [f.grad.flatten().cpu().double()])
+                r = torch.cat([g["grad"][f"{tag}/{k}"].flatten().double() for k, _ in it.named_parameters()] +
+                              [g["grad"][f"{tag}/f_y"].flatten().double()])
+                cos = float(a @ r / (a.norm() * r.norm()))
+                print(f"[parity] gno_shapes_bf16/{tag}/grads cosine={cos:.6f}")
+                assert cos >= 0.999
+    finally:
+        gaot_3d_amd.set_precision("fp32")

@@ -68,6 +68,25 @@ def test_integral_transform_variants():
     close(out, g["out"]["it_empty"])
 
 
+def test_integral_transform_other_shapes():
+    """the reference's default shapes (lifting_channels 16, gno_coord_dim 2: magno.py:25,28), 64 channels, four hidden
+    layers, coord dim 1"""
+    meta, g = gio.load("gno_shapes")
+    ei = g["in"]["edge_index"]
+    for v in meta["variants"]:
+        tag, cd = v["tag"], v["coord_dim"]
+        y, x = g["in"]["pos3"][:, :cd].contiguous(), g["in"]["lat3"][:, :cd].contiguous()
+        sd = {k: t.clone().requires_grad_(True) for k, t in gio.sub(g["sd"], tag).items()}
+        f = g["in"][f"{tag}/f_y"].clone().requires_grad_(True)
+        out = orc.integral_transform(sd, "", y, x, ei, f, "linear", None, cd)
+        close(out, g["out"][f"{tag}/out"])
+        (out * g["in"][f"{tag}/w"]).sum().backward()
+        close(f.grad, g["grad"][f"{tag}/f_y"], 1e-3, 1e-6)
+        for k, gr in gio.sub(g["grad"], tag).items():
+            if k != "f_y":
+                close(sd[k].grad, gr, 1e-3, 1e-5)
+
+
 def test_geoembed_variants():
     meta, g = gio.load("ops")
     pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
