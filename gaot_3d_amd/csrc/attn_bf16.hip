@@ -1135,9 +1135,16 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                 if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
                     // which would put block 0's MFMAs under block 1's mask work, is 7 % slower)
                     const uint32_t* awp = aw_s + (l31 & 1) * (FB_QS + 4) + 32 * t + 4 * hf;
+                    // the row words of group g4 + 1 are requested before group g4 is worked on (left alone the compiler loads
+                    // each group right before its first use and the wave sits out the LDS round trip four times per tile)
+                    uint4 wv = *reinterpret_cast<const uint4*>(awp);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const uint4 wv = *reinterpret_cast<const uint4*>(awp + 8 * g4);
+                        uint4 nxt = wv;
+                        if (g4 < 3) {
+                            nxt = *reinterpret_cast<const uint4*>(awp + 8 * (g4 + 1));
+                            asm volatile("" : "+v"(nxt.x), "+v"(nxt.y), "+v"(nxt.z), "+v"(nxt.w));   // keep the load here
+                        }
                         const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
                         for (int kb = 0; kb < FB_KB; ++kb)
@@ -1151,6 +1158,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                                 sc[kb][r] = pm;
                                 dp[kb][r] = p * (keep ? dp[kb][r] : dc[r]);
                             }
+                        wv = nxt;
                     }
                 }
 #pragma unroll

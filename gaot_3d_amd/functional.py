@@ -342,9 +342,11 @@ class DropoutFn(Function):
     stream, regenerated for the gradient"""
 
     @staticmethod
-    def forward(ctx, x: Tensor, p: float):
+    def forward(ctx, x: Tensor, p: float, salt: int = 0):
         xc = x if x.is_contiguous() else x.contiguous()
         seed = next_dropout_seed(xc.device)
+        if salt:      # a rank of a sharded step draws its own masks from the common seed stream
+            seed = seed + salt * 0x632BE59BD9B4E019 % (1 << 63)
         ctx.save_for_backward(seed)
         ctx.p = p
         return ops.dropout(xc, seed, p)
@@ -352,11 +354,11 @@ class DropoutFn(Function):
     @staticmethod
     def backward(ctx, d: Tensor):
         (seed,) = ctx.saved_tensors
-        return ops.dropout(d if d.is_contiguous() else d.contiguous(), seed, ctx.p), None
+        return ops.dropout(d if d.is_contiguous() else d.contiguous(), seed, ctx.p), None, None
 
 
-def dropout(x: Tensor, p: float, training: bool) -> Tensor:
-    return DropoutFn.apply(x, float(p)) if (training and p > 0.0) else x
+def dropout(x: Tensor, p: float, training: bool, salt: int = 0) -> Tensor:
+    return DropoutFn.apply(x, float(p), int(salt)) if (training and p > 0.0) else x
 
 
 class MatmulFn(Function):
@@ -421,7 +423,7 @@ class RopeFn(Function):
 
 
 def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, head_dim: int,
-                      dropout_p: float = 0.0) -> Tensor:
+                      dropout_p: float = 0.0, seed_rank: int = 0) -> Tensor:
     """softmax(Q K^T / sqrt(d)) V for ANY head_dim (reference attn.py:110-127 accepts every hidden_size % num_heads == 0):
     the unfused general path -- per (batch, head) an S x S score matrix in HBM, exact-fp32 MFMA GEMMs, the row softmax and
     element dropout kernels, autograd by composition.  head_dim 32 (every shipped configuration) runs the flash kernels."""
@@ -441,7 +443,7 @@ def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: i
             k = blk[:, (h + kv) * head_dim:(h + kv + 1) * head_dim]
             v = blk[:, (h + hkv + kv) * head_dim:(h + hkv + kv + 1) * head_dim]
             p = RowSoftmaxFn.apply(MatmulFn.apply(q, k, True))
-            p = dropout(p, dropout_p, dropout_p > 0.0)
+            p = dropout(p, dropout_p, dropout_p > 0.0, seed_rank)
             heads.append(MatmulFn.apply(p, v, False))
         outs.append(torch.cat(heads, dim=1))
     return outs[0] if b == 1 else torch.cat(outs, dim=0)

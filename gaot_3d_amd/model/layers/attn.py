@@ -110,9 +110,28 @@ class GroupQueryFlashAttention(nn.Module):
                 return y.view(b, s, -1)
         qkv = GF.multi_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], image_spec=spec)  # [B*S, (h+2hkv)*32]
         if self.head_dim != 32:
-            if seq_group is not None or getattr(self, "_head_group", None) is not None:
-                raise NotImplementedError("the sharded attention exchanges are written for head_dim 32")
-            o = GF.attention_general(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, self.head_dim, dp)
+            # any other head size: the general path (functional.attention_general); sharded, the same exchanges around it
+            head_group, hd = getattr(self, "_head_group", None), self.head_dim
+            if seq_group is not None:
+                import torch.distributed as dist
+                from ...sharding import HeadsToSeqFn, SeqToHeadsFn
+                g = dist.get_world_size(seq_group)
+                assert b == 1, "sequence-parallel attention splits ONE sample"
+                ql = SeqToHeadsFn.apply(qkv, seq_group, self.num_heads, self.num_kv_heads, hd)       # all rows, my heads
+                o = GF.attention_general(ql, freqs, b, s * g, self.num_heads // g, self.num_kv_heads // g, hd, dp,
+                                         dist.get_rank(seq_group))
+                o = HeadsToSeqFn.apply(o, seq_group)
+            elif head_group is not None:
+                import torch.distributed as dist
+                from ...sharding import GatherHeadsFn, LocalHeadsFn
+                g = dist.get_world_size(head_group)
+                if self.num_heads % g or self.num_kv_heads % g:
+                    raise ValueError(f"head-parallel attention: {self.num_heads} / {self.num_kv_heads} heads do not divide over {g} ranks")
+                ql = LocalHeadsFn.apply(qkv, head_group, self.num_heads, self.num_kv_heads, hd)
+                o = GatherHeadsFn.apply(GF.attention_general(ql, freqs, b, s, self.num_heads // g, self.num_kv_heads // g, hd, dp,
+                                                             dist.get_rank(head_group)), head_group)
+            else:
+                o = GF.attention_general(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, hd, dp)
         elif seq_group is not None:
             # sequence-parallel (gaot_3d_amd/sharding.py): x holds this rank's token rows; one all-to-all hands every rank
             # ALL rows of ITS heads, the kernels run unchanged on them, a second all-to-all brings the rows back

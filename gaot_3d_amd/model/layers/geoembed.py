@@ -41,8 +41,8 @@ class GeometricEmbedding(nn.Module):
             graph = graph_for(edge_index.to(query_pos.device), source_pos.shape[0], query_pos.shape[0])
         if self.method == "pointnet":
             if shard_group is not None and sharded_queries_total is None:
-                raise NotImplementedError("point-sharded PointNet GeoEmbed on the encoder side (edges of a token spread "
-                                          "over the ranks) is not implemented")
+                # encoder side of a point-sharded sample: a token's edges are spread over the ranks
+                return self._forward_pointnet_sharded(source_pos, query_pos, graph, shard_group)
             return self._forward_pointnet(source_pos, query_pos, graph)   # decoder side: every query's edges are local
         if shard_group is not None and sharded_queries_total is not None:
             # decoder side of a point-sharded sample: the query rows are spread over the ranks, only the z-score is global
@@ -68,6 +68,32 @@ class GeometricEmbedding(nn.Module):
                 graph.__dict__["_geo_feats"] = (source_pos, source_pos._version, query_pos, query_pos._version, feats)
         h = GF.linear(feats, self.mlp[0].weight, self.mlp[0].bias, act="relu", precision=0)
         return GF.linear(h, self.mlp[2].weight, self.mlp[2].bias, precision=0)
+
+    def _forward_pointnet_sharded(self, source_pos, query_pos, g, group):
+        """the same when the edges of a query row are spread over the ranks of ``group`` (sharding.py): per-edge MLP and the
+        segment pooling on the local edges, then max -> all-reduce(MAX) with the gradient routed to the owning rank(s), mean ->
+        all-reduce of sums and counts; fc and the empty-row mask on the global result (identical on every rank)"""
+        from ...sharding import GlobalSegmentMaxFn, GlobalSegmentMeanFn
+        nq = query_pos.shape[0]
+        rp = g.by_dst.rowptr
+        deg = (rp[1:] - rp[:-1]).to(torch.float32)
+        if g.by_dst.num_edges == 0:            # this rank holds no edge: it still takes part in the exchanges
+            local = torch.zeros(nq, 32, dtype=query_pos.dtype, device=query_pos.device)
+        else:
+            c = EO.edge_coords(source_pos, query_pos, g, 1)
+            h = GF.linear(c, self.pointnet_mlp[0].weight, self.pointnet_mlp[0].bias, act="relu", precision=0)
+            h = GF.linear(h, self.pointnet_mlp[2].weight, self.pointnet_mlp[2].bias, act="relu", precision=0)
+            local = EO.SegmentReduceFn.apply(h, g, EO.MAX if self.pooling == "max" else EO.MEAN)
+        if self.pooling == "max":
+            pooled, gdeg = GlobalSegmentMaxFn.apply(local, deg, group)
+        else:
+            pooled = GlobalSegmentMeanFn.apply(local, deg, group)
+            gdeg = deg.clone()
+            import torch.distributed as dist
+            from ... import comm
+            comm.run(lambda: dist.all_reduce(gdeg, op=dist.ReduceOp.SUM, group=group), (gdeg,))
+        po = GF.linear(pooled, self.fc[0].weight, self.fc[0].bias, precision=0)
+        return EO.RowScaleFn.apply(po, (gdeg > 0).to(torch.float32))
 
     def _forward_pointnet(self, source_pos, query_pos, g):
         """geoembed.py:184-222: MLP(nbr - query) per edge, segment max | mean, fc; rows without neighbours = 0"""

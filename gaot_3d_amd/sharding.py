@@ -104,6 +104,34 @@ class GlobalSegmentMeanFn(torch.autograd.Function):
         return g * ratio[:, None], None, None
 
 
+class GlobalSegmentMaxFn(torch.autograd.Function):
+    """local per-row maximum (0 where the rank has no edge of the row) + local degree -> (maximum over the edges of ALL ranks
+    with rows that have no edge anywhere = 0, global degree).  Backward: the gradient of a row / channel goes to the rank(s)
+    whose local maximum IS the global one (shared equally if several ranks tie, as torch's amax does among tied elements);
+    the local segment-max backward then routes it to the arg-max edge.  PointNet GeoEmbed of a point-sharded encoder
+    (reference geoembed.py:211-216, pooling 'max')."""
+
+    @staticmethod
+    def forward(ctx, local_max: Tensor, local_deg: Tensor, group):
+        has_local = (local_deg > 0)[:, None]
+        glob = torch.where(has_local, local_max, torch.full_like(local_max, float("-inf")))
+        mine = glob.clone()
+        comm.run(lambda: dist.all_reduce(glob, op=dist.ReduceOp.MAX, group=group), (glob,))
+        deg = local_deg.clone()
+        comm.run(lambda: dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group), (deg,))
+        owner = ((mine == glob) & has_local).to(local_max.dtype)
+        nown = owner.clone()
+        comm.run(lambda: dist.all_reduce(nown, op=dist.ReduceOp.SUM, group=group), (nown,))
+        ctx.save_for_backward(owner / nown.clamp(min=1.0))
+        ctx.mark_non_differentiable(deg)
+        return torch.where((deg > 0)[:, None], glob, torch.zeros_like(glob)), deg
+
+    @staticmethod
+    def backward(ctx, g: Tensor, _gdeg=None):
+        (share,) = ctx.saved_tensors
+        return g * share, None, None
+
+
 class AllReduceGradFn(torch.autograd.Function):
     """identity in forward; SUM all-reduce of the gradient in backward (partial -> full)."""
 
@@ -121,15 +149,15 @@ class AllReduceGradFn(torch.autograd.Function):
 
 
 # ---- head-parallel attention: the index arithmetic of the exchange (device independent; kernels live in functional.py)
-def head_slices(rank: int, world: int, h: int, hkv: int):
-    """column ranges of rank's q / k / v heads inside a fused [rows, (h + 2 hkv) * 32] projection"""
+def head_slices(rank: int, world: int, h: int, hkv: int, hd: int = 32):
+    """column ranges of rank's q / k / v heads inside a fused [rows, (h + 2 hkv) * hd] projection"""
     hl, kl = h // world, hkv // world
-    return ((rank * hl * 32, (rank + 1) * hl * 32), ((h + rank * kl) * 32, (h + (rank + 1) * kl) * 32),
-            ((h + hkv + rank * kl) * 32, (h + hkv + (rank + 1) * kl) * 32))
+    return ((rank * hl * hd, (rank + 1) * hl * hd), ((h + rank * kl) * hd, (h + (rank + 1) * kl) * hd),
+            ((h + hkv + rank * kl) * hd, (h + hkv + (rank + 1) * kl) * hd))
 
 
-def local_qkv(qkv: Tensor, rank: int, world: int, h: int, hkv: int) -> Tensor:
-    (q0, q1), (k0, k1), (v0, v1) = head_slices(rank, world, h, hkv)
+def local_qkv(qkv: Tensor, rank: int, world: int, h: int, hkv: int, hd: int = 32) -> Tensor:
+    (q0, q1), (k0, k1), (v0, v1) = head_slices(rank, world, h, hkv, hd)
     return torch.cat([qkv[:, q0:q1], qkv[:, k0:k1], qkv[:, v0:v1]], dim=1)
 
 
@@ -151,14 +179,43 @@ def gather_head_outputs(o_local: Tensor, group, world: int) -> Tensor:
     return allo.permute(1, 0, 2).reshape(o_local.shape[0], world * o_local.shape[1])
 
 
-def gather_qkv_grads(dqkv_local: Tensor, group, world: int, h: int, hkv: int) -> Tensor:
-    """[rows, (hl + 2 kl)*32] per rank (q | k | v of the rank's heads) -> [rows, (h + 2 hkv)*32] in the fused layout"""
+def gather_qkv_grads(dqkv_local: Tensor, group, world: int, h: int, hkv: int, hd: int = 32) -> Tensor:
+    """[rows, (hl + 2 kl)*hd] per rank (q | k | v of the rank's heads) -> [rows, (h + 2 hkv)*hd] in the fused layout"""
     hl, kl = h // world, hkv // world
     rows = dqkv_local.shape[0]
-    allg = all_gather_stack(dqkv_local, group, world).permute(1, 0, 2)           # [rows, world, (hl + 2 kl) * 32]
-    return torch.cat([allg[:, :, :hl * 32].reshape(rows, h * 32),
-                      allg[:, :, hl * 32:(hl + kl) * 32].reshape(rows, hkv * 32),
-                      allg[:, :, (hl + kl) * 32:].reshape(rows, hkv * 32)], dim=1)
+    allg = all_gather_stack(dqkv_local, group, world).permute(1, 0, 2)           # [rows, world, (hl + 2 kl) * hd]
+    return torch.cat([allg[:, :, :hl * hd].reshape(rows, h * hd),
+                      allg[:, :, hl * hd:(hl + kl) * hd].reshape(rows, hkv * hd),
+                      allg[:, :, (hl + kl) * hd:].reshape(rows, hkv * hd)], dim=1)
+
+
+class LocalHeadsFn(torch.autograd.Function):
+    """replicated q|k|v [rows, (h + 2 hkv) * hd] -> this rank's heads [rows, (h/G + 2 hkv/G) * hd]; backward all-gathers the
+    head gradients back into the fused layout (head-parallel attention on the general path, any head_dim)"""
+
+    @staticmethod
+    def forward(ctx, qkv: Tensor, group, h: int, hkv: int, hd: int):
+        ctx.meta = (group, dist.get_world_size(group), h, hkv, hd)
+        return local_qkv(qkv, dist.get_rank(group), ctx.meta[1], h, hkv, hd).contiguous()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        group, world, h, hkv, hd = ctx.meta
+        return gather_qkv_grads(g if g.is_contiguous() else g.contiguous(), group, world, h, hkv, hd), None, None, None, None
+
+
+class GatherHeadsFn(torch.autograd.Function):
+    """head outputs of this rank [rows, (h/G) * hd] -> all heads in global order [rows, h * hd]; backward keeps the rank's slice"""
+
+    @staticmethod
+    def forward(ctx, o: Tensor, group):
+        ctx.meta = (dist.get_world_size(group), dist.get_rank(group), o.shape[1])
+        return gather_head_outputs(o if o.is_contiguous() else o.contiguous(), group, ctx.meta[0])
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        world, rank, w = ctx.meta
+        return g[:, rank * w:(rank + 1) * w].contiguous(), None
 
 
 # ---- sequence-parallel Transformer: the exchange steps as autograd Functions (device independent) ----------------------
@@ -233,39 +290,39 @@ class AllGatherRowsFn(torch.autograd.Function):
         return _reduce_scatter_rows(g, ctx.group, ctx.world, ctx.rank), None
 
 
-def qkv_segments(h: int, hkv: int, world: int):
-    """(first column, per-rank width) of the q, k and v head groups inside a fused [rows, (h + 2 hkv) * 32] projection"""
-    hl, kl = h // world * 32, hkv // world * 32
-    return [(0, hl), (h * 32, kl), ((h + hkv) * 32, kl)]
+def qkv_segments(h: int, hkv: int, world: int, hd: int = 32):
+    """(first column, per-rank width) of the q, k and v head groups inside a fused [rows, (h + 2 hkv) * hd] projection"""
+    hl, kl = h // world * hd, hkv // world * hd
+    return [(0, hl), (h * hd, kl), ((h + hkv) * hd, kl)]
 
 
-def _pack_heads(qkv: Tensor, world: int, h: int, hkv: int) -> Tensor:
-    """fused [rows, (h + 2 hkv) * 32] -> [world, rows, (hl + 2 kl) * 32]: block j = q | k | v of rank j's heads"""
+def _pack_heads(qkv: Tensor, world: int, h: int, hkv: int, hd: int = 32) -> Tensor:
+    """fused [rows, (h + 2 hkv) * hd] -> [world, rows, (hl + 2 kl) * hd]: block j = q | k | v of rank j's heads"""
     rows = qkv.shape[0]
-    hl, kl = h // world * 32, hkv // world * 32
+    hl, kl = h // world * hd, hkv // world * hd
     out = torch.empty(world, rows, hl + 2 * kl, dtype=qkv.dtype, device=qkv.device)
     if qkv.is_cuda:    # one HIP launch (csrc/rowops.hip: k_pack_heads); the index arithmetic below is the host restatement
         from . import ops
-        ops.pack_heads(qkv if qkv.is_contiguous() else qkv.contiguous(), out, world, qkv_segments(h, hkv, world), True)
+        ops.pack_heads(qkv if qkv.is_contiguous() else qkv.contiguous(), out, world, qkv_segments(h, hkv, world, hd), True)
         return out
-    out[:, :, :hl] = qkv[:, :h * 32].view(rows, world, hl).permute(1, 0, 2)
-    out[:, :, hl:hl + kl] = qkv[:, h * 32:(h + hkv) * 32].view(rows, world, kl).permute(1, 0, 2)
-    out[:, :, hl + kl:] = qkv[:, (h + hkv) * 32:].view(rows, world, kl).permute(1, 0, 2)
+    out[:, :, :hl] = qkv[:, :h * hd].view(rows, world, hl).permute(1, 0, 2)
+    out[:, :, hl:hl + kl] = qkv[:, h * hd:(h + hkv) * hd].view(rows, world, kl).permute(1, 0, 2)
+    out[:, :, hl + kl:] = qkv[:, (h + hkv) * hd:].view(rows, world, kl).permute(1, 0, 2)
     return out
 
 
-def _unpack_heads(blocks: Tensor, world: int, h: int, hkv: int) -> Tensor:
+def _unpack_heads(blocks: Tensor, world: int, h: int, hkv: int, hd: int = 32) -> Tensor:
     """inverse of _pack_heads"""
     rows = blocks.shape[1]
-    hl, kl = h // world * 32, hkv // world * 32
-    out = torch.empty(rows, (h + 2 * hkv) * 32, dtype=blocks.dtype, device=blocks.device)
+    hl, kl = h // world * hd, hkv // world * hd
+    out = torch.empty(rows, (h + 2 * hkv) * hd, dtype=blocks.dtype, device=blocks.device)
     if blocks.is_cuda:
         from . import ops
-        ops.pack_heads(out, blocks if blocks.is_contiguous() else blocks.contiguous(), world, qkv_segments(h, hkv, world), False)
+        ops.pack_heads(out, blocks if blocks.is_contiguous() else blocks.contiguous(), world, qkv_segments(h, hkv, world, hd), False)
         return out
-    out[:, :h * 32].view(rows, world, hl).copy_(blocks[:, :, :hl].permute(1, 0, 2))
-    out[:, h * 32:(h + hkv) * 32].view(rows, world, kl).copy_(blocks[:, :, hl:hl + kl].permute(1, 0, 2))
-    out[:, (h + hkv) * 32:].view(rows, world, kl).copy_(blocks[:, :, hl + kl:].permute(1, 0, 2))
+    out[:, :h * hd].view(rows, world, hl).copy_(blocks[:, :, :hl].permute(1, 0, 2))
+    out[:, h * hd:(h + hkv) * hd].view(rows, world, kl).copy_(blocks[:, :, hl:hl + kl].permute(1, 0, 2))
+    out[:, (h + hkv) * hd:].view(rows, world, kl).copy_(blocks[:, :, hl + kl:].permute(1, 0, 2))
     return out
 
 
@@ -274,20 +331,20 @@ class SeqToHeadsFn(torch.autograd.Function):
     [S, (h/G + 2 hkv/G) * 32] (one all-to-all); backward is the inverse exchange of the gradient"""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, group, h: int, hkv: int):
+    def forward(ctx, qkv: Tensor, group, h: int, hkv: int, hd: int = 32):
         world = dist.get_world_size(group)
         if h % world or hkv % world:
             raise ValueError(f"sequence-parallel attention: {h} / {hkv} heads do not divide over {world} ranks")
-        ctx.meta = (group, world, h, hkv)
-        recv = _all_to_all(_pack_heads(qkv, world, h, hkv), group)          # block i = rank i's rows
+        ctx.meta = (group, world, h, hkv, hd)
+        recv = _all_to_all(_pack_heads(qkv, world, h, hkv, hd), group)      # block i = rank i's rows
         return recv.view(world * qkv.shape[0], recv.shape[2])
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        group, world, h, hkv = ctx.meta
+        group, world, h, hkv, hd = ctx.meta
         g = g if g.is_contiguous() else g.contiguous()
         recv = _all_to_all(g.view(world, g.shape[0] // world, g.shape[1]), group)   # block j = my rows, rank j's heads
-        return _unpack_heads(recv, world, h, hkv), None, None, None
+        return _unpack_heads(recv, world, h, hkv, hd), None, None, None, None
 
 
 class HeadsToSeqFn(torch.autograd.Function):
@@ -321,7 +378,9 @@ class HeadsToSeqFn(torch.autograd.Function):
         return recv.view(world * rows, hl), None
 
 
-PARTIAL_GRAD_PREFIXES = ("encoder.lifting.", "encoder.gno.", "decoder.")
+# parameters whose gradients are partial sums over a rank's points / edges (the per-edge PointNet MLP of an encoder-side
+# GeoEmbed included; its fc layer, like the statistical GeoEmbed's MLP, sees replicated per-token inputs)
+PARTIAL_GRAD_PREFIXES = ("encoder.lifting.", "encoder.gno.", "encoder.geoembed.pointnet_mlp.", "decoder.")
 SEQ_PARTIAL_GRAD_PREFIXES = PARTIAL_GRAD_PREFIXES + ("patch_linear.", "processor.")
 
 

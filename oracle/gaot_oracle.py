@@ -159,7 +159,7 @@ def geoembed_stat_features(source_pos: Tensor, query_pos: Tensor, edge_index: Te
     n_c = n_i.clone()
     n_c[n_c == 0] = 1.0
     cov = cov_sum / n_c.view(-1, 1, 1)                  # :151
-    pca = torch.zeros(nq, nd)
+    pca = torch.zeros(nq, nd, dtype=query_pos.dtype)
     if has.any():                                       # :155-166
         reg = cov[has] + 1e-6 * torch.eye(nd, dtype=cov.dtype).unsqueeze(0)
         ev = torch.linalg.eigvalsh(reg).flip(dims=[1])  # descending

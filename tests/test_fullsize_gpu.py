@@ -264,7 +264,7 @@ def test_configs3_radius_encoder_bidirectional_decoder_geoembed_both_sides(sampl
     batch, tokens = sample
     b = MeshBatch(pos=batch.pos, x=batch.x, c=torch.tensor([[0.85, 2.5]], device=DEV).expand(N_PTS, 2).contiguous(),
                   batch=batch.batch, ptr=batch.ptr)
-    cfg = _config(4)
+    cfg = _config(10)
     cfg.magno.neighbor_strategy = ["radius", "bidirectional"]
     cfg.magno.k_neighbors = 1
     cfg.magno.gno_radius = 0.033

@@ -197,14 +197,36 @@ def _sample_rows(deg, n, gen):
     return torch.tensor(sorted(rows), dtype=torch.long)
 
 
-@pytest.mark.parametrize("side,nh", [("encoder", 3), ("decoder", 2)])
+_CFG3_GRAPHS = {}
+
+
+def _cfg3_graph(batch, tokens, which):
+    """BASELINE configs[3] graphs on the 500 000-point sample, built by the device kernels (checked against the graph oracle
+    in tests/test_graph_gpu.py): radius-graph encoder (r = 0.033, at most 32 points per token) and bidirectional decoder
+    (knn k = 1 united with the radius graph around the points)"""
+    if which not in _CFG3_GRAPHS:
+        from gaot_3d_amd.model.layers.magno import get_neighbor_strategy
+        lat_b = torch.zeros(tokens.shape[0], dtype=torch.long, device=DEV)
+        strat, dec = ("radius", False) if which == "encoder_radius" else ("bidirectional", True)
+        _CFG3_GRAPHS[which] = get_neighbor_strategy(strat, batch.pos, batch.batch, tokens, lat_b, 0.033, 1, dec,
+                                                    latent_dims=(64, 64, 32)).to(torch.int32).contiguous()
+    return _CFG3_GRAPHS[which]
+
+
+@pytest.mark.parametrize("side,nh", [("encoder", 3), ("decoder", 2), ("encoder_radius", 3), ("decoder_bidirectional", 2)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
+    """the fused GNO forward / backward on the FULL graphs of configs[1] (knn, flipped) and of configs[3] (radius-capped
+    encoder, bidirectional decoder: variable degree on both sides) against the oracle on sampled rows"""
     from gaot_3d_amd import ops
     batch, tokens = sample
     m = tokens.shape[0]
     if side == "encoder":      # points -> tokens: variable degree, empty tokens, tokens with hundreds of points
         ei, y_pos, x_pos, n_src, n_dst = batch.encoder_edge_index_s0, batch.pos, tokens, N_PTS, m
+    elif side == "encoder_radius":
+        ei, y_pos, x_pos, n_src, n_dst = _cfg3_graph(batch, tokens, side), batch.pos, tokens, N_PTS, m
+    elif side == "decoder_bidirectional":
+        ei, y_pos, x_pos, n_src, n_dst = _cfg3_graph(batch, tokens, side), tokens, batch.pos, m, N_PTS
     else:                      # tokens -> points: degree k everywhere
         ei, y_pos, x_pos, n_src, n_dst = batch.decoder_edge_index_s0, tokens, batch.pos, m, N_PTS
     gen = torch.Generator().manual_seed(77)
@@ -234,7 +256,7 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
     sel = local[dst] >= 0
     sub = torch.stack([src[sel], local[dst[sel]]])
     ref = orc.integral_transform(sd, "", y_c, x_c[qs], sub, f_y)
-    assert int((deg_dst[qs] == 0).sum()) > 0 or side == "decoder"
+    assert int((deg_dst[qs] == 0).sum()) > 0 or side.startswith("decoder")
     if precision == "fp32":
         PAR.close(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 1e-4, 1e-5 * float(ref.abs().max()))
     else:
@@ -272,6 +294,50 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
             else:
                 PAR.cosine(f"{tag}/grad_{nm}{i}", got, r, 0.999)
                 PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 5e-2)
+
+
+@pytest.mark.parametrize("side", ["encoder_knn", "decoder_knn", "encoder_bidirectional"])
+def test_geoembed_statistics_full_size_vs_oracle(sample, side):
+    """Statistical GeoEmbed features at configs[1] size against the oracle's restatement of geoembed.py:99-182 on the WHOLE
+    graph (z-score over all rows included): token rows of the knn encoder graph (Q = 131 072, ~30 points each), the decoder
+    side (Q = N = 500 000 points with 8 tokens each) and the reference yaml's bidirectional encoder graph (token rows with
+    hundreds of points next to empty ones -- where the one-sweep kernel's covariance E[uu^T] - E[u]E[u]^T from fp64 moments
+    would show cancellation if it had any).  Both device forms are checked: the one-sweep moment form the model uses and the
+    two-sweep form of the point-sharded decoder side."""
+    from gaot_3d_amd import ops
+    batch, tokens = sample
+    pos, lat = batch.pos.cpu(), tokens.cpu()
+    if side == "encoder_knn":
+        src, qry, ei = pos, lat, batch.encoder_edge_index_s0.cpu().long()
+    elif side == "decoder_knn":
+        src, qry, ei = lat, pos, batch.decoder_edge_index_s0.cpu().long()
+    else:
+        from gaot_3d_amd.model.layers.magno import get_neighbor_strategy
+        lat_b = torch.zeros(tokens.shape[0], dtype=torch.long, device=DEV)
+        ei = get_neighbor_strategy("bidirectional", batch.pos, batch.batch, tokens, lat_b, 0.033, 1, False,
+                                   latent_dims=(64, 64, 32)).cpu().long()
+        src, qry = pos, lat
+    deg = torch.bincount(ei[1], minlength=qry.shape[0])
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref = orc.geoembed_stat_features(src, qry, ei)                               # the reference's own fp32 arithmetic
+    ref64 = orc.geoembed_stat_features(src.double(), qry.double(), ei).float()     # the same restatement evaluated in fp64
+    g = ops.build_graph(ei.to(DEV), src.shape[0], qry.shape[0])
+    one = ops.geoembed_from_moments(ops.geoembed_moments(src.to(DEV), qry.to(DEV), g))
+    two = ops.geoembed_stats_sharded_queries(src.to(DEV), qry.to(DEV), g, None, qry.shape[0])
+    torch.cuda.synchronize()
+    print(f"[parity] geoembed_full/{side}: {qry.shape[0]} rows, {ei.shape[1]} edges, degree max {int(deg.max())}, "
+          f"empty rows {int((deg == 0).sum())}")
+    heavy = int(deg.argmax())
+    # the reference sums thousands of fp32 terms per row and forms E[d^2] - E[d]^2 in fp32; the kernels accumulate in fp64.
+    # Bar: within 5e-4 of the feature peak of the fp32 oracle, and closer to the fp64 evaluation than the fp32 oracle itself is
+    noise = float((ref - ref64).abs().max())
+    print(f"[parity] geoembed_full/{side}: fp32 oracle vs its fp64 evaluation max_abs={noise:.3e}")
+    for name, got in (("one_sweep", one), ("two_sweep", two)):
+        PAR.close_peak(f"geoembed_full/{side}/{name} vs fp32 oracle", got, ref, 5e-4)
+        PAR.close_peak(f"geoembed_full/{side}/{name} vs fp64 oracle", got, ref64, 5e-5)
+        assert float((got.cpu() - ref64).abs().max()) <= noise + 1e-4
+        PAR.close_peak(f"geoembed_full/{side}/{name}/heaviest_row", got[heavy], ref64[heavy], 5e-5)
+    PAR.close(f"geoembed_full/{side}/one_vs_two_sweep", one, two, 1e-4, 1e-4)
 
 
 def _fullsize_oracle_skip_reason():

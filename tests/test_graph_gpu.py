@@ -1,6 +1,6 @@
-"""Device graph construction (csrc/graph.hip, gaot_3d_amd/graph.py) against the brute-force restatement of the
-reference's get_neighbor_strategy (gaot_3d_amd/data.py helpers + model/layers/magno.get_neighbor_strategy, themselves
-the construction used for the golden model cases): identical edge lists, integer-exact."""
+"""Device graph construction (csrc/graph.hip, gaot_3d_amd/graph.py) against the oracle's independent brute-force restatement
+of the reference's get_neighbor_strategy (oracle/graph_oracle.py; the product's own host helper in gaot_3d_amd/data.py is
+checked against the same oracle on the CPU, tests/test_host_cpu.py): identical edge lists, integer-exact."""
 import os
 import sys
 
@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import gaot_oracle as orc  # noqa: E402  (checker only)
+import graph_oracle as gorc  # noqa: E402  (checker only)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -60,10 +61,9 @@ def _as_set(e):
 def test_radius_matches_bruteforce(dims, radius, centers):
     """both orientations, the 32-per-centre cap included (radius 0.45 / 1.2 overflow it)"""
     from gaot_3d_amd import graph
-    from gaot_3d_amd.data import radius_edges_bruteforce
     lat = _grid(dims)
     pos = _points(1500, seed=int(radius * 100), lo=-1.0, hi=1.0)
-    ref = radius_edges_bruteforce(pos, lat, radius, 32, centers=centers)
+    ref = (gorc.encoder_edges if centers == "latent" else gorc.decoder_edges)("radius", pos, lat, radius, 1)
     g = graph.as_latent_grid(lat.to(DEV), dims)
     strat = graph._encoder_edges if centers == "latent" else graph._decoder_edges
     got = strat("radius", pos.to(DEV), g, radius, 1).cpu().long()
@@ -78,7 +78,7 @@ def test_get_neighbor_strategy_matches_host(strategy, is_decoder):
     """the reference function's conventions (orientation, coalesce, reverse = flip of the bidirectional encoder graph),
     two graphs in the batch"""
     from gaot_3d_amd import graph
-    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy as host_strategy
+    host_strategy = gorc.get_neighbor_strategy
     dims = (6, 5, 4)
     lat1 = _grid(dims)
     lat = lat1.repeat(2, 1)

@@ -2,6 +2,7 @@
 the drop-in model has the reference's state_dict layout, the host-side data helpers follow the reference's
 conventions, and the product refuses to run without the GPU path."""
 import glob
+import sys
 import os
 import re
 import types
@@ -337,3 +338,28 @@ def test_dataset_transforms_stats_and_loader(tmp_path):
     shuffled.set_epoch(1)
     c = [bb.pos.shape[0] for bb in shuffled]
     assert sorted(a) == sorted(c) == [40, 45, 50, 55] and a != c
+
+
+@pytest.mark.parametrize("strategy,is_decoder", [("knn", False), ("radius", False), ("bidirectional", False), ("knn", True),
+                                                 ("radius", True), ("bidirectional", True), ("reverse", True)])
+def test_host_graph_helper_matches_graph_oracle(strategy, is_decoder):
+    """the product's CPU graph helper (data preparation on the host: gaot_3d_amd/data.py + magno.get_neighbor_strategy for CPU
+    tensors) against the oracle's independent restatement of the reference conventions (oracle/graph_oracle.py): two graphs
+    per batch, 32-per-centre cap reached"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import graph_oracle as gorc
+    from gaot_3d_amd.data import latent_grid
+    from gaot_3d_amd.model.layers.magno import get_neighbor_strategy
+    g = torch.Generator().manual_seed(5)
+    lat1 = latent_grid((5, 4, 3))
+    lat = lat1.repeat(2, 1)
+    pos = torch.rand(900, 3, generator=g) * 2 - 1
+    bp = torch.cat([torch.zeros(500, dtype=torch.long), torch.ones(400, dtype=torch.long)])
+    bl = torch.arange(2).repeat_interleave(lat1.shape[0])
+    got = get_neighbor_strategy(strategy, pos, bp, lat, bl, 0.5, 3, is_decoder)
+    ref = gorc.get_neighbor_strategy(strategy, pos, bp, lat, bl, 0.5, 3, is_decoder)
+    assert got.shape == ref.shape
+    if strategy == "knn":
+        assert set(map(tuple, got.t().tolist())) == set(map(tuple, ref.t().tolist()))
+    else:
+        assert torch.equal(got.long(), ref)
