@@ -267,6 +267,31 @@ def test_gemm_bf16_in_memory(m, n, k, at, bt, a16, b16, c16):
     assert err <= tol
 
 
+@pytest.mark.parametrize("m", [1, 63, 65, 16384 - 27])
+def test_gemm_k256_ragged_rows_at_allocation_end(m):
+    """k_gemm_k256 with M % 64 != 0 on an A matrix that ends exactly where its allocation ends: the last row block's rows
+    past M must come back as zeros from the buffer range check (the row offset sits in voffset; an soffset is not range
+    checked and used to read up to 32 KB past A) -- results equal the reference, rows past M are never read"""
+    from gaot_3d_amd import ops
+    k, n = 256, 768
+    blk = 2 << 20                                                    # the allocator hands out 2 MiB-granular large blocks
+    nbytes = ((m * k * 2 + blk - 1) // blk) * blk
+    torch.cuda.empty_cache()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    a = buf[nbytes - m * k * 2:].view(torch.bfloat16).view(m, k)      # ends at the last byte of the block
+    av = gen(m, k, seed=m).bfloat16()
+    a.copy_(av.to(DEV))
+    w = gen(n, k, seed=m + 1).bfloat16()
+    out = ops.gemm(a, w.to(DEV), m, n, k, k, k, False, True, precision=1)
+    outb = ops.gemm(a, w.to(DEV), m, n, k, k, k, False, True, precision=1, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    ref = av.double() @ w.double().t()
+    err = float((out.double().cpu() - ref).abs().max())
+    print(f"[parity] gemm_k256_ragged m={m}: max_abs={err:.3e}")
+    assert err <= 1e-5 * float(ref.abs().max()) + 1e-6
+    assert float((outb.double().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+
+
 def test_cast_bf16_transpose_multi():
     """fp32 [r, c] -> bf16 [c, r] for several matrices in one launch: bit-exact against torch's own rounding"""
     from gaot_3d_amd import ops
