@@ -26,7 +26,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // what the epilogue writes: fp32 C, bf16 C, or the attention kernels' bf16 image of a fused q|k|v projection (RoPE applied to
 // the q and k heads from a [S][16] (cos, sin) table, q pre-scaled): the fp32 projection then never exists in HBM
-enum { OUT_F32 = 0, OUT_BF16 = 1, OUT_QKV_IMAGE = 2 };
+enum { OUT_F32 = 0, OUT_BF16 = 1, OUT_QKV_IMAGE = 2, OUT_SWIGLU = 3 };
 struct ImageArgs {
     const float* table;   // [S][16][2] = (cos, sin) of position * frequency, or null (no RoPE)
     int S, nq, nk;        // rows per sequence, number of q heads, of k heads (32 columns each; the rest are v heads)
@@ -34,26 +34,31 @@ struct ImageArgs {
     // pack_g > 1 (sequence-parallel exchange, gaot_qkv_image_packed): the image is written as pack_g blocks [M][lw], block j =
     // q | k | v of rank j's heads (lw = (nq + 2 nk) / pack_g * 32) -- the send buffer of the all-to-all, no repacking pass
     int pack_g;
+    // OUT_SWIGLU (gaot_ffn_w13_swiglu): W = [w1; w3] ([2F][256]); a wave's two 32-column tiles are columns n .. n+31 of w1 x and the
+    // SAME columns of w3 x, so the epilogue writes a | g (bf16 [M][2F], kept for the backward) and u = silu(a) g (bf16 [M][F])
+    void* u;
+    int F;
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, void* __restrict__ C,
                                                        int M, int N, int lda, int ldw, int ldc, int P, int subs, ImageArgs im) {
-    constexpr bool C16 = MODE != OUT_F32;
+    constexpr bool C16 = MODE != OUT_F32;   // OUT_SWIGLU: a | g are written as bf16 like OUT_BF16
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3, panel = j % P, sub = j / P;
     const int nblk = (M + RB - 1) / RB, c = xcd * subs + sub, nch = 8 * subs;
     const int t0 = (int)((int64_t)c * nblk / nch), t1 = (int)((int64_t)(c + 1) * nblk / nch);
     if (t0 >= t1) return;                                    // uniform over the workgroup
-    const int n0 = panel * 256 + wave * 64;
-    const bool wave_ok = n0 < N;                             // N % 64 == 0: a wave's 64 columns are all inside or all outside
+    // OUT_SWIGLU: a panel is 128 columns of a and the same 128 columns of g (tile 0 / tile 1 of a wave: columns n0 .. n0+31 of each)
+    const int n0 = MODE == OUT_SWIGLU ? panel * 128 + wave * 32 : panel * 256 + wave * 64;
+    const bool wave_ok = MODE == OUT_SWIGLU ? n0 < im.F : n0 < N;   // N % 64 == 0 (F % 32 == 0): all inside or all outside
 
     // the wave's weight slice as MFMA fragments: element (n = l31, k = 16 s + 8 hf + 0..7) of column tile jt
     bf16x8 bw[2][16];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-        int n = n0 + 32 * jt + l31;
+        int n = (MODE == OUT_SWIGLU ? n0 + jt * im.F : n0 + 32 * jt) + l31;
         n = n < N ? n : N - 1;
         const bf16_t* p = W + (int64_t)n * ldw + 8 * hf;
 #pragma unroll
@@ -63,6 +68,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
     const int64_t abytes = (int64_t)M * lda * 2, cbytes = (int64_t)M * ldc * (C16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(abytes > 0x7fffffff ? 0x7fffffff : abytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(cbytes > 0x7fffffff ? 0x7fffffff : cbytes), 0x00020000);
+    const int64_t ubytes = MODE == OUT_SWIGLU ? (int64_t)M * im.F * 2 : 0;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(MODE == OUT_SWIGLU ? im.u : C, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
     auto stage = [&](int t, int buf) {
         const int lh = lane >> 5;
 #pragma unroll
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
             unsigned rowoff = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * (C16 ? 2u : 4u) : 0x80000000u;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                int ncol = n0 + 32 * jt;        // first output column of this 32-wide tile
+                int ncol = MODE == OUT_SWIGLU ? n0 + jt * im.F : n0 + 32 * jt;        // first output column of this 32-wide tile
                 if constexpr (MODE == OUT_QKV_IMAGE) {
                     if (im.pack_g > 1) {        // uniform: destination = block of the rank that owns this head
                         const int head = ncol >> 5, hl = im.nq / im.pack_g, kl = im.nk / im.pack_g, lw = (hl + 2 * kl) * 32;
@@ -172,6 +179,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                     }
                 }
             }
+            if constexpr (MODE == OUT_SWIGLU) {
+                // u = silu(a) g from the ROUNDED a and g (what the stand-alone pass computes from the stored bf16 a | g)
+                auto rb = [](float v) { return __uint_as_float((unsigned)__builtin_bit_cast(bf16_t, (__bf16)v) << 16); };
+                unsigned pu[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float av = rb(acc[0][i][4 * q + e]), gv = rb(acc[1][i][4 * q + e]);
+                        o[e] = av * (1.0f / (1.0f + __expf(-av))) * gv;
+                    }
+                    pu[q][0] = pack2(o[0], o[1]);
+                    pu[q][1] = pack2(o[2], o[3]);
+                }
+                const unsigned urow = (m < M && wave_ok) ? (unsigned)m * (unsigned)im.F * 2u : 0x80000000u;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pu[q][0], pu[q + 2][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pu[q][1], pu[q + 2][1], false, false);
+                    const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, urs, urow + (n0 + 8 * q + 16 * hf) * 2, 0, 0);
+                }
+            }
         }
     }
 }
@@ -188,7 +219,7 @@ int launch_k256(const void* A, const void* W, void* C, int M, int N, int lda, in
         }
         attr_set = true;
     }
-    const int P = (N + 255) / 256, nblk = (M + RB - 1) / RB;
+    const int P = MODE == OUT_SWIGLU ? (im.F + 127) / 128 : (N + 255) / 256, nblk = (M + RB - 1) / RB;
     // ~512 workgroups (two per CU), but never more row chunks than row blocks
     int subs = std::max(1, 64 / P);
     subs = std::max(1, std::min(subs, (nblk + 7) / 8));
@@ -220,7 +251,7 @@ bool gaot_gemm_k256_applicable(const void* A, const void* W, const void* C, int6
 
 int gaot_gemm_k256_launch(const void* A, const void* W, void* C, int64_t M, int64_t N, int64_t lda, int64_t ldw, int64_t ldc,
                           int c16, hipStream_t st) {
-    const ImageArgs none{nullptr, 1, 0, 0, 1.0f, 1};
+    const ImageArgs none{nullptr, 1, 0, 0, 1.0f, 1, nullptr, 0};
     if (c16) return launch_k256<OUT_BF16>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
     return launch_k256<OUT_F32>(A, W, C, (int)M, (int)N, (int)lda, (int)ldw, (int)ldc, none, st);
 }
@@ -248,7 +279,7 @@ extern "C" int gaot_qkv_image(const void* x_bf16, const void* w_bf16, void* imag
         gaot_set_error("gaot_qkv_image: needs d_model = 256, 16-byte aligned bf16 rows and a heads * 32 that is a multiple of 64");
         return GAOT_ERR_UNSUPPORTED;
     }
-    const ImageArgs im{rope_table, S, H, HKV, qscale, 1};
+    const ImageArgs im{rope_table, S, H, HKV, qscale, 1, nullptr, 0};
     return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, image, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
 }
 
@@ -268,8 +299,24 @@ extern "C" int gaot_qkv_image_packed(const void* x_bf16, const void* w_bf16, voi
         return GAOT_ERR_UNSUPPORTED;
     }
     // positions are pos0 + local row: the table pointer is advanced, S only has to exceed the local row count
-    const ImageArgs im{rope_table ? rope_table + pos0 * 32 : nullptr, (int)rows, H, HKV, qscale, world};
+    const ImageArgs im{rope_table ? rope_table + pos0 * 32 : nullptr, (int)rows, H, HKV, qscale, world, nullptr, 0};
     return launch_k256<OUT_QKV_IMAGE>(x_bf16, w_bf16, packed, (int)rows, (int)N, (int)lda, (int)ldw, (int)N, im, (hipStream_t)stream);
+}
+
+// The first half of the SwiGLU FFN in one launch (reference attn.py:155-156: silu(w1 x) * w3 x): x [rows][256] bf16, w13 = the
+// co-located [w1; w3] ([2F][256] bf16); writes ag = w1 x | w3 x (bf16 [rows][2F], kept for the backward) and u = silu(a) g
+// (bf16 [rows][F]) -- stands in for gaot_gemm_ex + gaot_swiglu_fwd_bf16 (one read of the 64 MB a | g tensor less per layer).
+extern "C" int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, void* ag, void* u, int64_t rows, int64_t lda, int64_t ldw,
+                                   int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(x_bf16 && w13_bf16 && ag && u && rows > 0 && F > 0, "bad argument");
+    if (F % 32 != 0 || !gaot_gemm_k256_applicable(x_bf16, w13_bf16, ag, rows, 2 * (int64_t)F, KK, lda, ldw, 2 * (int64_t)F, 1) ||
+        ((uintptr_t)u % 16) != 0 || rows * (int64_t)F * 2 >= 0x7fffffff) {
+        gaot_set_error("gaot_ffn_w13_swiglu: needs d_model = 256, F a multiple of 32 and 16-byte aligned bf16 buffers");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const ImageArgs im{nullptr, 1, 0, 0, 1.0f, 1, u, F};
+    return launch_k256<OUT_SWIGLU>(x_bf16, w13_bf16, ag, (int)rows, 2 * F, (int)lda, (int)ldw, 2 * F, im, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

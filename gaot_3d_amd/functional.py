@@ -492,8 +492,11 @@ class FFNFn(Function):
         wcat_t, w2t = _wbt(wcat32), _wbt(_w2d(w2))   # bf16 transposes from the per-forward cast pass, or None
         xb = bf16_copy_of(x, (m, d))
         xa = xb if xb is not None else x2          # bf16 image written by the producing RMSNorm
-        ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
-        u = ops.swiglu_fwd_bf16(ag, f)
+        if xa.dtype == torch.bfloat16 and wcat.dtype == torch.bfloat16 and d == 256 and f % 32 == 0:
+            ag, u = ops.ffn_w13_swiglu(xa, wcat, f)     # projection + SwiGLU in one launch (csrc/gemm_k256.hip, OUT_SWIGLU)
+        else:
+            ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+            u = ops.swiglu_fwd_bf16(ag, f)
         res = None
         if res_is_x:
             res = x2

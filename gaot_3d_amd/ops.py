@@ -593,6 +593,21 @@ def swiglu_fwd_bf16(ag: Tensor, f: int) -> Tensor:
     return u
 
 
+def ffn_w13_swiglu(xb: Tensor, w13b: Tensor, f: int):
+    """x [rows, 256] bf16 times the co-located [w1; w3] bf16 weights -> (a | g bf16 [rows, 2F], silu(a) g bf16 [rows, F]) in one
+    launch (include/gaot3d_hip.h: gaot_ffn_w13_swiglu)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or w13b.dtype != torch.bfloat16 or not (xb.is_contiguous() and w13b.is_contiguous()):
+        raise GaotError("ffn_w13_swiglu: contiguous bf16 operands expected")
+    rows = xb.shape[0]
+    ag = torch.empty(rows, 2 * f, dtype=torch.bfloat16, device=xb.device)
+    u = torch.empty(rows, f, dtype=torch.bfloat16, device=xb.device)
+    with _timed("ffn_w13_swiglu"):
+        check(lib.gaot_ffn_w13_swiglu(_ptr(xb), _ptr(w13b), _ptr(ag), _ptr(u), rows, xb.shape[1], w13b.shape[1], int(f), _stream()),
+              "gaot_ffn_w13_swiglu")
+    return ag, u
+
+
 def swiglu_bwd_bf16(ag: Tensor, du: Tensor, f: int) -> Tensor:
     lib = _lib.load()
     dag = torch.empty_like(ag)

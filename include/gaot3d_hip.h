@@ -253,6 +253,11 @@ int gaot_cast_bf16_transpose_multi(const gaot_cast_tensor_t* tensors, const int*
                                    gaot_stream_t stream);
 /* the same with every buffer bf16 in memory (fp32 arithmetic); F % 8 == 0, 16-byte aligned buffers */
 int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stream_t stream);
+/* the first half of the SwiGLU FFN in ONE launch (reference attn.py:155-156: silu(w1 x) * w3 x): x [rows][256] bf16, w13 = the
+ * co-located [w1; w3] weights ([2F][256] bf16) -> ag = w1 x | w3 x (bf16 [rows][2F], kept for the backward) and u = silu(a) g
+ * (bf16 [rows][F]); same values as gaot_gemm_ex (bf16 result) followed by gaot_swiglu_fwd_bf16 */
+int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, void* ag, void* u, int64_t rows, int64_t lda, int64_t ldw, int F,
+                        gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
 int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream);
 int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period, gaot_stream_t stream);

@@ -316,6 +316,26 @@ def test_gemm_tn_n256_with_residual():
     assert err <= 1e-5 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("rows,f", [(1, 64), (300, 1024), (4097, 160), (16384, 1024)])
+def test_ffn_w13_swiglu_fused_equals_two_launches(rows, f):
+    """gaot_ffn_w13_swiglu (projection + SwiGLU in the K = 256 GEMM's epilogue) against gaot_gemm_ex (bf16 result) followed by
+    gaot_swiglu_fwd_bf16: a | g bit-identical, u within one bf16 ulp (the sigmoid is evaluated in the same arithmetic)"""
+    from gaot_3d_amd import ops
+    x = gen(rows, 256, seed=rows).bfloat16().to(DEV)
+    w = (gen(2 * f, 256, seed=f) * 0.2).bfloat16().to(DEV)
+    ag, u = ops.ffn_w13_swiglu(x, w, f)
+    ag2 = ops.gemm(x, w, rows, 2 * f, 256, 256, 256, False, True, precision=1, out_dtype=torch.bfloat16)
+    u2 = ops.swiglu_fwd_bf16(ag2, f)
+    torch.cuda.synchronize()
+    assert torch.equal(ag, ag2)
+    err = float((u.float() - u2.float()).abs().max())
+    print(f"[parity] ffn_w13_swiglu rows={rows} f={f}: u max_abs={err:.3e} peak={float(u2.float().abs().max()):.3e}")
+    assert err <= 2.0 ** -7 * float(u2.float().abs().max()) + 1e-6
+    a64, g64 = ag2.double()[:, :f], ag2.double()[:, f:]
+    ref = a64 * torch.sigmoid(a64) * g64
+    assert float((u.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+
+
 def test_gemm_bf16_in_memory_rejects_unsupported():
     from gaot_3d_amd import ops
     from gaot_3d_amd._lib import GaotError
