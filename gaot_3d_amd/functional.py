@@ -3,7 +3,6 @@ kernels through the C ABI (gaot_3d_amd.ops).  PyTorch only owns the device buffe
 Functions.  Nothing here falls back to ATen math or to the CPU."""
 from __future__ import annotations
 
-import os
 
 from typing import List, Optional
 
@@ -519,7 +518,7 @@ class FFNFn(Function):
         dy2 = dy.reshape(m, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        if _DY_BF16 and d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:
+        if d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:
             # dy W2 as x W^T with both operands bf16 in memory and K = 256 -> the weights-in-registers kernel
             # (csrc/gemm_k256.hip: 41 -> 18 us at configs[1]) for one rounding pass over dy and a 0.5 MB weight transpose;
             # the weight-gradient GEMM reads the same bf16 rows (half the A traffic)
@@ -533,7 +532,7 @@ class FFNFn(Function):
         dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _DY_BF16 and d == 256 and wcat.dtype == torch.bfloat16 and (2 * f) % 64 == 0 and 2 * f >= 512:
+            if d == 256 and wcat.dtype == torch.bfloat16 and (2 * f) % 64 == 0 and 2 * f >= 512:
                 # dag W13 as x W^T on the transposed bf16 weight [d, 2f]: both operands k-contiguous -> the streamed-weight
                 # kernel (csrc/gemm_k256.hip: k_gemm_tn_n256) instead of the generic tile kernel with transposed reads
                 dx = ops.gemm(dag, wcat_t if wcat_t.numel() else wcat.t().contiguous(), m, d, 2 * f, 2 * f, 2 * f, False, True,
@@ -694,7 +693,7 @@ class MultiLinearFn(Function):
             wcat = _wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), precision)
             xb = bf16_copy_of(x, (m, k)) if wcat.dtype == torch.bfloat16 else None
             xa = xb if xb is not None else x2      # bf16 image written by the producing RMSNorm: half the A traffic
-            if image_spec is not None and xb is not None and k == 256 and ntot % 64 == 0 and _QKV_IMAGE_FUSION:
+            if image_spec is not None and xb is not None and k == 256 and ntot % 64 == 0:
                 freqs, b, s, h, hkv, scale = image_spec
                 img = ops.qkv_image(xb, wcat, m, b, s, h, hkv, freqs, scale)
                 out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only: no [m, ntot] buffer
@@ -744,11 +743,6 @@ class MultiLinearFn(Function):
                        if ctx.needs_input_grad[3 + i] else None)
             col += n
         return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)
-
-
-# A/B switches (tools/microbench.py, tests): the projection-as-image path; bf16 copies of the RMSNorm input gradients
-_QKV_IMAGE_FUSION = os.environ.get("GAOT_QKV_IMAGE", "1") != "0"
-_DY_BF16 = os.environ.get("GAOT_DY_BF16", "1") != "0"
 
 
 def multi_linear(x: Tensor, weights, precision: Optional[int] = None, image_spec=None) -> Tensor:
