@@ -750,7 +750,7 @@ extern "C" size_t gaot_gno_bwd_workspace_bytes(const gaot_mlp_t* mlp, int64_t nu
     if (!mlp) return 0;
     const int total = param_total(mlp->n_hidden, mlp->hidden);
     const int grid = bwd_grid(num_edges);
-    size_t fl = (size_t)(ceil_div(num_edges, 32) * 2 * 32)  // segment partials
+    size_t fl = (size_t)(ceil_div(num_edges, 16) * 2 * 32)  // segment partials (16-edge tiles in bf16 mode, 32 in fp32)
                 + (size_t)total                             // transposed weights (<= total)
                 + (size_t)total                             // reduced flat gradient
                 + (size_t)grid * total                      // per-block partials
@@ -774,6 +774,9 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     // the bf16 kernel gathers its 128-byte rows through 2 GB buffer resources: 2^24 rows per table
     GAOT_CHECK_ARG(precision != 1 || (num_sources <= (1 << 24) && num_queries <= (1 << 24)),
                    "bf16 GNO backward: more than 2^24 source or query rows (run the mesh point-sharded or in fp32 mode)");
+    // ... and addresses the two 128-byte partial slots of a 16-edge tile with a 32-bit byte offset
+    GAOT_CHECK_ARG(precision != 1 || num_edges < ((int64_t)1 << 27),
+                   "bf16 GNO backward: 2^27 or more edges in one launch (run the mesh point-sharded or in fp32 mode)");
     GAOT_CHECK_ARG(workspace_bytes >= gaot_gno_bwd_workspace_bytes(mlp, num_edges, num_queries), "workspace too small");
     GAOT_CHECK_ARG(rowptr_src && rowptr_dst, "null rowptr");
     hipStream_t st = (hipStream_t)stream;
@@ -782,7 +785,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     const int grid = bwd_grid(num_edges);
     const int n_waves = grid;  // one partial per workgroup
     float* part = (float*)workspace;
-    float* wt = part + ceil_div(num_edges, 32) * 2 * 32;
+    float* wt = part + ceil_div(num_edges, 16) * 2 * 32;
     float* flat = wt + total;
     float* wpart = flat + total;
     float* gs = wpart + (size_t)grid * total;
@@ -843,8 +846,12 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     GAOT_KLAUNCH(k_scatter_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, flat, sd);
     if (num_sources > 0) {
         const int64_t n = num_sources * 32;
-        GAOT_KLAUNCH((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
-                           num_sources, part, grad_f_y, 0);
+        if (precision == 1)
+            GAOT_KLAUNCH((k_segment_fixup<32, 4>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
+                               num_sources, part, grad_f_y, 0);
+        else
+            GAOT_KLAUNCH((k_segment_fixup<32, 5>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
+                               num_sources, part, grad_f_y, 0);
     }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
             for (int t = 0; t < T; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const f32v2 y = gelu_fast2(f32v2{z[t][r], z[t][r + 1]});
+                    const f32v2 y = gelu_e2_2(f32v2{z[t][r], z[t][r + 1]});
                     z[t][r] = y[0]; z[t][r + 1] = y[1];
                 }
                 to_frags(z[t], hb[t][ob][0], hb[t][ob][1]);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
                 for (int ob = 0; ob < KB; ++ob) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        const f32v2 y = gelu_fast2(f32v2{z[t][ob][r], z[t][ob][r + 1]});
+                        const f32v2 y = gelu_e2_2(f32v2{z[t][ob][r], z[t][ob][r + 1]});
                         z[t][ob][r] = y[0]; z[t][ob][r + 1] = y[1];
                     }
                     to_frags(z[t][ob], hb[t][ob][0], hb[t][ob][1]);
@@ -253,49 +253,15 @@ int gaot_gno_fwd_bf16_dispatch(int n_hidden, const float* const* w, const float*
 }
 
 // =================================================================================================
-// Backward (bf16 matrix cores): operand images for k_gno_bwd2_bf16 (gno_bwd2_bf16.hip)
+// Backward (bf16 matrix cores): k_gno_bwd3_bf16 (gno_bwd3_bf16.hip)
 // =================================================================================================
-// The MLP weights are pre-arranged once per launch as per-lane bf16 MFMA fragments (recompute form and transposed
-// data-gradient form); the backward kernel keeps them resident in LDS.
-namespace {
-// fragment images: see the operand maps in the kernel
-__global__ void k_prep_bwd_images(MlpPtrs mlp, int nh, bf16_t* base) {
-    constexpr int H = 64, KB = 2;
-    const int per_hidden = KB * KB * 2 * 64 * 8, per_last = KB * 2 * 64 * 8;
-    const int total = (nh - 1) * 2 * per_hidden + 2 * per_last;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        int o = i;
-        float v;
-        if (o < (nh - 1) * per_hidden) {                       // fw[l], l = 1..nh-1
-            const int l = 1 + o / per_hidden; o %= per_hidden;
-            const int j = o & 7, ln = (o >> 3) & 63, fr = o >> 9, s = fr & 1, kb = (fr >> 1) % KB, ob = (fr >> 1) / KB;
-            v = mlp.w[l][(32 * ob + (ln & 31)) * H + 32 * kb + kmap(s, j, ln >> 5)];
-        } else if ((o -= (nh - 1) * per_hidden) < per_last) {  // fw[nh]: B operand of the transposed last layer
-            const int j = o & 7, ln = (o >> 3) & 63, fr = o >> 9, s = fr & 1, kb = fr >> 1;
-            v = mlp.w[nh][(ln & 31) * H + 32 * kb + kmap(s, j, ln >> 5)];
-        } else if ((o -= per_last) < (nh - 1) * per_hidden) {  // bw[l]: A = W_l^T, rows k, elements j
-            const int l = 1 + o / per_hidden; o %= per_hidden;
-            const int j = o & 7, ln = (o >> 3) & 63, fr = o >> 9, s = fr & 1, jb = (fr >> 1) % KB, kb = (fr >> 1) / KB;
-            v = mlp.w[l][(32 * jb + kmap(s, j, ln >> 5)) * H + 32 * kb + (ln & 31)];
-        } else {                                               // bw[nh]: A = W_L^T, rows k, elements c
-            o -= (nh - 1) * per_hidden;
-            const int j = o & 7, ln = (o >> 3) & 63, fr = o >> 9, s = fr & 1, kb = fr >> 1;
-            v = mlp.w[nh][kmap(s, j, ln >> 5) * H + 32 * kb + (ln & 31)];
-        }
-        base[i] = (bf16_t)f2bf(v);
-    }
-}
-
-int bwd_img_elems(int nh) { return (nh - 1) * 2 * (2 * 2 * 2 * 64 * 8) + 2 * (2 * 2 * 64 * 8); }
-
-}  // namespace
-
-int gaot_gno_bwd2_bf16_launch(int n_hidden, const void* images, const float* w0t, const float* const* w, const float* const* b,
+int gaot_gno_bwd3_bf16_launch(int n_hidden, void* images, const float* w0t, const float* const* w, const float* const* b,
                               const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
                               const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
                               int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st);
 
-size_t gaot_gno_bwd_bf16_image_bytes(int n_hidden) { return sizeof(bf16_t) * (size_t)bwd_img_elems(n_hidden) + 256; }
+// recompute and transposed data-gradient fragment images of the hidden layers (8 KB each) and of the last layer (4 KB each)
+size_t gaot_gno_bwd_bf16_image_bytes(int n_hidden) { return (size_t)(n_hidden - 1) * 2 * 8192 + 2 * 4096 + 256; }
 
 // called from gaot_gno_bwd (gno.hip) for precision == 1.  `images` = scratch of gaot_gno_bwd_bf16_image_bytes();
 // w0t = fp32 [6][64] transposed first-layer weight (prepared by the caller, shared with the fp32 path).
@@ -303,13 +269,6 @@ int gaot_gno_bwd_bf16_dispatch(int n_hidden, const float* const* w, const float*
                                void* images, const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
                                const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
                                int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st) {
-    MlpPtrs p;
-    for (int l = 0; l <= n_hidden; ++l) { p.w[l] = w[l]; p.b[l] = b[l]; }
-    bf16_t* base = (bf16_t*)images;
-    GAOT_KLAUNCH(k_prep_bwd_images, dim3(32), dim3(256), 0, st, p, n_hidden, base);
-    if (n_hidden >= 1 && n_hidden <= 3)
-        return gaot_gno_bwd2_bf16_launch(n_hidden, images, w0t, w, b, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src,
-                                         num_edges, grad_f, part, wpart, grid, st);
-    gaot_set_error("gaot_gno_bwd (bf16): unsupported n_hidden %d", n_hidden);
-    return GAOT_ERR_UNSUPPORTED;
+    return gaot_gno_bwd3_bf16_launch(n_hidden, images, w0t, w, b, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src,
+                                     num_edges, grad_f, part, wpart, grid, st);
 }

@@ -58,8 +58,9 @@ __device__ __forceinline__ void segment_walk(const float* stage, int ld, const i
     flush(cur, sum);
 }
 
-// rows with no edges -> 0; rows spanning several tiles -> ordered sum of the tile partials
-template <int C>
+// rows with no edges -> 0; rows spanning several tiles -> ordered sum of the tile partials (tiles of 2^SHIFT edges: 32
+// for the forward and the fp32 backward, 16 for the bf16 backward, whose waves own 16-edge tiles)
+template <int C, int SHIFT = 5>
 __global__ void k_segment_fixup(const int* __restrict__ rowptr, int64_t Q, const float* __restrict__ part,
                                 float* __restrict__ out, int mean) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,7 +72,7 @@ __global__ void k_segment_fixup(const int* __restrict__ rowptr, int64_t Q, const
         out[i] = 0.f;
         return;
     }
-    const int t0 = rb >> 5, t1 = (re - 1) >> 5;
+    const int t0 = rb >> SHIFT, t1 = (re - 1) >> SHIFT;
     if (t0 == t1) return;
     float s = part[((int64_t)t0 * 2 + 1) * C + c];
     for (int t = t0 + 1; t <= t1; ++t) s += part[((int64_t)t * 2 + 0) * C + c];

@@ -9,7 +9,7 @@
 // tiles (tile32.h).  Two accumulator orientations are used, each the B operand of what follows it:
 //   P: z[j][n] (hidden on registers, row on lanes)  -> out[c][n] and d_x^T[k][n]  (contract over hidden)
 //   Q: z^T[n][j] (row on registers, hidden on lanes) -> d_W1^T[k][j], d_W2, d_b1    (contract over rows)
-// The backward evaluates both (the K = 32 product is cheap); GELU / GELU' share one exp (gelu_fast_pair).
+// The backward evaluates both (the K = 32 product is cheap); GELU / GELU' share one exp (gelu_e2_pair, common.h).
 #include "common.h"
 #include "tile32.h"
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp2_fwd(Mlp2Args a, float* __restri
                 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][1], frag_rows(xt + t * TILE_BYTES, l31, hf, 1), z, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float y = gelu_fast(z[r]);
+                    const float y = gelu_e2(z[r]);
 #pragma unroll
                     for (int c = 0; c < OC; ++c) po[c] = fmaf(y, w2s[c * H + 32 * ob + mfma32_row(r, hf)], po[c]);
                 }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float y, gd;
-                    gelu_fast_pair(zq[r], y, gd);
+                    gelu_e2_pair(zq[r], y, gd);
                     const int n = 32 * t + mfma32_row(r, hf);
                     float dy = 0.f;
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float y, gd;
-                    gelu_fast_pair(zp[r], y, gd);
+                    gelu_e2_pair(zp[r], y, gd);
                     const int j = 32 * ob + mfma32_row(r, hf);
                     float dy = 0.f;
 #pragma unroll
