@@ -329,6 +329,11 @@ def _run_shard_workers(tmp_path, world, port, **env_extra):
     env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", **{k: str(v) for k, v in env_extra.items()})
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:   # keep the workers' own messages (the launcher's summary fills the tail of stderr)
+        dump = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(dump):
+            with open(os.path.join(dump, "shard_worker_stderr.txt"), "w") as f:
+                f.write(r.stderr)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.load(open(out))
 

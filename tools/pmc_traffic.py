@@ -7,8 +7,8 @@ import collections, csv, glob, json, sys
 
 NAMES = [("k_attn_fwd_bf16", "attn_fwd"), ("k_attn_bwd_dkv_kb", "attn_bwd_dkv"), ("k_attn_bwd_dkv_bf16", "attn_bwd_dkv"), ("k_attn_bwd_dq_kb", "attn_bwd_dq"), ("k_attn_bwd_dq_bf16", "attn_bwd_dq"),
          ("k_attn_fwd_f32", "attn_fwd"), ("k_attn_bwd_dkv_f32", "attn_bwd_dkv"), ("k_attn_bwd_dq_f32", "attn_bwd_dq"),
-         ("k_gno_fwd_bf16<3", "gno_fwd_nh3"), ("k_gno_fwd_bf16<2", "gno_fwd_nh2"), ("k_gno_bwd2_bf16<3", "gno_bwd_nh3"),
-         ("k_gno_bwd2_bf16<2", "gno_bwd_nh2"), ("k_attn_bwd_fused", "attn_bwd"),
+         ("k_gno_fwd_bf16<3", "gno_fwd_nh3"), ("k_gno_fwd_bf16<2", "gno_fwd_nh2"), ("k_gno_bwd3_bf16<3", "gno_bwd_nh3"),
+         ("k_gno_bwd3_bf16<2", "gno_bwd_nh2"), ("k_attn_bwd_fused", "attn_bwd"),
          ("k_gno_fwd<3", "gno_fwd_nh3"), ("k_gno_fwd<2", "gno_fwd_nh2"), ("k_gno_bwd<3", "gno_bwd_nh3"),
          ("k_gno_bwd<2", "gno_bwd_nh2")]
 
