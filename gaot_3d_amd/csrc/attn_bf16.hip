@@ -169,7 +169,44 @@ struct FwdArgs {
     // part p writes its own normalised O / lse at o + p*o_part, lse + p*lse_part (combined by k_attn_combine)
     int chunk;
     int64_t o_part, lse_part;
+    const float* kmax2;  // [B][KN_BLOCKS][HKV] partial maxima over the keys of |k|^2 (k_key_norm_max): bound of the scores
+    int* redo;           // one flag per workgroup of the grid, written by the bound-based kernel: 1 = rows exceed the bound
 };
+
+// max_s |k_s|^2 per (batch, kv head) of the bf16 image, as KN_BLOCKS partial maxima per batch element (the forward kernel
+// takes their maximum): out[b][block][hkv].  Non-negative floats order like their bit patterns, so the workgroup's maximum
+// is an integer LDS max -- order independent, bit-reproducible; no global atomics, nothing to clear beforehand.
+constexpr int KN_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_key_norm_max(const bf16_t* __restrict__ img, int64_t ld, int S, int H, int HKV,
+                                                      float* __restrict__ out) {
+    extern __shared__ unsigned kn_s[];   // [HKV]
+    const int b = blockIdx.y;
+    for (int h = threadIdx.x; h < HKV; h += 256) kn_s[h] = 0u;
+    __syncthreads();
+    for (int hkv = 0; hkv < HKV; ++hkv) {
+        float m = 0.f;
+        for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < S; row += (int64_t)KN_BLOCKS * 256) {
+            const bf16_t* kp = img + ((int64_t)b * S + row) * ld + (H + hkv) * D;
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                const uint4 a = *reinterpret_cast<const uint4*>(kp + 8 * c);
+                const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                    n2 = fmaf(lo, lo, fmaf(hi, hi, n2));
+                }
+            }
+            m = fmaxf(m, n2);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&kn_s[hkv], __float_as_uint(m));
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < HKV; h += 256) out[((int64_t)b * KN_BLOCKS + blockIdx.x) * HKV + h] = __uint_as_float(kn_s[h]);
+}
 
 // dropout words of one 32-key tile for the lanes that hold ONE query and runs of 4 consecutive keys (rows
 // 8g + 4hf + 0..3): 16 key-pair words per tile, stored as [hf][g][pair] so that a lane reads its 8 words with two
@@ -227,7 +264,7 @@ __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf
 // grows" ~40 % of the tiles of a wave went through the rescale path at S = 16 384 on random scores; now a handful do.
 // o = acc / l and lse = m ln2 + log l do not depend on where m sits.
 constexpr float RESCALE_SUM = 64.0f;
-template <int OCC, int TPM, bool DROP>
+template <int OCC, int TPM, bool DROP, bool FAST>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
     __shared__ __attribute__((aligned(16))) uint32_t bw_s[DROP ? 16 * TPM : 4];
@@ -268,11 +305,50 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     const short ts = (short)((int)a.drop.thr - 32768);
     const s16x2 tpk = {ts, ts};
 
+    // Static bound (FAST, the common case): the image's q rows carry scale * log2(e), so a score is at most |q| max_s |k_s| in
+    // log2 units (Cauchy-Schwarz on the very bf16 values the MFMA multiplies).  While that bound stays below 54 for every row
+    // of the workgroup, p = exp2(S) needs NO reference value at all: every p, the row sums (< S 2^54) and the O accumulator stay
+    // far inside fp32, and o = acc / l, lse = log l do not depend on a common factor.  The tile then costs 16 exp, 8 packs and
+    // the mask -- no maximum, no subtraction, and the row sums l come from the matrix core (a ones-row product with the packed
+    // P, two MFMAs on a pipe that is idle half of the time) instead of 16 adds; without the adaptive path's state the kernel
+    // fits 128 registers, so all 1024 workgroups of the shipped shape are resident at once (4 per CU, no second round).
+    // A workgroup whose bound is larger raises its flag and leaves; the adaptive kernel (!FAST, launched right after on the
+    // same grid) does exactly the flagged workgroups.
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if constexpr (FAST) {
+        constexpr float BOUND2 = 54.f * 54.f;
+        float q2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = __uint_as_float((unsigned)(unsigned short)qf[s][j] << 16);
+                q2 = fmaf(v, v, q2);
+            }
+        q2 += xhalf(q2);
+        float k2 = a.kmax2[((int64_t)b * KN_BLOCKS + lane) * a.HKV + hkv];   // KN_BLOCKS = 64 partial maxima, one per lane
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
+        const int over = __syncthreads_or(!(q2 * k2 <= BOUND2));
+        if (threadIdx.x == 0) a.redo[wg] = over ? 1 : 0;
+        if (over) return;
+    } else {
+        if (a.redo[wg] == 0) return;
+    }
+
     // one 32-key tile.  TAIL: keys >= S are masked.  Fast path (no running max grows): p = exp2(S - m) needs
     // no subtraction and the O accumulator is not rescaled; otherwise the max moves and everything at the old
     // scale (acc, l) is rescaled exactly once.
-    uint4 regs[TPM];
     const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
+    f32x16 lacc;   // fast path: every register = the row sum of the lane's query
+    bf16x8 ones;
+    if constexpr (FAST) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
+    }
+    uint4 regs[TPM];
     stage_loadN<TPM>(regs, kp, a.ld, vp, a.ld, lo, a.S);
     for (int64_t k0 = lo; k0 < hi; k0 += 32 * TPM) {
         __syncthreads();
@@ -298,6 +374,29 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                         if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
                 }
             };
+            if constexpr (FAST) {
+                f32x16 zero;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 0), qf[0], zero, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kt, l31, hf, 1), qf[1], sc, 0, 0, 0);
+                if (kb + 32 > a.S) {   // wave-uniform: only the last tile of the sequence
+                    const int nv = (int)(a.S - kb);
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (mfma32_row(r, hf) >= nv) sc[r] = -INFINITY;
+                }
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                bf16x8 p0, p1;
+                acc_to_frags(sc, p0, p1);
+                lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lacc, 0, 0, 0);   // l stays undropped
+                lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lacc, 0, 0, 0);
+                if constexpr (DROP) drop_packed(p0, p1, aw, bw_s + 16 * t, hf, tpk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
+                return;
+            }
             float ps0 = 0.f, ps1 = 0.f;   // two scalar chains: packed-f32 adds cost more issue cycles beside MFMAs
             auto exp_sum = [&]() {
                 ps0 = 0.f; ps1 = 0.f;
@@ -363,8 +462,9 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
             }
         }
     }
+    if constexpr (FAST) l = lacc[0];
     const int64_t qi = q0 + l31;
-    l += xhalf(l);
+    if constexpr (!FAST) l += xhalf(l);
     if (qi < a.S) {
         const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
         float* op = a.o + blockIdx.y * a.o_part + (rowbase + qi) * (a.H * D) + head * D;
@@ -1308,7 +1408,12 @@ int split_chunk(int S, int P) { return (int)(ceil_div(ceil_div(S, P), 128) * 128
 
 // fused-buffer bf16 path: qkv is ONE fp32 [B*S][(H+2*HKV)*32] projection output
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-static size_t image_only_bytes(int B, int S, int H, int HKV) { return align256(sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64); }
+// bf16 image | 64 B | max |k|^2 per (batch, kv head) (k_key_norm_max)
+static size_t key_norm_off(int B, int S, int H, int HKV) { return (sizeof(bf16_t) * (size_t)B * S * (H + 2 * HKV) * D + 64 + 15) & ~(size_t)15; }
+static size_t fwd_flags(int B, int S, int H) { return (size_t)B * 8 * (size_t)ceil_div(S, 128) * H; }   // grid of the forward, <= 8 key ranges
+static size_t image_only_bytes(int B, int S, int H, int HKV) {
+    return align256(key_norm_off(B, S, H, HKV) + sizeof(float) * (size_t)B * KN_BLOCKS * HKV + sizeof(int) * fwd_flags(B, S, H));
+}
 
 extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
     const int P = split_parts(ceil_div(S, 128) * H * B, S);
@@ -1348,6 +1453,11 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     if (qkv)
         GAOT_KLAUNCH(k_prep_qkv, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, qkv, (bf16_t*)qkv_image, rows, ld, H,
                      HKV, S, rope_freqs, scale * LOG2E);
+    // bound of the scores of a query row: |q| max_s |k_s| (see the kernel)
+    float* kmax2 = reinterpret_cast<float*>(reinterpret_cast<char*>(qkv_image) + key_norm_off(B, S, H, HKV));
+    int* redo = reinterpret_cast<int*>(kmax2 + (size_t)B * KN_BLOCKS * HKV);   // per-workgroup flags of the bound-based kernel
+    GAOT_KLAUNCH(k_key_norm_max, dim3(KN_BLOCKS, (unsigned)B), dim3(256), sizeof(unsigned) * HKV, st, (const bf16_t*)qkv_image,
+                 (int64_t)ld, S, H, HKV, kmax2);
     // few heads (head-parallel ranks): split the key range over blockIdx.y so that the launch still fills the chip;
     // every part writes a normalised O / lse of its keys into the scratch behind the image, combined below
     const int P = split_parts(ceil_div(S, 128) * H * B, S);
@@ -1355,16 +1465,20 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     const int64_t o_part = rows * H * D, lse_part = (int64_t)B * H * S;
     float* lse_parts = o_parts + (size_t)P * o_part;
     FwdArgs a{(const bf16_t*)qkv_image, P > 1 ? o_parts : o, P > 1 ? lse_parts : lse, ld, B, S, H, HKV,
-              gdrop::make_drop(dropout_seed, dropout_p), P > 1 ? split_chunk(S, P) : S, o_part, lse_part};
+              gdrop::make_drop(dropout_seed, dropout_p), P > 1 ? split_chunk(S, P) : S, o_part, lse_part, kmax2, redo};
     const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), (unsigned)(P > 1 ? ceil_div(S, a.chunk) : 1), (unsigned)B);
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its exp / sum / mask VALU work and loses more from the halved occupancy; a rolled 5-waves/SIMD variant was slower too)
     // with the maximum-free tile path the kernels need ~150 registers: three waves per SIMD without scratch beat four with it
     // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
-    if (a.drop.thr)
-        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true>), fgrid, dim3(256), 0, st, a);
-    else
-        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false>), fgrid, dim3(256), 0, st, a);
+    // bound-based kernel (128 registers: 4 workgroups per CU), then the adaptive one for the workgroups it flagged
+    if (a.drop.thr) {
+        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true>), fgrid, dim3(256), 0, st, a);
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true, false>), fgrid, dim3(256), 0, st, a);
+    } else {
+        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, false, true>), fgrid, dim3(256), 0, st, a);
+        GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false, false>), fgrid, dim3(256), 0, st, a);
+    }
     if (P > 1)
         GAOT_KLAUNCH(k_attn_combine, dim3((unsigned)ceil_div(rows * H * 8, 256)), dim3(256), 0, st, o_parts, lse_parts,
                            (int)fgrid.y, o_part, lse_part, B, S, H, o, lse);
