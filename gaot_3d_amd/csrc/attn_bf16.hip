@@ -174,38 +174,34 @@ struct FwdArgs {
 };
 
 // max_s |k_s|^2 per (batch, kv head) of the bf16 image, as KN_BLOCKS partial maxima per batch element (the forward kernel
-// takes their maximum): out[b][block][hkv].  Non-negative floats order like their bit patterns, so the workgroup's maximum
-// is an integer LDS max -- order independent, bit-reproducible; no global atomics, nothing to clear beforehand.
+// takes their maximum): out[b][block][hkv], one workgroup per (block, batch element, head).  A maximum does not depend on
+// the order it is formed in: bit-reproducible without atomics, nothing to clear beforehand.
 constexpr int KN_BLOCKS = 64;
 __global__ __launch_bounds__(256) void k_key_norm_max(const bf16_t* __restrict__ img, int64_t ld, int S, int H, int HKV,
                                                       float* __restrict__ out) {
-    extern __shared__ unsigned kn_s[];   // [HKV]
-    const int b = blockIdx.y;
-    for (int h = threadIdx.x; h < HKV; h += 256) kn_s[h] = 0u;
-    __syncthreads();
-    for (int hkv = 0; hkv < HKV; ++hkv) {
-        float m = 0.f;
-        for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < S; row += (int64_t)KN_BLOCKS * 256) {
-            const bf16_t* kp = img + ((int64_t)b * S + row) * ld + (H + hkv) * D;
-            float n2 = 0.f;
+    __shared__ float red[4];
+    const int b = blockIdx.y, hkv = blockIdx.z;
+    float m = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < S; row += (int64_t)KN_BLOCKS * 256) {
+        const bf16_t* kp = img + ((int64_t)b * S + row) * ld + (H + hkv) * D;
+        float n2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < D / 8; ++c) {
-                const uint4 a = *reinterpret_cast<const uint4*>(kp + 8 * c);
-                const unsigned w[4] = {a.x, a.y, a.z, a.w};
+        for (int c = 0; c < D / 8; ++c) {
+            const uint4 a = *reinterpret_cast<const uint4*>(kp + 8 * c);
+            const unsigned w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
-                    n2 = fmaf(lo, lo, fmaf(hi, hi, n2));
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                n2 = fmaf(lo, lo, fmaf(hi, hi, n2));
             }
-            m = fmaxf(m, n2);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(&kn_s[hkv], __float_as_uint(m));
+        m = fmaxf(m, n2);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int h = threadIdx.x; h < HKV; h += 256) out[((int64_t)b * KN_BLOCKS + blockIdx.x) * HKV + h] = __uint_as_float(kn_s[h]);
+    if (threadIdx.x == 0) out[((int64_t)b * KN_BLOCKS + blockIdx.x) * HKV + hkv] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // dropout words of one 32-key tile for the lanes that hold ONE query and runs of 4 consecutive keys (rows
@@ -1456,7 +1452,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // bound of the scores of a query row: |q| max_s |k_s| (see the kernel)
     float* kmax2 = reinterpret_cast<float*>(reinterpret_cast<char*>(qkv_image) + key_norm_off(B, S, H, HKV));
     int* redo = reinterpret_cast<int*>(kmax2 + (size_t)B * KN_BLOCKS * HKV);   // per-workgroup flags of the bound-based kernel
-    GAOT_KLAUNCH(k_key_norm_max, dim3(KN_BLOCKS, (unsigned)B), dim3(256), sizeof(unsigned) * HKV, st, (const bf16_t*)qkv_image,
+    GAOT_KLAUNCH(k_key_norm_max, dim3(KN_BLOCKS, (unsigned)B, (unsigned)HKV), dim3(256), 0, st, (const bf16_t*)qkv_image,
                  (int64_t)ld, S, H, HKV, kmax2);
     // few heads (head-parallel ranks): split the key range over blockIdx.y so that the launch still fills the chip;
     // every part writes a normalised O / lse of its keys into the scratch behind the image, combined below
