@@ -282,6 +282,41 @@ def test_gno_bf16_backward(nh):
         check(f"grad_b{i}", gb[i], sdr[f"channel_mlp.fcs.{i}.bias"].grad)
 
 
+@pytest.mark.parametrize("e", [1, 15, 16, 17, 127, 129, 2049])
+def test_gno_bf16_backward_tile_tails(e):
+    """the bf16 backward's waves own 16-edge tiles, eight per workgroup iteration: edge counts around those boundaries (one
+    edge, a tile minus / plus one, an iteration plus one), a source row that runs through every tile (open on both sides
+    of the inner tiles: the partial slots + k_segment_fixup<32, 4>), and two runs bit-identical (no atomics)"""
+    from gaot_3d_amd import ops
+    gen = torch.Generator().manual_seed(70 + e)
+    n_src, n_dst = 40, 23
+    ei = rand_graph(n_src, n_dst, e, seed=80 + e, dtype=torch.int32)
+    ei[0, : max(1, (2 * e) // 3)] = 7       # one long source row
+    y = torch.rand(n_src, 3, generator=gen) * 2 - 1
+    x = torch.rand(n_dst, 3, generator=gen) * 2 - 1
+    f = torch.randn(n_src, 32, generator=gen)
+    w = torch.randn(n_dst, 32, generator=gen)
+    nh = 3
+    sd = _mlp_sd([6] + [64] * nh + [32], seed=5)
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(nh + 1)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(nh + 1)]
+    g = ops.build_graph(ei.to(DEV), n_src, n_dst)
+    runs = []
+    for _ in range(2):
+        gf, gw, gb = ops.gno_backward(ws, bs, y.to(DEV), x.to(DEV), f.to(DEV), w.to(DEV), g, precision=1)
+        torch.cuda.synchronize()
+        runs.append([gf] + list(gw) + list(gb))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    _, rgf, sdr = _oracle_gno(sd, y, x, ei, f, w)
+    refs = [rgf] + [sdr[f"channel_mlp.fcs.{i}.weight"].grad for i in range(nh + 1)] + [sdr[f"channel_mlp.fcs.{i}.bias"].grad for i in range(nh + 1)]
+    for i, (a, b) in enumerate(zip(runs[0], refs)):
+        a, b = a.detach().cpu().double(), b.double()
+        err = (a - b).abs().max().item()
+        print(f"[parity] gno_bf16_bwd_tails_e{e}/{i}: max_abs={err:.3e} ref_peak={b.abs().max().item():.3e}")
+        assert err <= 3e-2 * b.abs().max().item() + 1e-6, (e, i)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_integral_transform_other_shapes_golden(precision):
     """The reference's default shapes -- lifting_channels 16, gno_coord_dim 2 (magno.py:25,28) -- 64 and 48 channels, coord
