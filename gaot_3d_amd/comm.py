@@ -12,7 +12,9 @@ reference has no counterpart (its only parallel mode is sample-level DDP, src/tr
 
 Boundaries can fall inside ``loss.backward()`` (the exchange Functions' backward), i.e. on the autograd engine's device
 thread: captures therefore run in "relaxed" mode (begin and end on different threads are legal, and the process-group
-watchdog's event queries do not invalidate the capture).  All segments share one allocator pool and are replayed in
+watchdog's event queries do not invalidate the capture).  While a step is being RECORDED no collective is issued at all (the
+closures are only noted): the recording executes nothing, and RCCL work enqueued between captures made the watchdog thread
+abort the process now and then (see ``boundary``).  All segments share one allocator pool and are replayed in
 capture order, so a block freed in one segment and re-used in a later one is re-used identically at every replay.
 """
 from __future__ import annotations
@@ -67,8 +69,12 @@ class SegmentedGraph:
         self._cur = None
 
     def boundary(self, fn, keep):
+        # The closure is only RECORDED here, not run: the recording pass executes no kernel, so no value it would move is
+        # needed, and every rank skips the same closures (no rank waits for another).  Running it would enqueue RCCL work
+        # while captures begin and end on this stream, and the process group's watchdog thread polls that work's events
+        # from the side: about one recording in thirty then died with hipErrorCapturedEvent ("event last recorded in a
+        # capturing stream") raised in the watchdog (profiles/r3_o_rccl_watchdog_abort.txt).
         self._end(fn, keep)
-        fn()            # every rank issues the same collectives in the same order during recording too (values are not used)
         self._begin()
 
     def capture(self, step: Callable[[], object]):
@@ -78,8 +84,12 @@ class SegmentedGraph:
         if _ACTIVE is not None:
             raise RuntimeError("a SegmentedGraph capture is already in progress")
         import gc
+        import time
         gc.collect()
         torch.cuda.synchronize()
+        # let the process groups' watchdog threads (100 ms period) retire the finished collectives of the eager steps before
+        # the first capture begins: nothing of theirs is then left to poll while this stream is capturing
+        time.sleep(0.3)
         self.pool = torch.cuda.graph_pool_handle()
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
