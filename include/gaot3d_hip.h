@@ -166,7 +166,9 @@ int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride,
 
 /* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
- * rope_freqs != NULL, q pre-scaled) into qkv_image (gaot_attn_bf16_image_bytes), which the backward re-uses;
+ * rope_freqs != NULL, q pre-scaled) into qkv_image (gaot_attn_bf16_image_bytes: the image, then the forward's own
+ * scratch -- the partial maxima of |k|^2 it bounds the scores with, one flag per workgroup, the key-range parts of
+ * launches with few heads), which the backward re-uses;
  * backward writes the fp32 gradient w.r.t. the projection output into dqkv: with rope_freqs (the forward's) the dq / dk
  * tiles are rotated back in the kernels' epilogues; with NULL the gradient is w.r.t. the ROTATED q|k|v.
  * do_image: scratch of gaot_attn_bwd_bf16_scratch_bytes (bf16 dO image; for launches with few heads also the
