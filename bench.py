@@ -392,6 +392,8 @@ def main(argv=None):
                 pred = model(batch=batch, tokens_pos=tokens)
                 loss = GF.mse_loss(pred, batch.x)
                 loss.backward()
+                loss = loss.detach()    # nothing of the step's autograd graph outlives the step: a live AccumulateGrad node of
+                                        # an eager step would drag its (default) stream into the next step's capture
             else:
                 loss = step_ctx.forward_backward(batch, tokens)
             opt.step()
