@@ -739,7 +739,7 @@ extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         }
         if (rc != GAOT_OK) return rc;
     }
-    const int64_t n = num_queries * 32;
+    const int64_t n = num_queries * 8;   // four channels per thread
     GAOT_KLAUNCH((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_dst,
                        num_queries, part, out, 1);
     GAOT_LAUNCH_CHECK();
@@ -845,7 +845,7 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     }
     GAOT_KLAUNCH(k_scatter_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, flat, sd);
     if (num_sources > 0) {
-        const int64_t n = num_sources * 32;
+        const int64_t n = num_sources * 8;   // four channels per thread
         if (precision == 1)
             GAOT_KLAUNCH((k_segment_fixup<32, 4>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
                                num_sources, part, grad_f_y, 0);

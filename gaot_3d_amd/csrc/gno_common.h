@@ -63,21 +63,30 @@ __device__ __forceinline__ void segment_walk(const float* stage, int ld, const i
 template <int C, int SHIFT = 5>
 __global__ void k_segment_fixup(const int* __restrict__ rowptr, int64_t Q, const float* __restrict__ part,
                                 float* __restrict__ out, int mean) {
+    static_assert(C % 4 == 0, "four channels per thread");
+    constexpr int TPR = C / 4;                                   // threads per row, 16 bytes each
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q * C) return;
-    const int64_t q = i / C;
-    const int c = (int)(i % C);
+    if (i >= Q * TPR) return;
+    const int64_t q = i / TPR;
+    const int c = (int)(i % TPR) * 4;
     const int rb = rowptr[q], re = rowptr[q + 1];
+    float4* o = reinterpret_cast<float4*>(out + q * C + c);
     if (re == rb) {
-        out[i] = 0.f;
+        *o = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const int t0 = rb >> SHIFT, t1 = (re - 1) >> SHIFT;
     if (t0 == t1) return;
-    float s = part[((int64_t)t0 * 2 + 1) * C + c];
-    for (int t = t0 + 1; t <= t1; ++t) s += part[((int64_t)t * 2 + 0) * C + c];
-    out[i] = mean ? s / (float)(re - rb) : s;
+    float4 s = *reinterpret_cast<const float4*>(part + ((int64_t)t0 * 2 + 1) * C + c);
+    for (int t = t0 + 1; t <= t1; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)t * 2 + 0) * C + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (mean) {
+        const float d = (float)(re - rb);
+        s.x /= d; s.y /= d; s.z /= d; s.w /= d;
+    }
+    *o = s;
 }
-
 
 }  // namespace gno
