@@ -401,9 +401,12 @@ def test_attention_spike_rows():
     close("attn_spike_grad", qd.grad, qr.grad, 1e-3, 2e-5)
 
 
+@pytest.mark.parametrize("spike", [6.0, 9.0])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_attention_bf16_deferred_rescale_branch(p_drop):
-    """The bf16 forward moves a row's reference value only when a score exceeds it by more than 2^6 (attn_bf16.hip:
+def test_attention_bf16_deferred_rescale_branch(p_drop, spike):
+    """spike = 6: |q| max|k| stays below the bound of the forward's reference-free kernel (scores up to ~49 log2 units: p up to
+    2^49 without any maximum); spike = 9: above it (~73), the workgroups raise their flags and the adaptive kernel runs, of
+    which the following was written.  The bf16 forward moves a row's reference value only when a score exceeds it by more than 2^6 (attn_bf16.hip:
     RESCALE_THR); random scores never do, so the branch is forced here: key 150 is aligned with query 7 (its score jumps
     by ~50 log2 units in a late tile: the rescale path), key 300 with query 9 just above that row's running maximum (growth
     below the threshold: the path without rescale must cope with p > 1), and a third spike sits in the LAST, ragged tile.
@@ -412,7 +415,7 @@ def test_attention_bf16_deferred_rescale_branch(p_drop):
     from gaot_3d_amd import functional as GF
     b, s, h = 1, 397, 2
     qkv = gen(b * s, 6 * 32, seed=21)
-    qkv[150, 64:96] = qkv[7, 0:32] * 6.0          # head 0: k[150] ~ 6 q[7]
+    qkv[150, 64:96] = qkv[7, 0:32] * spike        # head 0: k[150] ~ 6 q[7] (9 q[7]: beyond the reference-free kernel's bound)
     qkv[300, 64:96] = qkv[9, 0:32] * 0.6          # head 0: k[300] ~ 0.6 q[9]
     qkv[390, 96:128] = qkv[11, 32:64] * 5.0       # head 1: k[390] ~ 5 q[11], in the last (13-key) tile
     w = gen(b * s, h * 32, seed=22)
@@ -436,10 +439,11 @@ def test_attention_bf16_deferred_rescale_branch(p_drop):
         torch.cuda.synchronize()
     finally:
         gaot_3d_amd.set_precision("fp32")
-    close_peak(f"attn_bf16_rescale_branch_p{p_drop}/out", out, ref, 2e-2, 1.5e-2)
-    cosine(f"attn_bf16_rescale_branch_p{p_drop}/dqkv", qd.grad, qr.grad, 0.999)
+    tag = f"attn_bf16_rescale_branch_p{p_drop}_spike{spike:g}"
+    close_peak(f"{tag}/out", out, ref, 2e-2, 1.5e-2)
+    cosine(f"{tag}/dqkv", qd.grad, qr.grad, 0.999)
     for row in (7, 9, 11):
-        close_peak(f"attn_bf16_rescale_branch_p{p_drop}/out_row{row}", out[row], ref[row], 3e-2)
+        close_peak(f"{tag}/out_row{row}", out[row], ref[row], 3e-2)
 
 
 def test_rmsnorm_swiglu_rope_patchify_mse():
