@@ -446,6 +446,49 @@ def test_attention_bf16_deferred_rescale_branch(p_drop, spike):
         close_peak(f"{tag}/out_row{row}", out[row], ref[row], 3e-2)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_qkv_image_packed_and_pack_heads_per_world(world):
+    """the sequence-parallel exchange's layouts at every degree the benchmark runs (2 / 4 / 8 ranks; the whole-model equality
+    tests cover 2 and 4): rank r's slice of the packed projection, gathered over the ranks' row ranges, must be the unsharded
+    attention image restricted to rank r's heads, bit for bit; and rows <-> per-rank blocks must round-trip for fp32 and bf16"""
+    from gaot_3d_amd import ops
+    s_total, h, hkv = 1024, 8, 8
+    rows = s_total // world
+    x = (gen(s_total, 256, seed=61) * 0.5).to(DEV).bfloat16().contiguous()
+    w = (gen((h + 2 * hkv) * 32, 256, seed=62) * 0.06).to(DEV).bfloat16().contiguous()
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(DEV)
+    scale = 32 ** -0.5
+    ld = (h + 2 * hkv) * 32
+    img = ops.qkv_image(x, w, s_total, 1, s_total, h, hkv, freqs, scale)
+    full = img[: s_total * ld * 2].view(torch.bfloat16).view(s_total, ld).clone()
+    hl, kl = h // world, hkv // world
+    lw = (hl + 2 * kl) * 32
+    recv = [torch.empty(world, rows, lw, dtype=torch.bfloat16, device=DEV) for _ in range(world)]
+    for src in range(world):      # what rank `src` sends: block j goes to rank j (the all-to-all, done by hand)
+        packed = ops.qkv_image_packed(x[src * rows:(src + 1) * rows].contiguous(), w, rows, src * rows, s_total, h, hkv, freqs, scale, world)
+        for dst in range(world):
+            recv[dst][src] = packed[dst]
+    torch.cuda.synchronize()
+    for r in range(world):
+        got = recv[r].reshape(s_total, lw)
+        want = torch.cat([full[:, (r * hl) * 32:(r + 1) * hl * 32], full[:, (h + r * kl) * 32:(h + (r + 1) * kl) * 32],
+                          full[:, (h + hkv + r * kl) * 32:(h + hkv + (r + 1) * kl) * 32]], dim=1)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (world, r)
+    # rows <-> blocks, three column segments (q | k | v of a fused projection), both dtypes on either side
+    segs = [(0, hl * 32), (h * 32, kl * 32), ((h + hkv) * 32, kl * 32)]
+    for dt_rows, dt_blocks in ((torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)):
+        src_rows = gen(rows, ld, seed=63).to(DEV).bfloat16().to(dt_rows).contiguous()      # bf16-representable values
+        blocks = torch.empty(world, rows, lw, dtype=dt_blocks, device=DEV)
+        ops.pack_heads(src_rows, blocks, world, segs, True)
+        back = torch.zeros_like(src_rows)
+        ops.pack_heads(back, blocks, world, segs, False)
+        torch.cuda.synchronize()
+        assert torch.equal(back, src_rows), (world, dt_rows, dt_blocks)
+        for r in range(world):
+            want = torch.cat([src_rows[:, c0 + r * wd:c0 + (r + 1) * wd] for c0, wd in segs], dim=1)
+            assert torch.equal(blocks[r].to(dt_rows), want), (world, r, dt_rows, dt_blocks)
+
+
 def test_rmsnorm_swiglu_rope_patchify_mse():
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd import ops
