@@ -373,12 +373,14 @@ def test_point_shard_other_variants_one_gpu(tmp_path, parallel, head_dim, embed,
     assert n > 20
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world):
     """bf16 mode, d_model 256 (8 heads): the sequence-parallel attention node (sharding.SeqAttnFn) -- projection written as
     the all-to-all's bf16 send buffer by the GEMM epilogue, every exchanged tensor bf16, bucketed gradient all-reduce from
     hooks on a second process group -- against the UNSHARDED bf16 step on the same model and sample.  The roundings are those
-    the consuming MFMA kernels apply anyway (delta is formed from the rounded dO: the one numerical difference)."""
+    the consuming MFMA kernels apply anyway (delta is formed from the rounded dO: the one numerical difference).
+    world = 8 is the benchmark's largest degree: ONE head per rank (a 16 x 8 x 8 latent grid there, so that a rank still owns
+    16 token rows)."""
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd.data import make_synthetic_sample
@@ -386,14 +388,16 @@ def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world):
     gaot_3d_amd.set_precision("bf16")
     try:
         torch.manual_seed(0)
-        model = init_model(6, 1, "gaot_3d", small_config(False, hidden=256)).to(DEV).train()
-        batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device=str(DEV))
+        latent = (16, 8, 8) if world == 8 else (8, 8, 4)
+        model = init_model(6, 1, "gaot_3d", small_config(False, hidden=256, latent=latent)).to(DEV).train()
+        batch, tokens = make_synthetic_sample(3001, latent, k=4, seed=1, device=str(DEV))
         loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens.to(DEV)), batch.x)
         loss.backward()
         torch.cuda.synchronize()
     finally:
         gaot_3d_amd.set_precision("fp32")
-    got = _run_shard_workers(tmp_path, world, 29561 + world, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq")
+    got = _run_shard_workers(tmp_path, world, 29561 + world, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq",
+                             GAOT_TEST_LATENT=",".join(str(v) for v in latent))
     print(f"[parity] seq_bf16_w{world}/loss: {got['loss']:.8f} vs {float(loss):.8f}")
     assert abs(got["loss"] - float(loss)) <= 2e-3 * abs(float(loss))
     n = 0
