@@ -107,27 +107,6 @@ __device__ __forceinline__ float relu_bits(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
-__device__ __forceinline__ float gelu_e2_tail(float a) {   // Phi(-a), 0 <= a <= GELU_A_MAX
-    float p = fmaf(a, GELU_P4, GELU_P3);
-    p = fmaf(a, p, GELU_P2);
-    p = fmaf(a, p, GELU_P1);
-    p = fmaf(a, p, GELU_P0);
-    return __builtin_amdgcn_exp2f(p);
-}
-__device__ __forceinline__ float gelu_e2(float x) {
-    const float a = gelu_arg(x);
-    return fmaf(-a, gelu_e2_tail(a), relu_bits(x));
-}
-__device__ __forceinline__ void gelu_e2_pair(float x, float& g, float& dg) {
-    const float a = gelu_arg(x);
-    const float t = gelu_e2_tail(a);
-    g = fmaf(-a, t, relu_bits(x));
-    float q = fmaf(a, GELU_Q4, GELU_Q3);
-    q = fmaf(a, q, GELU_Q2);
-    q = fmaf(a, q, GELU_Q1);
-    q = fmaf(a, q, 1.0f);
-    dg = 0.5f + copysignf(fmaf(-t, q, 0.5f), x);
-}
 // two activations at a time (v_pk_fma_f32 runs two lanes' worth of fp32 per issue slot; left to itself the compiler packs
 // only part of the scalar form)
 __device__ __forceinline__ f32v2 gelu_e2_tail2(f32v2 a) {
@@ -154,6 +133,18 @@ __device__ __forceinline__ void gelu_e2_pair2(f32v2 x, f32v2& g, f32v2& dg) {
     const f32v2 w = __builtin_elementwise_fma(-t, q, (f32v2)(0.5f));
     const f32v2 sw = {copysignf(w[0], x[0]), copysignf(w[1], x[1])};
     dg = sw + (f32v2)(0.5f);
+}
+
+__device__ __forceinline__ f32v2 gelu_e2_grad2(f32v2 x) {   // the derivative alone
+    const f32v2 a = {gelu_arg(x[0]), gelu_arg(x[1])};
+    const f32v2 t = gelu_e2_tail2(a);
+    f32v2 q = __builtin_elementwise_fma(a, (f32v2)(GELU_Q4), (f32v2)(GELU_Q3));
+    q = __builtin_elementwise_fma(a, q, (f32v2)(GELU_Q2));
+    q = __builtin_elementwise_fma(a, q, (f32v2)(GELU_Q1));
+    q = __builtin_elementwise_fma(a, q, (f32v2)(1.0f));
+    const f32v2 w = __builtin_elementwise_fma(-t, q, (f32v2)(0.5f));
+    const f32v2 sw = {copysignf(w[0], x[0]), copysignf(w[1], x[1])};
+    return sw + (f32v2)(0.5f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -100,10 +100,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp2_fwd(Mlp2Args a, float* __restri
                 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][0], frag_rows(xt + t * TILE_BYTES, l31, hf, 0), z, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][1], frag_rows(xt + t * TILE_BYTES, l31, hf, 1), z, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float y = gelu_e2(z[r]);
+                for (int r2 = 0; r2 < 16; r2 += 2) {   // two activations per packed-fp32 instruction
+                    const f32v2 y2 = gelu_e2_2(f32v2{z[r2], z[r2 + 1]});
 #pragma unroll
-                    for (int c = 0; c < OC; ++c) po[c] = fmaf(y, w2s[c * H + 32 * ob + mfma32_row(r, hf)], po[c]);
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int c = 0; c < OC; ++c) po[c] = fmaf(y2[u], w2s[c * H + 32 * ob + mfma32_row(r2 + u, hf)], po[c]);
                 }
             }
 #pragma unroll
@@ -205,20 +207,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
                 zq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr1, w1f[o][1], zq, 0, 0, 0);
                 float s1 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y, gd;
-                    gelu_e2_pair(zq[r], y, gd);
-                    const int n = 32 * t + mfma32_row(r, hf);
-                    float dy = 0.f;
+                for (int r2 = 0; r2 < 16; r2 += 2) {   // two activations per packed-fp32 instruction
+                    f32v2 y2, gd2;
+                    gelu_e2_pair2(f32v2{zq[r2], zq[r2 + 1]}, y2, gd2);
 #pragma unroll
-                    for (int c = 0; c < OC; ++c) {
-                        const float d = dos[n * OC + c];
-                        dy = fmaf(d, w2l[o][c], dy);
-                        dw2[o][c] = fmaf(d, y, dw2[o][c]);
+                    for (int u = 0; u < 2; ++u) {
+                        const int r = r2 + u;
+                        const int n = 32 * t + mfma32_row(r, hf);
+                        float dy = 0.f;
+#pragma unroll
+                        for (int c = 0; c < OC; ++c) {
+                            const float d = dos[n * OC + c];
+                            dy = fmaf(d, w2l[o][c], dy);
+                            dw2[o][c] = fmaf(d, y2[u], dw2[o][c]);
+                        }
+                        const float dz = dy * gd2[u];
+                        s1 += dz;
+                        zq[r] = dz;
                     }
-                    const float dz = dy * gd;
-                    s1 += dz;
-                    zq[r] = dz;
                 }
                 db1[o] += s1;
                 {
@@ -237,14 +243,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
                 zp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][0], xr0, zp, 0, 0, 0);
                 zp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][1], xr1, zp, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y, gd;
-                    gelu_e2_pair(zp[r], y, gd);
-                    const int j = 32 * ob + mfma32_row(r, hf);
-                    float dy = 0.f;
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    const f32v2 gd2 = gelu_e2_grad2(f32v2{zp[r2], zp[r2 + 1]});
 #pragma unroll
-                    for (int c = 0; c < OC; ++c) dy = fmaf(dol[c], w2s[c * H + j], dy);
-                    zp[r] = dy * gd;
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = 32 * ob + mfma32_row(r2 + u, hf);
+                        float dy = 0.f;
+#pragma unroll
+                        for (int c = 0; c < OC; ++c) dy = fmaf(dol[c], w2s[c * H + j], dy);
+                        zp[r2 + u] = dy * gd2[u];
+                    }
                 }
                 {
                     bf16x8 f0, f1;
