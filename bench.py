@@ -510,6 +510,10 @@ def main(argv=None):
 
     n_total = args.points * world if args.scaling == "weak" else args.points
     use_graph = (not args.no_graph) and world == 1
+    if world > 1:
+        # eager steps, recording and replay of the sharded step all on ONE side stream: nothing of the step (autograd's
+        # stream-bound gradient accumulators included) ever involves the default stream, which a capture cannot contain
+        torch.cuda.set_stream(torch.cuda.Stream())
     # second process group over the same ranks: the bucketed weight-gradient all-reduce runs on its own RCCL stream
     grad_group = dist.new_group(backend="gloo" if one_device else "nccl") if world > 1 else None
     model, step, edge_counts = build(n_total, args.atten_dropout, args.parallel)

@@ -91,8 +91,12 @@ class SegmentedGraph:
         # the first capture begins: nothing of theirs is then left to poll while this stream is capturing
         time.sleep(0.3)
         self.pool = torch.cuda.graph_pool_handle()
-        self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
+        # record on the caller's stream when it is a side stream already (a caller that runs its eager steps there too keeps
+        # every stream-bound piece of autograd state -- AccumulateGrad nodes remember the stream they were made on -- on the
+        # recording stream); the default stream cannot be captured: a fresh side stream then
+        cur = torch.cuda.current_stream()
+        self.stream = cur if cur != torch.cuda.default_stream() else torch.cuda.Stream()
+        self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self._begin()
             _ACTIVE = self
