@@ -298,6 +298,37 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def summarize_exchange_profiles(per_rank):
+    """per_rank: one {"eager": ExchangeProfile.summary, "segmented": ...} per rank -> per mode MIN / MAX over the ranks of
+    the step's device ms, of the part inside exchange steps and of the part inside kernels, plus per collective kind the
+    count, the bytes per step and the MIN / MAX exposed device ms.  `grad_bucket_wait` is what the asynchronous bucketed
+    weight-gradient all-reduce did NOT hide under the remaining backward."""
+    out = {}
+    for mode in ("eager", "segmented"):
+        recs = [r.get(mode) for r in per_rank if isinstance(r, dict) and isinstance(r.get(mode), dict)]
+        good = [r for r in recs if "error" not in r]
+        if not good:
+            if recs:
+                out[mode] = dict(error=recs[0].get("error"))
+            continue
+        ent = {}
+        for key in ("step_device_ms", "exchange_device_ms", "compute_device_ms"):
+            vals = [r[key] for r in good]
+            ent[key] = dict(min=round(min(vals), 4), max=round(max(vals), 4))
+        kinds = {}
+        for r in good:
+            for kind, kv in r["kinds"].items():
+                k = kinds.setdefault(kind, dict(count_per_step=kv["count"], bytes_per_step=kv["bytes"], device_ms=[]))
+                k["device_ms"].append(kv["device_ms"])
+        for kind, k in kinds.items():
+            v = k.pop("device_ms")
+            k["device_ms_min"], k["device_ms_max"] = round(min(v), 4), round(max(v), 4)
+        ent["kinds"] = kinds
+        ent["ranks"] = len(good)
+        out[mode] = ent
+    return out
+
+
 def dry_run(args):
     """launch / rendezvous check without GPU work: every rank joins a gloo group and rank 0 prints the line"""
     import torch
@@ -366,6 +397,8 @@ def main(argv=None):
     m_lat = latent[0] * latent[1] * latent[2]
     s_tok = m_lat // 8
 
+    geometry_cached = {"on": False}
+
     def build(n_total, atten_dropout, parallel):
         """model + optimizer + rank-local inputs + step() for one sample of n_total points"""
         cfg = model_config(latent, args.layers, args.knn, atten_dropout, args.workload)
@@ -386,7 +419,11 @@ def main(argv=None):
         edges = dict(enc=int(batch.encoder_edge_index_s0.shape[1]), dec=int(batch.decoder_edge_index_s0.shape[1]))
 
         def step():
-            gaot_3d_amd.clear_graph_cache(batch)
+            if not geometry_cached["on"]:
+                # CSR build and GeoEmbed statistics are per-sample constants (the reference precomputes its edges offline,
+                # stat.py:126-224): the headline step rebuilds them every time, the `geometry_cached` figure serves them from
+                # the per-sample cache on the batch
+                gaot_3d_amd.clear_graph_cache(batch)
             opt.zero_grad(set_to_none=True)
             if step_ctx is None:
                 pred = model(batch=batch, tokens_pos=tokens)
@@ -480,16 +517,16 @@ def main(argv=None):
             return None, "capture failed (see stderr); eager launches timed instead"
         return (e, g, l, th), "ok"
 
-    def measure_segmented(step, steps, warmup):
+    def record_segmented(step, sg, warmup):
         """N>1 default launch mode: the step recorded as hipGraph segments between eagerly issued exchange steps
-        (gaot_3d_amd/comm.py).  No collective is captured.  -> (elapsed, SegmentedGraph, loss, host seconds of the timed
-        region, host seconds of it spent inside the exchange closures)"""
-        from gaot_3d_amd import comm
+        (gaot_3d_amd/comm.py).  No collective is captured, and the recording pass itself issues none."""
         for _ in range(max(warmup, 1)):
             step()                              # eager: lazy initialisation, co-located weights
         torch.cuda.synchronize()
-        sg = comm.SegmentedGraph()
         sg.capture(step)
+
+    def time_segmented(sg, steps, warmup):
+        """-> (elapsed, loss, host seconds of the timed region, host seconds of it spent inside the exchange closures)"""
         for _ in range(max(warmup, 1)):
             sg.replay()
         torch.cuda.synchronize()
@@ -506,7 +543,7 @@ def main(argv=None):
         elapsed = time.perf_counter() - t0
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return tt.item(), sg, sg.result, t_host, sg.host_exchange_s
+        return tt.item(), sg.result, t_host, sg.host_exchange_s
 
     n_total = args.points * world if args.scaling == "weak" else args.points
     use_graph = (not args.no_graph) and world == 1
@@ -519,27 +556,75 @@ def main(argv=None):
     model, step, edge_counts = build(n_total, args.atten_dropout, args.parallel)
     elapsed, graph, loss, t_host_main = measure(step, args.steps, args.warmup, use_graph)
     eager_rec = seg_rec = None
+    exchange_profile = {}
     if world > 1 and not args.no_graph and not args.no_segmented:
         eager_rec = dict(ms_per_step=elapsed / args.steps * 1e3, value=n_total / (elapsed / args.steps),
                          host_ms_per_step=round(t_host_main / args.steps * 1e3, 3))
+        from gaot_3d_amd import comm
+        # per-rank split of the EAGER step's device time first (no capture involved): exchange steps vs kernels
         try:
-            e_s, sg, loss_s, th_s, tx_s = measure_segmented(step, args.steps, args.warmup)
+            k_prof = max(1, min(args.steps, 3))
+            with comm.eager_profile() as prof:
+                for _ in range(k_prof):
+                    step()
+            torch.cuda.synchronize()
+            exchange_profile["eager"] = prof.summary(k_prof)
+        except Exception as ex:
+            exchange_profile["eager"] = dict(error=f"{type(ex).__name__}: {ex}")
+        sg = None
+        seg_err = None
+        try:
+            sg = comm.SegmentedGraph()
+            record_segmented(step, sg, args.warmup)
+        except Exception as ex:
+            seg_err = f"{type(ex).__name__}: {ex}"
+            sg = None
+            print(f"[bench] rank {rank}: segmented capture failed ({seg_err})", file=sys.stderr)
+            torch.cuda.synchronize()
+        # every rank must take the SAME branch: one rank replaying while another launches eagerly would pair different
+        # collectives and hang.  MIN over the ranks' success flags decides.
+        okf = torch.tensor([1.0 if sg is not None else 0.0], device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if okf.item() >= 1.0:
+            e_s, loss_s, th_s, tx_s = time_segmented(sg, args.steps, args.warmup)
             seg_rec = dict(ms_per_step=e_s / args.steps * 1e3, value=n_total / (e_s / args.steps),
                            host_ms_per_step=round(th_s / args.steps * 1e3, 3),
                            host_ms_per_step_outside_exchange=round((th_s - tx_s) / args.steps * 1e3, 3),
                            graph_segments=sg.num_segments, exchanges=sg.num_exchanges,
                            host_launches_plus_collectives=sg.num_segments + sg.num_exchanges)
+            try:
+                exchange_profile["segmented"] = sg.replay_profiled(max(1, min(args.steps, 3)))
+            except Exception as ex:
+                exchange_profile["segmented"] = dict(error=f"{type(ex).__name__}: {ex}")
             if e_s < elapsed:
                 elapsed, loss, t_host_main, graph = e_s, loss_s, th_s, sg
-        except Exception as ex:
-            seg_rec = dict(error=f"{type(ex).__name__}: {ex}")
-            print(f"[bench] segmented capture failed ({type(ex).__name__}: {ex}); eager launches reported", file=sys.stderr)
-            torch.cuda.synchronize()
+        else:
+            seg_rec = dict(error=seg_err or "the recording failed on another rank: every rank reports its eager launches")
 
     secondary = None
     fp32_mode = None
     weak = None
+    geom_cached = None
+    copy_peak = None
+    if world == 1:
+        try:
+            copy_peak = round(ops.stream_copy_gbps(), 1)     # float4 copy, 1 GiB, read + written bytes / HIP-event time
+        except Exception as ex:
+            copy_peak = None
+            print(f"[bench] stream copy failed ({type(ex).__name__}: {ex})", file=sys.stderr)
     if world == 1 and not args.no_secondary:
+        # the same step with the per-sample constants (neighbour lists, GeoEmbed statistics) served from the cache on the
+        # batch, as the reference's offline edge precompute does (stat.py:126-224); SURVEY 8d asks for both figures
+        try:
+            geometry_cached["on"] = True
+            eg, gg, _, _ = measure(step, args.steps, args.warmup, use_graph)
+            geom_cached = dict(ms_per_step=eg / args.steps * 1e3, value=n_total / (eg / args.steps),
+                               note="CSR build + GeoEmbed statistics cached per sample (built once, outside the step)")
+            del gg
+        except Exception as ex:
+            geom_cached = dict(error=f"{type(ex).__name__}: {ex}")
+        finally:
+            geometry_cached["on"] = False
         if args.atten_dropout > 0.0:
             # the same step with the dropout switched off (what the kernels do in eval mode / atten_dropout = 0)
             for mod in model.modules():
@@ -722,6 +807,10 @@ def main(argv=None):
             "instrumented_eager_ms_per_step": round(t_eager * 1e3, 3),
             "instrumented_eager_host_ms_per_step": round(t_host * 1e3, 3),
             "without_attention_dropout": secondary,
+            "geometry_cached": geom_cached,
+            "hbm_copy_peak_measured": (dict(gbps=copy_peak, frac_of_8tbps=round(copy_peak / 8000.0, 4),
+                                            how="float4 grid-stride copy of 1 GiB, read + written bytes, HIP events, same run")
+                                       if copy_peak else None),
             "fp32_mode": fp32_mode,
             "other_scaling": weak,
             "roofline": roof,
@@ -737,6 +826,17 @@ def main(argv=None):
     else:
         launch_txt = "hipGraph replay of one captured step" if graph is not None else "eager"
     out = make_out(elapsed, launch_txt, t_host_main) if rank == 0 else None
+    if world > 1:
+        # one line that explains a flat curve: per rank, the device time inside exchange steps (per collective kind, with the
+        # bytes moved) against the device time inside the kernels between them; MIN / MAX over the ranks
+        gathered = [None] * world
+        dist.all_gather_object(gathered, exchange_profile)
+        if rank == 0:
+            out["exchange_profile"] = summarize_exchange_profiles(gathered)
+            out["exchange_profile"]["backend"] = dict(
+                name=str(dist.get_backend()), world_size=dist.get_world_size(),
+                rccl_version=(".".join(str(v) for v in torch.cuda.nccl.version()) if not one_device else None),
+                grad_group="second communicator (bucketed weight-gradient all-reduce, asynchronous)")
     if rank == 0 and world > 1:
         out["eager"], out["segmented"] = eager_rec, seg_rec
     attempted = False
@@ -754,7 +854,7 @@ def main(argv=None):
                 eg, _, _, thg = res
                 out["graph"] = dict(ms_per_step=eg / args.steps * 1e3, value=n_total / (eg / args.steps))
                 if eg < elapsed:
-                    keep = {kk: out[kk] for kk in ("eager", "segmented", "graph", "graph_attempt")}
+                    keep = {kk: out[kk] for kk in ("eager", "segmented", "graph", "graph_attempt", "exchange_profile") if kk in out}
                     out = make_out(eg, "hipGraph replay of one captured step (RCCL collectives captured)", thg)
                     out.update(keep)
     if rank == 0:

@@ -101,6 +101,7 @@ SIGNATURES = {
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
+    "gaot_stream_copy": (_i, [_p, _p, _i64, _p]),
     "gaot_patchify": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gaot_mse_workspace_bytes": (_sz, []),
     "gaot_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
@@ -132,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 7:
+    if lib.gaot_abi_version() != 8:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

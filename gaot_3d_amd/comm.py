@@ -25,17 +25,96 @@ import torch
 
 _ACTIVE: Optional["SegmentedGraph"] = None
 COUNTS = {"collectives": 0}
+_EAGER_PROFILE: Optional["ExchangeProfile"] = None
 
 
-def run(fn: Callable[[], None], keep: Tuple = ()) -> None:
+def _nbytes(keep: Tuple) -> int:
+    """payload of an exchange step = the first tensor of ``keep`` (the buffer the collective fills / reduces in place)"""
+    for t in keep:
+        if isinstance(t, torch.Tensor):
+            return int(t.numel() * t.element_size())
+    return 0
+
+
+def run(fn: Callable[[], None], keep: Tuple = (), kind: str = "collective") -> None:
     """issue one exchange step.  ``fn`` must only call collectives / copies on tensors that already exist (``keep`` lists
-    them so that a recorded step keeps them alive at their addresses)."""
+    them so that a recorded step keeps them alive at their addresses).  ``kind`` names the collective for the per-kind
+    device-time / byte accounting of ``ExchangeProfile`` (bench.py --gpus N)."""
     COUNTS["collectives"] += 1
     rec = _ACTIVE
     if rec is None:
-        fn()
+        prof = _EAGER_PROFILE
+        if prof is None:
+            fn()
+        else:
+            prof.around(fn, kind, _nbytes(keep))
     else:
-        rec.boundary(fn, keep)
+        rec.boundary(fn, keep, kind)
+
+
+class ExchangeProfile:
+    """Device time of a step split into "inside exchange steps" and "inside everything else" (graph segments / eager
+    kernels), per collective kind, from HIP events recorded on the step's stream around every ``comm.run`` closure.  A
+    blocking collective (``async_op=False``) makes the step's stream wait for the communicator's stream, so the event
+    after the closure fires when the exchange is done: the interval is the exchange's EXPOSED device time.  The bucketed
+    gradient all-reduce is issued asynchronously on its own communicator: its issue closure costs ~nothing and what is not
+    hidden under the remaining backward shows up in the ``grad_bucket_wait`` interval."""
+
+    def __init__(self):
+        self.marks = []          # (kind, bytes, event_before, event_after)
+        self.t0 = self.t1 = None
+
+    def begin(self):
+        self.t0 = torch.cuda.Event(enable_timing=True)
+        self.t0.record()
+
+    def end(self):
+        self.t1 = torch.cuda.Event(enable_timing=True)
+        self.t1.record()
+
+    def around(self, fn, kind, nbytes):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.marks.append((kind, nbytes, a, b))
+
+    def summary(self, steps: int = 1) -> dict:
+        """call after a synchronize; per-step numbers"""
+        total = self.t0.elapsed_time(self.t1) / steps
+        kinds = {}
+        exch = 0.0
+        for kind, nbytes, a, b in self.marks:
+            ms = a.elapsed_time(b)
+            exch += ms
+            k = kinds.setdefault(kind, dict(count=0, bytes=0, device_ms=0.0))
+            k["count"] += 1
+            k["bytes"] += nbytes
+            k["device_ms"] += ms
+        for k in kinds.values():
+            k["count"] = k["count"] / steps
+            k["bytes"] = k["bytes"] / steps
+            k["device_ms"] = round(k["device_ms"] / steps, 4)
+        exch /= steps
+        return dict(step_device_ms=round(total, 4), exchange_device_ms=round(exch, 4),
+                    compute_device_ms=round(total - exch, 4), kinds=kinds)
+
+
+class eager_profile:
+    """``with comm.eager_profile() as prof: step()`` -- the same accounting for eagerly launched steps"""
+
+    def __enter__(self):
+        global _EAGER_PROFILE
+        self.prof = ExchangeProfile()
+        _EAGER_PROFILE = self.prof
+        self.prof.begin()
+        return self.prof
+
+    def __exit__(self, *exc):
+        global _EAGER_PROFILE
+        self.prof.end()
+        _EAGER_PROFILE = None
+        return False
 
 
 def capturing() -> bool:
@@ -51,6 +130,7 @@ class SegmentedGraph:
 
     def __init__(self):
         self.segments: List[Tuple[torch.cuda.CUDAGraph, Optional[Callable[[], None]], Tuple]] = []
+        self.kinds: List[Tuple[str, int]] = []          # (kind, bytes) of the exchange that follows segment i
         self.pool = None
         self.stream: Optional[torch.cuda.Stream] = None
         self._cur: Optional[torch.cuda.CUDAGraph] = None
@@ -63,18 +143,19 @@ class SegmentedGraph:
         g.capture_begin(pool=self.pool, capture_error_mode="relaxed")
         self._cur = g
 
-    def _end(self, fn, keep):
+    def _end(self, fn, keep, kind="collective"):
         self._cur.capture_end()
         self.segments.append((self._cur, fn, tuple(keep)))
+        self.kinds.append((kind, _nbytes(tuple(keep))))
         self._cur = None
 
-    def boundary(self, fn, keep):
+    def boundary(self, fn, keep, kind="collective"):
         # The closure is only RECORDED here, not run: the recording pass executes no kernel, so no value it would move is
         # needed, and every rank skips the same closures (no rank waits for another).  Running it would enqueue RCCL work
         # while captures begin and end on this stream, and the process group's watchdog thread polls that work's events
         # from the side: about one recording in thirty then died with hipErrorCapturedEvent ("event last recorded in a
         # capturing stream") raised in the watchdog (profiles/r3_o_rccl_watchdog_abort.txt).
-        self._end(fn, keep)
+        self._end(fn, keep, kind)
         self._begin()
 
     def capture(self, step: Callable[[], object]):
@@ -102,10 +183,24 @@ class SegmentedGraph:
             _ACTIVE = self
             try:
                 self.result = step()
-            finally:
+            except BaseException:
+                # the capture is invalid now: ending it may raise as well and must not mask the step's own error; leave
+                # nothing half-built behind (a caller that falls back to eager steps starts from a clean object)
                 _ACTIVE = None
-                if self._cur is not None:
-                    self._end(None, ())
+                try:
+                    if self._cur is not None:
+                        self._cur.capture_end()
+                except Exception:
+                    pass
+                self._cur = None
+                self.segments = []
+                self.kinds = []
+                self.pool = None
+                self.result = None
+                raise
+            _ACTIVE = None
+            if self._cur is not None:
+                self._end(None, ())
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         return self.result
@@ -128,6 +223,21 @@ class SegmentedGraph:
                     t0 = time.perf_counter()
                     fn()
                     self.host_exchange_s += time.perf_counter() - t0
+
+    def replay_profiled(self, steps: int = 1) -> dict:
+        """``steps`` replays with HIP events around every exchange closure on the replay stream -> ExchangeProfile.summary:
+        device ms inside exchange steps (per kind, with bytes) vs inside the graph segments"""
+        prof = ExchangeProfile()
+        with torch.cuda.stream(self.stream):
+            prof.begin()
+            for _ in range(steps):
+                for (g, fn, _), (kind, nbytes) in zip(self.segments, self.kinds):
+                    g.replay()
+                    if fn is not None:
+                        prof.around(fn, kind, nbytes)
+            prof.end()
+        torch.cuda.synchronize()
+        return prof.summary(steps)
 
     @property
     def num_segments(self) -> int:

@@ -1412,7 +1412,12 @@ extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
 }
 // the fused backward (k_attn_bwd_fused) is taken when its grid -- one workgroup per 512 keys and kv head -- covers at least
 // half of the chip; smaller launches (few heads per rank of a sharded step) keep the two range-split passes
-static bool fused_bwd_ok(int B, int S, int H, int HKV) { return (int64_t)ceil_div(S, 512) * HKV * B >= 128; }
+// ... and when its dQ slab partials -- B * H * ceil(S/512) * S * 32 bf16, QUADRATIC in S: 268 MB at S = 16 384, 4.3 GB at
+// S = 65 536 -- stay under 1 GiB; longer sequences keep the two-pass form, whose scratch is O(S)
+static size_t fused_dqpart_bytes(int B, int S, int H) { return (size_t)B * H * (size_t)ceil_div(S, 512) * (size_t)S * D * sizeof(bf16_t); }
+static bool fused_bwd_ok(int B, int S, int H, int HKV) {
+    return (int64_t)ceil_div(S, 512) * HKV * B >= 128 && fused_dqpart_bytes(B, S, H) <= ((size_t)1 << 30);
+}
 extern "C" int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV) { return fused_bwd_ok(B, S, H, HKV) ? 1 : 0; }
 static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {
     const int P = split_parts(ceil_div(S, 128) * H * B, S);
@@ -1420,7 +1425,7 @@ static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {
 }
 extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV) {
     // dO image | range-split partial gradients (small grids) | dQ slab partials of the fused pass [B][H][S/512][S][32] fp32
-    const size_t dqpart = fused_bwd_ok(B, S, H, HKV) ? (size_t)B * H * ceil_div(S, 512) * S * D * sizeof(bf16_t) : 0;
+    const size_t dqpart = fused_bwd_ok(B, S, H, HKV) ? fused_dqpart_bytes(B, S, H) : 0;
     return align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64) + bwd_parts_bytes(B, S, H, HKV) + dqpart;
 }
 
@@ -1510,7 +1515,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                            S, H);
     if (phase_mask & (16 | 32)) {   // 16: dK / dV and dQ slab partials from one pass over the score tiles; 32: the slab reduction
         if (!fused_bwd_ok(B, S, H, HKV)) {
-            gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need ceil(S/512)*HKV*B >= 128 workgroups; use phases 2 and 4");
+            gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need ceil(S/512)*HKV*B >= 128 workgroups and <= 1 GiB of dQ slab partials; use phases 2 and 4");
             return GAOT_ERR_UNSUPPORTED;
         }
         const int nslab = (int)ceil_div(S, fb_keys(8));

@@ -542,12 +542,12 @@ int gaot_gno_bwd3_bf16_launch(int n_hidden, void* images, const float* w0t, cons
                               const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
                               const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
                               int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st) {
-    MlpPtrs p;
-    for (int l = 0; l <= n_hidden; ++l) { p.w[l] = w[l]; p.b[l] = b[l]; }
-    if (n_hidden < 1 || n_hidden > 3) {
+    if (n_hidden < 1 || n_hidden > 3) {      // before anything indexes w / b / MlpPtrs with it
         gaot_set_error("gaot_gno_bwd (bf16): unsupported n_hidden %d", n_hidden);
         return GAOT_ERR_UNSUPPORTED;
     }
+    MlpPtrs p;
+    for (int l = 0; l <= n_hidden; ++l) { p.w[l] = w[l]; p.b[l] = b[l]; }
     GAOT_KLAUNCH(k_prep_bwd3_images, dim3(32), dim3(256), 0, st, p, n_hidden, (bf16_t*)images);
     switch (n_hidden) {
         case 1: return launch_bwd3<1>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);

@@ -51,7 +51,7 @@ class GeometricEmbedding(nn.Module):
             import torch.distributed as dist
             mom = ops.geoembed_moments(source_pos, query_pos, graph)
             from ... import comm
-            comm.run(lambda: dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group), (mom,))
+            comm.run(lambda: dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=shard_group), (mom,), "all_reduce")
             feats = ops.geoembed_from_moments(mom)
         else:
             # geometry only: no autograd through it.  One sweep over the neighbour lists (additive fp64 moments about the
@@ -91,7 +91,7 @@ class GeometricEmbedding(nn.Module):
             gdeg = deg.clone()
             import torch.distributed as dist
             from ... import comm
-            comm.run(lambda: dist.all_reduce(gdeg, op=dist.ReduceOp.SUM, group=group), (gdeg,))
+            comm.run(lambda: dist.all_reduce(gdeg, op=dist.ReduceOp.SUM, group=group), (gdeg,), "all_reduce")
         po = GF.linear(pooled, self.fc[0].weight, self.fc[0].bias, precision=0)
         return EO.RowScaleFn.apply(po, (gdeg > 0).to(torch.float32))
 

@@ -269,6 +269,23 @@ def axpy(a: Tensor, b: Tensor, alpha: float = 1.0, period: Optional[int] = None)
     return out
 
 
+def stream_copy_gbps(nbytes: int = 1 << 30, reps: int = 10) -> float:
+    """measured float4 streaming-copy rate of this device in GB/s (read + written bytes over the HIP-event time of ``reps``
+    copies of ``nbytes``): the practical HBM ceiling quoted beside the 8 TB/s spec figure"""
+    lib = _lib.load()
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        check(lib.gaot_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "gaot_stream_copy")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        check(lib.gaot_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "gaot_stream_copy")
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, want_bf16: bool = False):
     """-> (y, rstd, y_bf16 | None); the bf16 copy (same rounding a GEMM would apply to y as its A operand) is written by
     the same pass"""
@@ -656,7 +673,7 @@ def geoembed_stats_sharded_queries(source_pos: Tensor, query_pos: Tensor, g: Bip
                                 _ptr(sums), _ptr(ws), ws.numel(), _stream()), "gaot_geoembed_raw")
     if group is not None:
         from . import comm
-        comm.run(lambda: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), (sums,))
+        comm.run(lambda: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), (sums,), "all_reduce")
     check(lib.gaot_geoembed_finalize(_ptr(feat), q, _ptr(sums), int(num_queries_total), _ptr(ws), ws.numel(), _stream()),
           "gaot_geoembed_finalize")
     return feat

@@ -93,7 +93,7 @@ class GlobalSegmentMeanFn(torch.autograd.Function):
     def forward(ctx, local_mean: Tensor, local_deg: Tensor, group):
         # ONE all-reduce of [M, C + 1]: the per-token sums (the kernel's mean times its own edge count) and the counts
         buf = torch.cat([local_mean * local_deg[:, None], local_deg[:, None]], dim=1)
-        comm.run(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group), (buf,))
+        comm.run(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group), (buf,), "all_reduce")
         dg = buf[:, -1].clamp(min=1.0)
         ctx.save_for_backward(local_deg / dg)
         return buf[:, :-1] / dg[:, None]
@@ -116,12 +116,12 @@ class GlobalSegmentMaxFn(torch.autograd.Function):
         has_local = (local_deg > 0)[:, None]
         glob = torch.where(has_local, local_max, torch.full_like(local_max, float("-inf")))
         mine = glob.clone()
-        comm.run(lambda: dist.all_reduce(glob, op=dist.ReduceOp.MAX, group=group), (glob,))
+        comm.run(lambda: dist.all_reduce(glob, op=dist.ReduceOp.MAX, group=group), (glob,), "all_reduce")
         deg = local_deg.clone()
-        comm.run(lambda: dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group), (deg,))
+        comm.run(lambda: dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group), (deg,), "all_reduce")
         owner = ((mine == glob) & has_local).to(local_max.dtype)
         nown = owner.clone()
-        comm.run(lambda: dist.all_reduce(nown, op=dist.ReduceOp.SUM, group=group), (nown,))
+        comm.run(lambda: dist.all_reduce(nown, op=dist.ReduceOp.SUM, group=group), (nown,), "all_reduce")
         ctx.save_for_backward(owner / nown.clamp(min=1.0))
         ctx.mark_non_differentiable(deg)
         return torch.where((deg > 0)[:, None], glob, torch.zeros_like(glob)), deg
@@ -144,7 +144,7 @@ class AllReduceGradFn(torch.autograd.Function):
     def backward(ctx, g: Tensor):
         g = g.contiguous().clone()
         group = ctx.group
-        comm.run(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group), (g,))
+        comm.run(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group), (g,), "all_reduce")
         return g, None
 
 
@@ -166,10 +166,10 @@ def all_gather_stack(t: Tensor, group, world: int) -> Tensor:
     t = t if t.is_contiguous() else t.contiguous()
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if dist.get_backend(group) == "nccl":
-        comm.run(lambda: dist.all_gather_into_tensor(out, t, group=group), (out, t))
+        comm.run(lambda: dist.all_gather_into_tensor(out, t, group=group), (out, t), "all_gather")
     else:
         parts = list(out.unbind(0))
-        comm.run(lambda: dist.all_gather(parts, t, group=group), (out, t))
+        comm.run(lambda: dist.all_gather(parts, t, group=group), (out, t), "all_gather")
     return out
 
 
@@ -236,9 +236,9 @@ def _all_to_all_into(recv: Tensor, send: Tensor, group) -> None:
             r = torch.empty_like(h)
             dist.all_to_all_single(r, h, group=group)
             recv.copy_(r)
-        comm.run(staged, (recv, send))
+        comm.run(staged, (recv, send), "all_to_all")
     else:
-        comm.run(lambda: dist.all_to_all_single(recv, send, group=group), (recv, send))
+        comm.run(lambda: dist.all_to_all_single(recv, send, group=group), (recv, send), "all_to_all")
 
 
 def _reduce_scatter_rows(t: Tensor, group, world: int, rank: int) -> Tensor:
@@ -247,10 +247,10 @@ def _reduce_scatter_rows(t: Tensor, group, world: int, rank: int) -> Tensor:
     r = t.shape[0] // world
     if dist.get_backend(group) == "nccl":
         out = torch.empty((r,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        comm.run(lambda: dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group), (out, t))
+        comm.run(lambda: dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group), (out, t), "reduce_scatter")
         return out
     full = t.clone()
-    comm.run(lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group), (full,))
+    comm.run(lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group), (full,), "all_reduce")
     return full[rank * r:(rank + 1) * r].clone()
 
 
@@ -486,13 +486,18 @@ def partial_grad_parameters(model, parallel: str = "head") -> List[torch.nn.Para
 
 
 def allreduce_partial_grads(params: List[torch.nn.Parameter], group):
-    """one flat SUM all-reduce over the gradients of the per-point / per-edge parameters"""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    """one flat SUM all-reduce over the gradients of the per-point / per-edge parameters.  A parameter without a local
+    gradient (a rank whose shard holds no edge of that operator) contributes zeros, so the flat buffer has the same size on
+    every rank, and every rank ends up with the summed gradient in ``p.grad``."""
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    comm.run(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group), (flat,))
-    torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params])
+    comm.run(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group), (flat,), "all_reduce")
+    for p, v in zip(params, flat.split([p.numel() for p in params])):
+        if p.grad is None:
+            p.grad = v.view_as(p).clone()
+        else:
+            p.grad.copy_(v.view_as(p))
 
 
 class GradBuckets:
@@ -517,6 +522,7 @@ class GradBuckets:
             self._add(cur)
         self._index = {}
         self._hooks = []
+        self._unused = None        # ids of parameters NO rank produces a gradient for (found at the first eager finish())
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[id(p)] = bi
@@ -530,29 +536,56 @@ class GradBuckets:
             off += p.numel()
         self.buckets.append(dict(params=list(ps), flat=flat, views=views, pending=len(ps), handle=None, launched=False))
 
+    def reset(self):
+        """start of a step: no gradient seen yet, nothing in flight (``forward_backward`` calls it; an exception in the
+        middle of a backward leaves stale counters otherwise)"""
+        for b in self.buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                b["handle"] = None
+            b["pending"], b["launched"] = len(b["params"]), False
+
     def _on_grad(self, p):
         b = self.buckets[self._index[id(p)]]
+        if b["launched"]:
+            # a second backward before finish() (gradient accumulation) would accumulate in place into the flat buffer
+            # while its all-reduce may still be in flight on the other communicator: refuse instead of racing
+            raise RuntimeError("GradBuckets: a gradient arrived for a bucket whose all-reduce is already launched; call "
+                               "finish() (or reset()) between two backward passes")
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
 
     def _launch(self, b):
-        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
-        if len(have) < len(b["params"]):
-            b["flat"].zero_()      # parameters without a gradient this step contribute zeros
-        if have:
-            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
-            for p, v in have:
-                p.grad = v
+        # EVERY parameter of the bucket ends up with p.grad = its view of the flat buffer -- also one that received no
+        # gradient on this rank (a shard without an edge of that operator): its view is zero-filled here and holds the other
+        # ranks' sum afterwards, so the optimizer steps it on every rank alike and the replicas cannot drift apart
+        copy_dst, copy_src = [], []
+        unused = self._unused or ()
+        for p, v in zip(b["params"], b["views"]):
+            g = p.grad
+            if g is None and id(p) in unused:
+                continue               # no rank has a gradient for it (e.g. skip_proj without long-range skips): stays None
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                copy_dst.append(v)
+                copy_src.append(g)
+            p.grad = v
+        if copy_dst:
+            torch._foreach_copy_(copy_dst, copy_src)
         flat, group = b["flat"], self.group
 
         def issue():
             b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        comm.run(issue, (flat,))
+        comm.run(issue, (flat,), "grad_bucket_issue")
         b["launched"] = True
 
     def finish(self):
-        """launch what backward left incomplete (parameters that received no gradient), then wait for every bucket"""
+        """launch what backward left incomplete (parameters that received no gradient), then wait for every bucket; after
+        it every ``p.grad`` of every bucket is a view into the flat buffer holding the sum over the ranks"""
+        if self._unused is None and not comm.capturing():
+            self._find_unused()
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
@@ -563,9 +596,19 @@ class GradBuckets:
                 if b["handle"] is not None:
                     b["handle"].wait()
                     b["handle"] = None
-        comm.run(wait, ())
+        comm.run(wait, (), "grad_bucket_wait")
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
+
+    def _find_unused(self):
+        """one tiny all-reduce at the first eager step: which parameters get a gradient on NO rank.  Those keep
+        ``grad = None`` as in an unsharded run (the optimizer skips them: reference semantics for ``skip_proj`` with
+        ``use_long_range_skip=False``, attn.py:321); a parameter that only THIS rank has no gradient for is zero-filled."""
+        ps = [p for b in self.buckets for p in b["params"]]
+        # a bucket launched from the hooks has already re-pointed its gradients: those parameters have one somewhere
+        flags = torch.tensor([0.0 if (p.grad is None) else 1.0 for p in ps], dtype=torch.float32, device=ps[0].device)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
+        self._unused = {id(p) for p, f in zip(ps, flags.tolist()) if f == 0.0}
 
     def remove(self):
         for h in self._hooks:
@@ -623,6 +666,8 @@ class ShardedStep:
 
     def forward_backward(self, batch: MeshBatch, tokens_pos: Optional[Tensor]):
         from . import functional as GF
+        if self.buckets is not None:
+            self.buckets.reset()
         pred = self.model(batch=batch, tokens_pos=tokens_pos)
         n_local = pred.shape[0]
         # global MSE = sum over ranks of (local sum of squares) / (N_total * out)
@@ -634,5 +679,5 @@ class ShardedStep:
             allreduce_partial_grads(self.partial, self.group)
         total = loss.detach().clone()
         group = self.group
-        comm.run(lambda: dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group), (total,))
+        comm.run(lambda: dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group), (total,), "all_reduce")
         return total

@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 7
+#define GAOT_ABI_VERSION 8
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -263,6 +263,9 @@ int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, void* ag, void
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
 int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream);
 int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period, gaot_stream_t stream);
+/* dst = src as a float4 grid-stride copy: the streaming-copy rate bench.py reports beside the 8 TB/s spec figure
+ * (SURVEY 8d "also report vs a measured streaming-copy peak"; no reference counterpart) */
+int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream);
 int gaot_patchify(const float* src, float* dst, int B, int D, int H, int W, int P, int C, int to_tokens,
                   gaot_stream_t stream);
 size_t gaot_mse_workspace_bytes(void);

@@ -69,9 +69,7 @@ def _worker(rank, world, port, ret):
         pred, loss = _pipeline(leaves, local, lat, n, dist.group.WORLD)
         loss.backward()
         # per-point / per-edge parameters carry partial sums; the replicated mixer already has the full gradient
-        class P:  # minimal parameter-like holder
-            def __init__(self, t): self.grad = t.grad
-        allreduce_partial_grads([P(v) for k, v in leaves.items() if not k.startswith("mix.")], dist.group.WORLD)
+        allreduce_partial_grads([v for k, v in leaves.items() if not k.startswith("mix.")], dist.group.WORLD)
         tot = loss.detach().clone()
         dist.all_reduce(tot)
         ret[rank] = dict(pred=pred.detach(), loss=tot, lo_hi=local.shard[2:4],
@@ -272,19 +270,36 @@ def _bucket_worker(rank, world, port, ret):
         torch.set_num_threads(1)
         g = torch.Generator().manual_seed(5)
         ps = [torch.nn.Parameter(torch.randn(n, 7, generator=g)) for n in (3, 50, 11, 200, 5)]
-        unused = torch.nn.Parameter(torch.randn(4, 4, generator=g))            # never receives a gradient
-        gb = GradBuckets(ps + [unused], dist.new_group(backend="gloo"), bucket_bytes=1000)
+        unused = torch.nn.Parameter(torch.randn(4, 4, generator=g))            # never receives a gradient on ANY rank
+        lonely = torch.nn.Parameter(torch.randn(6, 7, generator=g))            # a gradient on rank 1 only (rank 0's shard is empty)
+        gb = GradBuckets(ps + [unused, lonely], dist.new_group(backend="gloo"), bucket_bytes=1000)
         assert len(gb.buckets) >= 3
         x = torch.randn(7, generator=torch.Generator().manual_seed(100 + rank))
         for it in range(2):                                                     # second pass: counters were re-armed
-            for p in ps + [unused]:
+            for p in ps + [unused, lonely]:
                 p.grad = None
             n0 = comm.COUNTS["collectives"]
             loss = sum(((p * (i + 1)) @ x).sum() for i, p in enumerate(ps))
+            if rank == 1:
+                loss = loss + (lonely @ x).sum()
             loss.backward()
             launched_in_backward = comm.COUNTS["collectives"] - n0
             gb.finish()
-        ret[rank] = ([p.grad.clone() for p in ps], unused.grad is None, launched_in_backward)
+        grads_out = [p.grad.clone() for p in ps]
+        lonely_out = None if lonely.grad is None else lonely.grad.clone()
+        unused_none = unused.grad is None
+        # a second backward while a bucket is in flight must be refused, not raced
+        refused = False
+        for p in ps + [unused, lonely]:
+            p.grad = None
+        loss = sum(((p * (i + 1)) @ x).sum() for i, p in enumerate(ps)) + (lonely @ x).sum() * 0.0
+        loss.backward()
+        try:
+            sum((p @ x).sum() for p in ps).backward()
+        except RuntimeError as e:
+            refused = "already launched" in str(e)
+        gb.reset()
+        ret[rank] = (grads_out, unused_none, launched_in_backward, lonely_out, refused)
     finally:
         dist.destroy_process_group()
 
@@ -296,8 +311,11 @@ def test_grad_buckets_allreduce_from_hooks():
     mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
     xs = [torch.randn(7, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     for r in range(world):
-        grads, unused_none, in_bwd = ret[r]
+        grads, unused_none, in_bwd, lonely, refused = ret[r]
         assert unused_none and in_bwd >= 2          # complete buckets were launched while backward was still running
+        # the rank whose shard produced no gradient for `lonely` holds the other rank's gradient afterwards
+        assert lonely is not None and torch.allclose(lonely, xs[1][None, :].expand(6, 7), rtol=1e-6, atol=1e-6)
+        assert refused
         for i, gsum in enumerate(grads):
             ref = sum((i + 1) * x for x in xs)[None, :].expand_as(gsum)
             assert torch.allclose(gsum, ref, rtol=1e-6, atol=1e-6), i
