@@ -100,6 +100,7 @@ SIGNATURES = {
     "gaot_ffn_w13_swiglu": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_act_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
     "gaot_stream_copy": (_i, [_p, _p, _i64, _p]),
     "gaot_patchify": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -58,6 +58,57 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Activation ids of the GEMM epilogues and gaot_act_bwd.  0-3 are the shipped configurations' (mlp.py:330-331 F.gelu,
+// geoembed.py:37 ReLU, attn.py:156 SiLU); 4.. cover the rest of the reference's `activation_fn(name)` surface
+// (src/model/layers/mlp.py:27-35: any F.<name>) with torch's default parameters.
+enum { GAOT_ACT_NONE = 0, GAOT_ACT_GELU = 1, GAOT_ACT_RELU = 2, GAOT_ACT_SILU = 3, GAOT_ACT_TANH = 4, GAOT_ACT_LEAKY_RELU = 5,
+       GAOT_ACT_ELU = 6, GAOT_ACT_SIGMOID = 7, GAOT_ACT_SOFTPLUS = 8, GAOT_ACT_SELU = 9, GAOT_ACT_RELU6 = 10,
+       GAOT_ACT_HARDSWISH = 11, GAOT_ACT_MISH = 12, GAOT_ACT_GELU_TANH = 13, GAOT_ACT_COUNT = 14 };
+__device__ __forceinline__ float gaot_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }   // F.softplus threshold 20
+__device__ __forceinline__ float gaot_act_fwd(float v, int act) {
+    switch (act) {
+        case GAOT_ACT_GELU: return gelu_f(v);
+        case GAOT_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GAOT_ACT_SILU: return v / (1.f + __expf(-v));
+        case GAOT_ACT_TANH: return tanhf(v);
+        case GAOT_ACT_LEAKY_RELU: return v > 0.f ? v : 0.01f * v;
+        case GAOT_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case GAOT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case GAOT_ACT_SOFTPLUS: return gaot_softplus(v);
+        case GAOT_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
+        case GAOT_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+        case GAOT_ACT_HARDSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case GAOT_ACT_MISH: return v * tanhf(gaot_softplus(v));
+        case GAOT_ACT_GELU_TANH: { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); return 0.5f * v * (1.f + tanhf(u)); }
+        default: return v;
+    }
+}
+// d act(v) / dv  (torch autograd's formulas)
+__device__ __forceinline__ float gaot_act_grad(float v, int act) {
+    switch (act) {
+        case GAOT_ACT_GELU: return gelu_grad_f(v);
+        case GAOT_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+        case GAOT_ACT_SILU: { const float s = 1.f / (1.f + __expf(-v)); return s * (1.f + v * (1.f - s)); }
+        case GAOT_ACT_TANH: { const float t = tanhf(v); return 1.f - t * t; }
+        case GAOT_ACT_LEAKY_RELU: return v > 0.f ? 1.f : 0.01f;
+        case GAOT_ACT_ELU: return v > 0.f ? 1.f : expf(v);
+        case GAOT_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-v)); return s * (1.f - s); }
+        case GAOT_ACT_SOFTPLUS: return v > 20.f ? 1.f : 1.f / (1.f + expf(-v));
+        case GAOT_ACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? 1.f : 1.6732632423543772848170429916717f * expf(v));
+        case GAOT_ACT_RELU6: return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+        case GAOT_ACT_HARDSWISH: return v < -3.f ? 0.f : (v > 3.f ? 1.f : (2.f * v + 3.f) * (1.f / 6.f));
+        case GAOT_ACT_MISH: {
+            const float sp = gaot_softplus(v), t = tanhf(sp), sg = 1.f / (1.f + expf(-v));
+            return t + v * (1.f - t * t) * sg;
+        }
+        case GAOT_ACT_GELU_TANH: {
+            const float k = 0.7978845608028654f, u = k * (v + 0.044715f * v * v * v), t = tanhf(u);
+            return 0.5f * (1.f + t) + 0.5f * v * (1.f - t * t) * k * (1.f + 3.f * 0.044715f * v * v);
+        }
+        default: return 1.f;
+    }
+}
+
 // Fast erf-GELU for the per-edge MLP (192 activations per edge make erff the top VALU cost of the GNO kernels):
 // Abramowitz-Stegun 7.1.26 on u = |x|/sqrt(2) -- 1 v_rcp + 1 v_exp + 7 FMA, the exponential is shared with
 // gelu'(x).  Measured max |error| over [-8, 8] in fp32: 4.2e-7 (gelu), 3.2e-7 (gelu') -- the level of fp32 erff.

@@ -27,11 +27,13 @@ struct GemmArgs {
     const float* residual;
     int64_t M, N, K;      // K = full reduction length
     int64_t lda, ldb, ldc, ldr;
-    int act;              // 0 none, 1 gelu(erf), 2 relu, 3 silu
+    int act;              // GAOT_ACT_* (common.h): 0 none, 1 gelu(erf), 2 relu, 3 silu, 4.. the wider F.<name> surface
     int splits;           // >1: write raw partials [split][M][N] to C (ldc = N), epilogue done by k_splitk_reduce
     int64_t k_per_split;
 };
 
+// the epilogue knows the shipped activations only (a switch over the whole GAOT_ACT_* set would drag libm's tanhf / expm1f
+// into every GEMM instantiation); the others run as gaot_act_fwd on the pre-activation (functional.LinearFn)
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case 1: return gelu_f(v);
@@ -345,7 +347,7 @@ static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N
                      int64_t ldr, float* preact, int precision, void* workspace, size_t workspace_bytes,
                      gaot_stream_t stream) {
     GAOT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
-    GAOT_CHECK_ARG(act >= 0 && act <= 3, "bad activation id");
+    GAOT_CHECK_ARG(act >= 0 && act <= 3, "bad activation id (the epilogue has none / gelu / relu / silu; others: gaot_act_fwd)");
     GAOT_CHECK_ARG(precision == 0 || precision == 1, "precision must be 0 (fp32) or 1 (bf16 operands)");
     if (M == 0 || N == 0) return GAOT_OK;
     GAOT_CHECK_ARG(A && B && C, "null pointer");

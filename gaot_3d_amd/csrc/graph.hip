@@ -32,7 +32,9 @@ __device__ __forceinline__ float dist2(const float* __restrict__ tok, int lin, f
 
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_grid(const float* __restrict__ pos, int64_t N, GridDesc g,
-                                                  const float* __restrict__ tok, int* __restrict__ out) {
+                                                  const float* __restrict__ tok, int* __restrict__ out, int kout) {
+    // K = capacity of the register list (an instantiated size >= kout); the first kout entries of the sorted top-K list ARE
+    // the top-kout list, so any k <= 64 runs on the next instantiated capacity (torch_cluster takes any k, magno.py:183-189)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
@@ -79,10 +81,14 @@ __global__ __launch_bounds__(256) void k_knn_grid(const float* __restrict__ pos,
         // exact once the k-th distance is strictly inside the window (1e-4 relative slack covers the rounding of the
         // grid coordinates against the stored token coordinates), or the window is the whole grid
         const float b = bound * (1.0f - 1e-4f);
-        if (whole || (bound > 0.f && bd[K - 1] < b * b)) break;
+        float kth = bd[K - 1];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) kth = (j == kout - 1) ? bd[j] : kth;
+        if (whole || (bound > 0.f && kth < b * b)) break;
     }
 #pragma unroll
-    for (int j = 0; j < K; ++j) out[i * K + j] = bi[j];
+    for (int j = 0; j < K; ++j)
+        if (j < kout) out[i * kout + j] = bi[j];
 }
 
 // tokens within `radius` of point i, ascending token index; FILL == false: counts[i] = min(count, cap);
@@ -129,7 +135,7 @@ constexpr int BRUTE_TILE = 2048;
 
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_brute(const float* __restrict__ pos, int64_t N, const float* __restrict__ tok,
-                                                   int64_t M, int* __restrict__ out) {
+                                                   int64_t M, int* __restrict__ out, int kout) {
     __shared__ float ts[BRUTE_TILE * 3];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(256) void k_knn_brute(const float* __restrict__ pos
     }
     if (live)
 #pragma unroll
-        for (int j = 0; j < K; ++j) out[i * K + j] = bi[j];
+        for (int j = 0; j < K; ++j)
+            if (j < kout) out[i * kout + j] = bi[j];      // K = capacity >= kout (see k_knn_grid)
 }
 
 template <bool FILL>
@@ -282,13 +289,13 @@ extern "C" int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_gr
     GAOT_CHECK_ARG(make_grid(grid, g) == 0, "bad grid descriptor");
     GAOT_CHECK_ARG(num_points >= 0, "negative size");
     const int64_t m = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
-    GAOT_CHECK_ARG(k >= 1 && k <= 32 && k <= m, "k must be in [1, min(32, number of tokens)]");
+    GAOT_CHECK_ARG(k >= 1 && k <= 64 && k <= m, "k must be in [1, min(64, number of tokens)]");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
-#define GAOT_KNN(KK) GAOT_KLAUNCH((k_knn_grid<KK>), grd, blk, 0, st, pos, num_points, g, token_pos, out_idx)
-    switch (k) {
+#define GAOT_KNN(KK) GAOT_KLAUNCH((k_knn_grid<KK>), grd, blk, 0, st, pos, num_points, g, token_pos, out_idx, k)
+    switch (k <= 8 ? k : k <= 12 ? 12 : k <= 16 ? 16 : k <= 24 ? 24 : k <= 32 ? 32 : k <= 48 ? 48 : 64) {
         case 1: GAOT_KNN(1); break;
         case 2: GAOT_KNN(2); break;
         case 3: GAOT_KNN(3); break;
@@ -299,10 +306,10 @@ extern "C" int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_gr
         case 8: GAOT_KNN(8); break;
         case 12: GAOT_KNN(12); break;
         case 16: GAOT_KNN(16); break;
+        case 24: GAOT_KNN(24); break;
         case 32: GAOT_KNN(32); break;
-        default:
-            gaot_set_error("gaot_knn_grid: k = %d is not instantiated (1-8, 12, 16, 32)", k);
-            return GAOT_ERR_UNSUPPORTED;
+        case 48: GAOT_KNN(48); break;
+        default: GAOT_KNN(64); break;
     }
 #undef GAOT_KNN
     GAOT_LAUNCH_CHECK();
@@ -313,13 +320,13 @@ extern "C" int gaot_knn_brute(const float* pos, int64_t num_points, const float*
                               int32_t* out_idx, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(num_points >= 0 && num_tokens >= 1, "bad size");
-    GAOT_CHECK_ARG(k >= 1 && k <= 32 && k <= num_tokens, "k must be in [1, min(32, number of tokens)]");
+    GAOT_CHECK_ARG(k >= 1 && k <= 64 && k <= num_tokens, "k must be in [1, min(64, number of tokens)]");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
-#define GAOT_KNNB(KK) GAOT_KLAUNCH((k_knn_brute<KK>), grd, blk, 0, st, pos, num_points, token_pos, num_tokens, out_idx)
-    switch (k) {
+#define GAOT_KNNB(KK) GAOT_KLAUNCH((k_knn_brute<KK>), grd, blk, 0, st, pos, num_points, token_pos, num_tokens, out_idx, k)
+    switch (k <= 8 ? k : k <= 12 ? 12 : k <= 16 ? 16 : k <= 24 ? 24 : k <= 32 ? 32 : k <= 48 ? 48 : 64) {
         case 1: GAOT_KNNB(1); break;
         case 2: GAOT_KNNB(2); break;
         case 3: GAOT_KNNB(3); break;
@@ -330,10 +337,10 @@ extern "C" int gaot_knn_brute(const float* pos, int64_t num_points, const float*
         case 8: GAOT_KNNB(8); break;
         case 12: GAOT_KNNB(12); break;
         case 16: GAOT_KNNB(16); break;
+        case 24: GAOT_KNNB(24); break;
         case 32: GAOT_KNNB(32); break;
-        default:
-            gaot_set_error("gaot_knn_brute: k = %d is not instantiated (1-8, 12, 16, 32)", k);
-            return GAOT_ERR_UNSUPPORTED;
+        case 48: GAOT_KNNB(48); break;
+        default: GAOT_KNNB(64); break;
     }
 #undef GAOT_KNNB
     GAOT_LAUNCH_CHECK();

@@ -321,18 +321,20 @@ __global__ void k_swiglu_bwd_bf16(const unsigned short* __restrict__ ag, const u
     reinterpret_cast<uint4*>(dag + r * 2 * F + F)[c] = pack8(dg);
 }
 
+// h = act(z) for the activations the GEMM epilogue does not carry (GAOT_ACT_* >= 4)
+__global__ void k_act_fwd(const float* __restrict__ z, float* __restrict__ h, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    h[i] = gaot_act_fwd(z[i], act);
+}
+
 // dz = dh * act'(z)
 __global__ void k_act_bwd(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, int64_t n,
                           int act) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = z[i];
-    float d;
-    if (act == 1) d = gelu_grad_f(v);
-    else if (act == 2) d = v > 0.f ? 1.f : 0.f;
-    else if (act == 3) { const float s = sigmoid_f(v); d = s * (1.f + v * (1.f - s)); }
-    else d = 1.f;
-    dz[i] = dh[i] * d;
+    dz[i] = dh[i] * gaot_act_grad(v, act);
 }
 
 // out = a + alpha * b (b may be broadcast over rows with period `period` elements; period == n: plain)
@@ -750,9 +752,19 @@ extern "C" int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, i
     return GAOT_OK;
 }
 
+extern "C" int gaot_act_fwd(const float* z, float* h, int64_t n, int act, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(n >= 0 && act >= 0 && act < GAOT_ACT_COUNT, "bad argument");
+    if (n == 0) return GAOT_OK;
+    GAOT_CHECK_ARG(z && h, "null pointer");
+    GAOT_KLAUNCH(k_act_fwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, h, n, act);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
 extern "C" int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream) {
     GAOT_ENTER();
-    GAOT_CHECK_ARG(n >= 0 && act >= 0 && act <= 3, "bad argument");
+    GAOT_CHECK_ARG(n >= 0 && act >= 0 && act < GAOT_ACT_COUNT, "bad argument");
     if (n == 0) return GAOT_OK;
     GAOT_CHECK_ARG(z && dh && dz, "null pointer");
     GAOT_KLAUNCH(k_act_bwd, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, dh, dz, n, act);

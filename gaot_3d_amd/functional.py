@@ -100,7 +100,12 @@ class LinearFn(Function):
             if not res.is_contiguous():
                 res = res.contiguous()
         w = _wb(w, precision)
-        if act:
+        if act > 3:     # outside the GEMM epilogue's set (ops.ACT): pre-activation from the GEMM, activation as its own pass
+            if res is not None:
+                raise GaotError("linear: a residual together with an activation outside none / gelu / relu / silu")
+            z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, 0, precision=precision)
+            y = ops.act_fwd(z, act)
+        elif act:
             y, z = ops.gemm(x2, w, m, n, k, k, k, False, True, bias, act, residual=res, ldr=n, want_preact=True,
                             precision=precision)
         else:

@@ -136,28 +136,51 @@ class IntegralTransform(nn.Module):
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
     def _forward_general(self, fcs, y_pos, x_pos, f_y, g):
-        """integral_transform.py:114-171 on per-edge tensors (dst-sorted order)"""
+        """integral_transform.py:114-171 on per-edge tensors (dst-sorted order).  Coordinates of dimension 1 / 2 (the
+        reference's default is ``gno_coord_dim: 2``, magno.py:28) are padded with zeros to the kernels' 3-D rows and the first
+        layer's weight gets zero columns for the padding: every added product is exactly 0, as in ``_fused_plan``."""
         tt = self.transform_type
         act = activation_name(getattr(self.channel_mlp, "non_linearity", "gelu"))
         pdrop = getattr(self.channel_mlp, "dropout_p", 0.0)
-        k = EO.EdgeInputFn.apply(y_pos, x_pos, f_y if (f_y is not None and tt != "linear") else None, g)   # :146-152
+        cdp = y_pos.shape[1]
+        if cdp > 3 or x_pos.shape[1] != cdp:
+            raise NotImplementedError(f"coordinates of dimension {tuple(y_pos.shape[1:])} / {tuple(x_pos.shape[1:])}: 1..3 supported")
+        y3, x3 = y_pos, x_pos
+        if cdp < 3:
+            y3 = torch.nn.functional.pad(y_pos, (0, 3 - cdp))
+            x3 = torch.nn.functional.pad(x_pos, (0, 3 - cdp))
+        with_f = f_y is not None and tt != "linear"
+        k = EO.EdgeInputFn.apply(y3, x3, f_y if with_f else None, g)                                        # :146-152
         for i, fc in enumerate(fcs):                                                                        # :154
             w = fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight
+            if i == 0 and cdp < 3:      # [src coords | query coords | features] -> [src, 0.. | query, 0.. | features]
+                nf = w.shape[1] - 2 * cdp
+                cols = torch.tensor(list(range(cdp)) + [3 + j for j in range(cdp)] + [6 + j for j in range(nf)], device=w.device)
+                w = w.new_zeros(w.shape[0], 6 + nf).index_copy(1, cols, w)
             k = GF.linear(k, w, fc.bias, act=act if i < len(fcs) - 1 else None)
             k = GF.dropout(k, pdrop, self.training)
         if f_y is not None and tt != "nonlinear_kernelonly":                                                # :156-157
             k = EO.MulFn.apply(k, EO.GatherFn.apply(f_y, g, 0))
         mode = EO.MEAN
         if self.use_attn:                                                                                   # :126-142
-            cd = self.coord_dim
-            if cd != 3:
-                raise NotImplementedError("use_attn on the HIP path needs coord_dim = 3")
+            # the scores see the first coord_dim coordinates only (integral_transform.py:128-129: `[:, :self.coord_dim]`)
+            cd = int(self.coord_dim) if self.coord_dim is not None else cdp
+            if not 1 <= cd <= min(3, cdp):
+                raise ValueError(f"coord_dim {cd} with {cdp}-dimensional coordinates")
+            xa, ya = x3, y3
+            if cd < cdp:             # drop the coordinates the scores do not see, keep the kernels' 3-D rows
+                xa = torch.nn.functional.pad(x_pos[:, :cd], (0, 3 - cd))
+                ya = torch.nn.functional.pad(y_pos[:, :cd], (0, 3 - cd))
             if self.attention_type == "dot_product":
-                qn = GF.linear(x_pos, self.query_proj.weight, self.query_proj.bias, precision=0)
-                kn = GF.linear(y_pos, self.key_proj.weight, self.key_proj.bias, precision=0)
+                wq, wk = self.query_proj.weight, self.key_proj.weight
+                if cd < 3:           # Linear(coord_dim -> 64) on zero-padded coordinates: zero columns, exact
+                    wq = torch.nn.functional.pad(wq, (0, 3 - cd))
+                    wk = torch.nn.functional.pad(wk, (0, 3 - cd))
+                qn = GF.linear(xa.contiguous(), wq, self.query_proj.bias, precision=0)
+                kn = GF.linear(ya.contiguous(), wk, self.key_proj.bias, precision=0)
                 sc = EO.RowDotFn.apply(EO.GatherFn.apply(qn, g, 1), EO.GatherFn.apply(kn, g, 0), self.scaling_factor)
             else:
-                sc = EO.edge_coords(y_pos, x_pos, g, 2)          # cosine of the raw coordinates: no parameters
+                sc = EO.edge_coords(ya.contiguous(), xa.contiguous(), g, 2)   # cosine of the raw coordinates: no parameters
             k = EO.RowScaleFn.apply(k, EO.SegmentSoftmaxFn.apply(sc, g))                                    # :159-160
             mode = EO.SUM                                                                                   # :163
         return EO.SegmentReduceFn.apply(k, g, mode)

@@ -12,25 +12,37 @@ _FP32 = 0
 
 def activation_name(fn) -> str:
     """The reference passes activations as callables (``non_linearity=F.gelu``, mlp.py:227-335,
-    ``channel_mlp_non_linearity=F.gelu``, integral_transform.py:35); the HIP kernels take an activation id.  Accepts the
-    callable (F.gelu / F.relu / F.silu, torch.relu, nn.GELU() / nn.ReLU() / nn.SiLU() instances) or its name."""
+    ``channel_mlp_non_linearity=F.gelu``, integral_transform.py:35) or builds them from a name with ``activation_fn``
+    (mlp.py:27-35: "none", "swish", or any ``F.<name>``); the HIP kernels take an activation id (csrc/common.h GAOT_ACT_*).
+    Accepts the callable (F.gelu, torch.tanh, nn.ELU() ... with torch's default parameters) or its name.  The fused GNO /
+    projection kernels are built for erf-GELU; every other activation runs on the general per-edge / per-node path."""
     import torch.nn.functional as F
+    from ...ops import ACT
     if fn is None:
         return "none"
     if isinstance(fn, str):
-        name = {"swish": "silu"}.get(fn.lower(), fn.lower())
-    elif fn in (F.gelu,) or isinstance(fn, nn.GELU):
-        if isinstance(fn, nn.GELU) and getattr(fn, "approximate", "none") != "none":
-            raise NotImplementedError("tanh-approximated GELU: the HIP kernels evaluate the erf form (F.gelu default)")
-        name = "gelu"
-    elif fn in (F.relu, torch.relu) or isinstance(fn, nn.ReLU):
-        name = "relu"
-    elif fn in (F.silu,) or isinstance(fn, nn.SiLU):
-        name = "silu"
+        name = {"swish": "silu", "identity": "none"}.get(fn.lower(), fn.lower())
+    elif isinstance(fn, nn.GELU):
+        name = "gelu" if getattr(fn, "approximate", "none") == "none" else "gelu_tanh"
+    elif isinstance(fn, nn.Identity):
+        name = "none"
+    elif isinstance(fn, nn.Module):
+        table = {nn.ReLU: "relu", nn.SiLU: "silu", nn.Tanh: "tanh", nn.LeakyReLU: "leaky_relu", nn.ELU: "elu",
+                 nn.Sigmoid: "sigmoid", nn.Softplus: "softplus", nn.SELU: "selu", nn.ReLU6: "relu6",
+                 nn.Hardswish: "hardswish", nn.Mish: "mish"}
+        name = table.get(type(fn))
+        defaults = {"leaky_relu": ("negative_slope", 0.01), "elu": ("alpha", 1.0)}
+        if name in defaults and getattr(fn, defaults[name][0]) != defaults[name][1]:
+            raise NotImplementedError(f"{fn!r}: only torch's default parameters have a HIP kernel")
+        if name == "softplus" and (fn.beta != 1.0 or fn.threshold != 20.0):
+            raise NotImplementedError(f"{fn!r}: only torch's default parameters have a HIP kernel")
     else:
-        raise NotImplementedError(f"activation {fn!r} has no HIP kernel (supported: gelu, relu, silu)")
-    if name not in ("gelu", "relu", "silu", "none"):
-        raise NotImplementedError(f"activation '{name}' has no HIP kernel (supported: gelu, relu, silu)")
+        table = {F.gelu: "gelu", F.relu: "relu", torch.relu: "relu", F.silu: "silu", F.tanh: "tanh", torch.tanh: "tanh",
+                 F.leaky_relu: "leaky_relu", F.elu: "elu", F.sigmoid: "sigmoid", torch.sigmoid: "sigmoid",
+                 F.softplus: "softplus", F.selu: "selu", F.relu6: "relu6", F.hardswish: "hardswish", F.mish: "mish"}
+        name = table.get(fn)
+    if name is None or name not in ACT:
+        raise NotImplementedError(f"activation {fn!r} has no HIP kernel (supported: {sorted(k for k in ACT if k)})")
     return name
 
 

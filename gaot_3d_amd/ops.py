@@ -214,7 +214,9 @@ def get_precision() -> str:
     return "bf16" if _PRECISION["mode"] else "fp32"
 
 
-ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3}
+# activation ids of the GEMM epilogues / gaot_act_bwd (csrc/common.h GAOT_ACT_*)
+ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3, "tanh": 4, "leaky_relu": 5, "elu": 6, "sigmoid": 7, "softplus": 8,
+       "selu": 9, "relu6": 10, "hardswish": 11, "mish": 12, "gelu_tanh": 13}
 
 
 def gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_trans: bool, b_trans: bool,
@@ -252,6 +254,14 @@ def colsum(x: Tensor, m: int, n: int, ld: int) -> Tensor:
     ws = _ws(lib.gaot_colsum_workspace_bytes(m, n), x.device)
     check(lib.gaot_colsum(_ptr(x), m, n, ld, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_colsum")
     return out
+
+
+def act_fwd(z: Tensor, act: int) -> Tensor:
+    """h = act(z) for the activation ids the GEMM epilogue does not carry (ACT >= 4)"""
+    lib = _lib.load()
+    h = torch.empty_like(z)
+    check(lib.gaot_act_fwd(_ptr(z), _ptr(h), z.numel(), act, _stream()), "gaot_act_fwd")
+    return h
 
 
 def act_bwd(z: Tensor, dh: Tensor, act: int) -> Tensor:

@@ -261,6 +261,11 @@ int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stre
 int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, void* ag, void* u, int64_t rows, int64_t lda, int64_t ldw, int F,
                         gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
+/* Activations outside the GEMM epilogue's none / gelu / relu / silu: the rest of the reference's `activation_fn(name)`
+ * surface (src/model/layers/mlp.py:27-35: any F.<name>, torch's default parameters).  act ids: 0 none, 1 gelu (erf), 2 relu,
+ * 3 silu, 4 tanh, 5 leaky_relu, 6 elu, 7 sigmoid, 8 softplus, 9 selu, 10 relu6, 11 hardswish, 12 mish, 13 gelu (tanh form).
+ * gaot_act_fwd: h = act(z); gaot_act_bwd: dz = dh * act'(z) (every id). */
+int gaot_act_fwd(const float* z, float* h, int64_t n, int act, gaot_stream_t stream);
 int gaot_act_bwd(const float* z, const float* dh, float* dz, int64_t n, int act, gaot_stream_t stream);
 int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, int64_t period, gaot_stream_t stream);
 /* dst = src as a float4 grid-stride copy: the streaming-copy rate bench.py reports beside the 8 TB/s spec figure

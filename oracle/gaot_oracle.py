@@ -96,10 +96,21 @@ def _segment_softmax(scores: Tensor, index: Tensor, dim_size: int) -> Tensor:
     return e / esum[index]
 
 
+def activation_fn(name: str):
+    """the reference's name -> callable rule, src/model/layers/mlp.py:27-35: "none" -> identity, "swish" -> SiLU, else F.<name>"""
+    if name == "none":
+        return lambda x: x
+    if name == "swish":
+        return F.silu
+    if hasattr(F, name):
+        return getattr(F, name)
+    raise ValueError(f"Activation function {name} not found")
+
+
 def integral_transform(sd: SD, prefix: str, y_pos: Tensor, x_pos: Tensor, edge_index: Tensor,
                        f_y: Optional[Tensor], transform_type: str = "linear",
                        use_attn: Optional[bool] = None, coord_dim: int = 3,
-                       attention_type: str = "cosine") -> Tensor:
+                       attention_type: str = "cosine", act=F.gelu) -> Tensor:
     nq = x_pos.shape[0]
     if edge_index.shape[1] == 0:  # integral_transform.py:106-112
         n = _n_fcs(sd, prefix + "channel_mlp.")
@@ -125,7 +136,7 @@ def integral_transform(sd: SD, prefix: str, y_pos: Tensor, x_pos: Tensor, edge_i
     agg = torch.cat([rep, slf], dim=-1)  # :146  (source coords first)
     if feat is not None and transform_type in ("nonlinear", "nonlinear_kernelonly"):
         agg = torch.cat([agg, feat], dim=-1)  # :148-152
-    k = channel_mlp(sd, prefix + "channel_mlp.", agg)  # :154
+    k = channel_mlp(sd, prefix + "channel_mlp.", agg, act)  # :154 (channel_mlp_non_linearity, :35)
     if feat is not None and transform_type != "nonlinear_kernelonly":
         k = k * feat          # :156-157
     if attw is not None:

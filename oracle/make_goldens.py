@@ -389,6 +389,61 @@ def gno_shapes_case():
     save("gno_shapes", dict(name="gno_shapes", variants=variants), arrays)
 
 
+def gno_variants_case():
+    """IntegralTransform variants the reference's config surface reaches beyond the shipped yaml: segment-softmax attention
+    weights on coordinates of dimension 2 / 1 (`gno_coord_dim: 2` is the reference's default, magno.py:28; scores slice
+    `[:, :coord_dim]`, integral_transform.py:126-142) and kernel MLPs built with other activations through the reference's own
+    `activation_fn(name)` (mlp.py:27-35: "swish", "none", any F.<name>)"""
+    from src.model.layers.integral_transform import IntegralTransform
+    from src.model.layers.mlp import activation_fn
+
+    gen = torch.Generator().manual_seed(23)
+    torch.manual_seed(23)
+    lat3 = latent_grid((4, 4, 3))
+    pos3 = torch.rand(210, 3, generator=gen) * 2 - 1
+    pos3, enc = variable_degree_graph(pos3, lat3, 0.45, heavy_token=5, n_heavy=37, gen=gen)
+    arrays = {"in/pos3": pos3, "in/lat3": lat3, "in/edge_index": enc.to(torch.int32)}
+    variants = []
+    cases = [("attn_cos_cd2", 2, [4, 64, 64, 32], "linear", True, "cosine", "gelu"),
+             ("attn_dot_cd2", 2, [4, 64, 64, 16], "linear", True, "dot_product", "gelu"),
+             ("attn_cos_cd1", 1, [2, 64, 32], "linear", True, "cosine", "gelu"),
+             ("attn_dot_cd2_nonlinear", 2, [4 + 32, 64, 32], "nonlinear", True, "dot_product", "gelu"),
+             ("act_tanh", 3, [6, 64, 64, 32], "linear", None, "cosine", "tanh"),
+             ("act_leaky_relu", 3, [6, 64, 32], "linear", None, "cosine", "leaky_relu"),
+             ("act_elu_cd2", 2, [4, 64, 64, 32], "linear", None, "cosine", "elu"),
+             ("act_swish", 3, [6, 64, 32], "linear", None, "cosine", "swish"),
+             ("act_none", 3, [6, 64, 32], "linear", None, "cosine", "none"),
+             ("act_softplus_attn", 3, [6, 64, 32], "linear", True, "cosine", "softplus"),
+             ("act_sigmoid", 3, [6, 48, 32], "linear", None, "cosine", "sigmoid"),
+             ("act_selu", 3, [6, 64, 32], "linear", None, "cosine", "selu"),
+             ("act_mish", 3, [6, 64, 32], "linear", None, "cosine", "mish"),
+             ("act_hardswish", 3, [6, 64, 32], "linear", None, "cosine", "hardswish"),
+             ("act_relu6", 3, [6, 64, 32], "linear", None, "cosine", "relu6")]
+    for tag, cd, layers, tt, use_attn, atype, act in cases:
+        it = IntegralTransform(channel_mlp_layers=layers, channel_mlp_non_linearity=activation_fn(act), transform_type=tt,
+                               use_attn=use_attn, coord_dim=cd, attention_type=atype)
+        with torch.no_grad():
+            for p in it.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        y, x = pos3[:, :cd].contiguous(), lat3[:, :cd].contiguous()
+        f = torch.randn(pos3.shape[0], 32 if tt == "nonlinear" else layers[-1], generator=gen).requires_grad_(True)
+        out = it(y_pos=y, x_pos=x, edge_index=enc, f_y=f)
+        w = torch.randn(out.shape, generator=gen)
+        (out * w).sum().backward()
+        arrays[f"in/{tag}/f_y"] = f.detach()
+        arrays[f"in/{tag}/w"] = w
+        arrays[f"out/{tag}/out"] = out
+        arrays[f"grad/{tag}/f_y"] = f.grad
+        for k, v in it.state_dict().items():
+            arrays[f"sd/{tag}/{k}"] = v
+        for k, g in grads_of(it).items():
+            arrays[f"grad/{tag}/{k}"] = g
+        variants.append(dict(tag=tag, coord_dim=cd, layers=layers, transform_type=tt, use_attn=bool(use_attn),
+                             attention_type=atype, act=act))
+    save("gno_variants", dict(name="gno_variants", variants=variants), arrays)
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not present: goldens can only be regenerated in the authoring container"
     install_stubs()
@@ -406,8 +461,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "gno_shapes":
         gno_shapes_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "gno_variants":
+        gno_variants_case()
+        return
     ops_case()
     gno_shapes_case()
+    gno_variants_case()
     attn_dropout_case()
     lr_schedule_case()
     cond_norm_case()

@@ -345,3 +345,50 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
         n += 1
     print(f"[parity] configs2_2rank: {n} gradient tensors, worst norm deviation {worst:.2e}")
     assert n > 100
+
+
+def test_configs4_point_sharded_two_ranks_one_gpu(tmp_path):
+    """BASELINE configs[4] in its POINT-SHARDED form (only the single-GPU 8 M-point form ran under -m gpu): the
+    8 000 000-point, 4-field sample (64 M edges per direction, L = 10, bf16) split over two ranks -- both on this GPU, gloo;
+    points / edges by range, latent sums all-reduced, Transformer by token rows, attention by heads with the bf16 exchange --
+    against the unsharded bf16 step on the same weights: loss 2e-3, every gradient tensor's norm 3e-2, leading values."""
+    import gaot_3d_amd
+    import bench
+    import test_model_gpu as TM
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model import init_model
+    n = 8_000_000
+    batch, tokens = make_synthetic_sample(n, LATENT, k=KNN, seed=1, device=DEV, out_channels=4)
+    tokens = tokens.to(DEV)
+    torch.manual_seed(0)
+    model = init_model(6, 4, "gaot_3d", bench.model_config(LATENT, 10, KNN, 0.0, "cfg4")).to(DEV).train()
+    gaot_3d_amd.set_precision("bf16")
+    try:
+        gaot_3d_amd.clear_graph_cache(batch)
+        loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens), batch.x)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    ref_loss = float(loss.detach())
+    ref = {k: (float(p.grad.detach().double().norm()), p.grad.detach().cpu().double().flatten()[:64].clone(),
+               float(p.grad.detach().abs().max())) for k, p in model.named_parameters() if p.grad is not None}
+    del model, batch, loss
+    torch.cuda.empty_cache()
+    got = TM._run_shard_workers(tmp_path, 2, 29593, GAOT_TEST_PREC="bf16", GAOT_TEST_CFG="bench", GAOT_TEST_WORKLOAD="cfg4",
+                                GAOT_TEST_PARALLEL="seq", GAOT_TEST_POINTS=n, GAOT_TEST_LATENT=",".join(str(v) for v in LATENT),
+                                GAOT_TEST_K=KNN, GAOT_TEST_LAYERS=10, GAOT_TEST_SEED=1, GAOT_TEST_OUT=4)
+    print(f"[parity] configs4_2rank/loss: {got['loss']:.8f} vs {ref_loss:.8f}")
+    assert abs(got["loss"] - ref_loss) <= 2e-3 * abs(ref_loss)
+    worst, cnt = 0.0, 0
+    for k, (nrm, head_ref, peak) in ref.items():
+        assert k in got["norms"], k
+        rel = abs(got["norms"][k] - nrm) / (nrm + 1e-30)
+        worst = max(worst, rel)
+        assert rel <= 3e-2, (k, got["norms"][k], nrm)
+        head = torch.tensor(got["grads"][k], dtype=torch.float64)
+        assert float((head - head_ref).abs().max()) <= 5e-2 * peak + 1e-9, k
+        cnt += 1
+    print(f"[parity] configs4_2rank: {cnt} gradient tensors, worst norm deviation {worst:.2e}")
+    assert cnt > 100

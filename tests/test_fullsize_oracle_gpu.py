@@ -95,7 +95,7 @@ def test_attention_full_sequence_vs_fp64_oracle(precision, p):
         PAR.close_peak(f"{tag}/out", out, ref, 2e-2, rel_l2=1e-2)
         for nm, lo, hi in names:
             PAR.cosine(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 0.999)
-            PAR.close_peak(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 5e-2)
+            PAR.close_peak(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 2e-2)   # achieved ~8e-3 (2e-2 of peak)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
@@ -142,7 +142,7 @@ def test_attention_fused_backward_vs_fp64_oracle(p):
     for blk, nm in ((0, "dq"), (1, "dk"), (2, "dv")):
         got, want = g_fused[:, cols(blk)], gref[:, 32 * blk:32 * (blk + 1)]
         PAR.cosine(f"{tag}/{nm} vs fp64", got, want, 0.999)
-        PAR.close_peak(f"{tag}/{nm} vs fp64", got, want, 5e-2)
+        PAR.close_peak(f"{tag}/{nm} vs fp64", got, want, 2e-2)   # achieved ~8e-3 (2e-2 of peak)
 
 
 @pytest.mark.parametrize("b,s,h,hkv,p", [(8, 2085, 8, 4, 0.1), (2, 4133, 8, 8, 0.0), (1, 16384 - 37, 8, 4, 0.1)])
@@ -412,5 +412,63 @@ def test_model_full_size_vs_oracle():
             PAR.close_peak("fullsize_vs_oracle_bf16/pred", pred, pred_r, 3e-2, rel_l2=2e-2)
             PAR.close("fullsize_vs_oracle_bf16/loss", loss, loss_r, 1e-2, 0.0)
             PAR.grads_cosine("fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.999, per_tensor=0.99)
+        del m, pred, loss, grads
+        torch.cuda.empty_cache()
+
+
+def test_configs3_full_size_vs_oracle():
+    """The WHOLE configs[3] step (only operator-by-operator before) -- 500 000 points, radius-graph encoder capped
+    at 32 points per token, bidirectional decoder (variable degree, empty rows), statistical GeoEmbed on BOTH sides, 5 input
+    channels (pos + [Mach, AOA]), L = 10, RoPE, attention dropout off -- against the oracle (CPU restatement of the reference,
+    fp32; geoembed.py:99-182, magno.py:468-600, 691-798) on the same sample, graphs and weights: predictions, loss and every
+    parameter gradient, fp32 kernels 2e-4 of peak / gradient cosine 0.99999, bf16 kernels at the bf16 bar."""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.model import init_model
+    import bench
+    import parity as PAR
+    why = _fullsize_oracle_skip_reason()
+    if why is not None:
+        print(f"[parity] test_configs3_full_size_vs_oracle skipped: {why}")
+        pytest.skip(why)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    latent, n, k, layers = (64, 64, 32), 500000, 8, 10
+    cfg = bench.model_config(latent, layers, k, 0.0, "cfg3")
+    torch.manual_seed(0)
+    model = init_model(5, 1, "gaot_3d", cfg)
+    bd, tk = bench.make_workload_sample("cfg3", n, latent, k, 0, DEV)       # graphs built by the device kernels
+    batch, tokens = bd.to("cpu"), tk.cpu()
+    print(f"[parity] configs[3] graphs: encoder {batch.encoder_edge_index_s0.shape[1]} edges, decoder "
+          f"{batch.decoder_edge_index_s0.shape[1]} edges")
+    sd = {kk: v.clone() for kk, v in model.state_dict().items()}
+    with torch.no_grad():
+        p0 = orc.gaot3d_forward(sd, cfg, batch, tokens)
+    last = model.decoder.projection.fcs[-1]
+    PAR.unit_scale_last_layer(last.weight, last.bias, float(p0.std()))
+    sd = {kk: v.clone() for kk, v in model.state_dict().items()}
+    pred_r, loss_r, grads_r = orc.train_step_grads(sd, cfg, batch, tokens)
+    print(f"[parity] configs[3] full-size oracle: loss={float(loss_r):.6f} pred std={float(pred_r.std()):.4f}")
+    for precision in ("fp32", "bf16"):
+        gaot_3d_amd.set_precision(precision)
+        try:
+            m = init_model(5, 1, "gaot_3d", cfg)
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval().train()
+            gaot_3d_amd.clear_graph_cache(bd)
+            pred = m(batch=bd, tokens_pos=tk)
+            loss = GF.mse_loss(pred, bd.x)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            gaot_3d_amd.set_precision("fp32")
+        grads = {kk: p.grad for kk, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+        if precision == "fp32":
+            PAR.close_peak("configs3_fullsize_vs_oracle_fp32/pred", pred, pred_r, 2e-4, rel_l2=1e-4)
+            PAR.close("configs3_fullsize_vs_oracle_fp32/loss", loss, loss_r, 1e-5, 0.0)
+            PAR.grads_cosine("configs3_fullsize_vs_oracle_fp32/grads", grads, grads_r, 0.99999, per_tensor=0.9999)
+        else:
+            PAR.close_peak("configs3_fullsize_vs_oracle_bf16/pred", pred, pred_r, 3e-2, rel_l2=2e-2)
+            PAR.close("configs3_fullsize_vs_oracle_bf16/loss", loss, loss_r, 1e-2, 0.0)
+            PAR.grads_cosine("configs3_fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.999, per_tensor=0.99)
         del m, pred, loss, grads
         torch.cuda.empty_cache()

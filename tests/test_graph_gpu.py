@@ -29,7 +29,7 @@ def _grid(dims, lo=(-1.0, -1.0, -1.0), hi=(1.0, 1.0, 1.0)):
 
 @pytest.mark.parametrize("dims,lo,hi", [((8, 8, 8), (-1, -1, -1), (1, 1, 1)), ((16, 16, 8), (-1, -1, -1), (1, 1, 1)),
                                          ((5, 9, 3), (-0.5, -1.0, 0.0), (0.7, 1.0, 0.4)), ((6, 1, 7), (-1, 0, -1), (1, 0, 1))])
-@pytest.mark.parametrize("k", [1, 4, 8, 16])
+@pytest.mark.parametrize("k", [1, 4, 8, 11, 16, 27, 40, 64])     # torch_cluster takes any k (magno.py:183-189): any k <= 64 here
 def test_knn_to_grid_matches_bruteforce(dims, lo, hi, k):
     from gaot_3d_amd import graph
     lat = _grid(dims, lo, hi)
@@ -107,7 +107,8 @@ def test_irregular_tokens_and_cpu_inputs_raise():
     with pytest.raises(GaotError):
         graph.knn_to_grid(_points(10, 0), g, 2)        # CPU tensor: no fallback
     with pytest.raises(GaotError):
-        graph.knn_to_grid(_points(10, 0).to(DEV), g, 9)   # k not instantiated
+        graph.knn_to_grid(_points(10, 0).to(DEV), g, 65)  # k beyond the largest register list (64)
+    assert graph.knn_to_grid(_points(10, 0).to(DEV), g, 9).shape == (10, 9)   # any k <= 64 runs (round 3: 1-8, 12, 16, 32 only)
 
 
 def test_full_size_knn_feeds_the_model_graph():
@@ -302,6 +303,13 @@ def test_arbitrary_token_sets_on_the_device(strategy, is_decoder):
     a = fn(strategy, p, graph.as_latent_grid(grid, dims), 0.45, 3)
     b = fn(strategy, p, graph.TokenSet(grid), 0.45, 3)
     assert torch.equal(a, b)
+    if strategy == "knn" and not is_decoder:      # k outside the instantiated register lists, non-grid token set
+        for kk in (9, 21, 50):
+            ref_k = strategy_fn("knn", pos, bp, lat, bl, 0.3, kk, False)
+            got_k = strategy_fn("knn", pos.to(DEV), bp.to(DEV), lat.to(DEV), bl.to(DEV), 0.3, kk, False).cpu().long()
+            assert got_k.shape == ref_k.shape and _as_set(got_k) == _as_set(ref_k), kk
+            assert torch.equal(graph.knn_to_grid(p, graph.as_latent_grid(grid, dims), kk),
+                               graph.knn_to_grid(p, graph.TokenSet(grid), kk)), kk
 
 
 def test_model_with_custom_token_set_builds_its_graphs_on_the_device():

@@ -206,11 +206,12 @@ gaot_3d_amd.set_precision(E("GAOT_TEST_PREC", "fp32"))
 npts, latent, k = int(E("GAOT_TEST_POINTS", "3001")), tuple(int(v) for v in E("GAOT_TEST_LATENT", "8,8,4").split(",")), int(E("GAOT_TEST_K", "4"))
 if E("GAOT_TEST_CFG") == "bench":    # the benchmark's model section (pressure.yaml), dropout off
     import bench
-    cfg = bench.model_config(latent, int(E("GAOT_TEST_LAYERS", "10")), k, 0.0)
+    cfg = bench.model_config(latent, int(E("GAOT_TEST_LAYERS", "10")), k, 0.0, E("GAOT_TEST_WORKLOAD", "cfg1"))
 else:
     cfg = T.small_config(hidden=int(E("GAOT_TEST_HIDDEN", "0")) or None, layers=int(E("GAOT_TEST_LAYERS", "2")), latent=latent, k=k)
-model = init_model(6, 1, "gaot_3d", cfg).to(dev).train()
-batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=int(E("GAOT_TEST_SEED", "1")), device="cuda:0")
+nout = int(E("GAOT_TEST_OUT", "1"))
+model = init_model(6, nout, "gaot_3d", cfg).to(dev).train()
+batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=int(E("GAOT_TEST_SEED", "1")), device="cuda:0", out_channels=nout)
 tokens = tokens.to(dev)
 local = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
 del batch

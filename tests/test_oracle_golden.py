@@ -87,6 +87,26 @@ def test_integral_transform_other_shapes():
                 close(sd[k].grad, gr, 1e-3, 1e-5)
 
 
+def test_integral_transform_attention_low_dim_and_activations():
+    """attention weights on coordinates of dimension 2 / 1 and kernel MLPs with the other activations the reference's
+    `activation_fn` builds (tests/golden/gno_variants.npz, captured from the reference's IntegralTransform)"""
+    meta, g = gio.load("gno_variants")
+    ei = g["in"]["edge_index"]
+    for v in meta["variants"]:
+        tag, cd = v["tag"], v["coord_dim"]
+        y, x = g["in"]["pos3"][:, :cd].contiguous(), g["in"]["lat3"][:, :cd].contiguous()
+        sd = {k: t.clone().requires_grad_(True) for k, t in gio.sub(g["sd"], tag).items()}
+        f = g["in"][f"{tag}/f_y"].clone().requires_grad_(True)
+        out = orc.integral_transform(sd, "", y, x, ei, f, v["transform_type"], v["use_attn"] or None, cd, v["attention_type"],
+                                     act=orc.activation_fn(v["act"]))
+        close(out, g["out"][f"{tag}/out"])
+        (out * g["in"][f"{tag}/w"]).sum().backward()
+        close(f.grad, g["grad"][f"{tag}/f_y"], 1e-3, 1e-6)
+        for k, gr in gio.sub(g["grad"], tag).items():
+            if k != "f_y":
+                close(sd[k].grad, gr, 1e-3, 1e-5)
+
+
 def test_geoembed_variants():
     meta, g = gio.load("ops")
     pos, lat, ei = g["in"]["pos"], g["in"]["lat"], g["in"]["edge_index"]
