@@ -1059,26 +1059,40 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
 // LDS: stage tiles 8 KB + row constants + K tiles 32 KB + dS tiles 32 KB + dQ slots 64 KB = 137 KB -> one workgroup per CU,
 // two waves per SIMD (256 registers), grid = (S/512) * HKV workgroups: at S = 16 384, 8 heads exactly one per CU.
 // ------------------------------------------------------------------------------------------------
-constexpr int FB_KB = 2, FB_NT = 2, FB_QS = 32 * FB_NT;
-constexpr int FB_OFF_STAGE = 0;                                           // Q tiles, then dO tiles
-constexpr int FB_OFF_LSE = FB_OFF_STAGE + 2 * FB_NT * TILE_BYTES;         // float[QS]
-constexpr int FB_OFF_DEL = FB_OFF_LSE + FB_QS * 4;                        // float[QS]
-constexpr int FB_OFF_AW = FB_OFF_DEL + FB_QS * 4;                         // uint32[2 * QS + 4] (+ pad to 16 B)
-constexpr int FB_OFF_K = FB_OFF_AW + (2 * FB_QS + 8) * 4;                 // per wave KB K tiles
-constexpr int fb_off_ds(int W) { return FB_OFF_K + W * FB_KB * TILE_BYTES; }          // per wave KB dS tiles
-constexpr int fb_off_slot(int W) { return fb_off_ds(W) + W * FB_KB * TILE_BYTES; }    // [NT][wave][32 q][32 d] fp32
-constexpr int fb_lds(int W) { return fb_off_slot(W) + FB_NT * W * 4096; }
-constexpr int fb_keys(int W) { return W * FB_KB * 32; }
+// LDS layout of k_attn_bwd_fused<DROP, W waves, KB key blocks per wave, NT query tiles per stage>
+template <int W, int KB, int NT>
+struct FusedLds {
+    static constexpr int QS = 32 * NT;
+    static constexpr int STAGE = 0;                                  // Q tiles, then dO tiles
+    static constexpr int LSE = STAGE + 2 * NT * TILE_BYTES;          // float[QS]
+    static constexpr int DEL = LSE + QS * 4;                         // float[QS]
+    static constexpr int AW = DEL + QS * 4;                          // uint32[2 * QS + 4] (+ pad to 16 B)
+    static constexpr int K = AW + (2 * QS + 8) * 4;                  // per wave KB K tiles
+    static constexpr int DS = K + W * KB * TILE_BYTES;               // per wave KB dS tiles
+    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32
+    static constexpr int TOTAL = SLOT + NT * W * 4096;
+    static constexpr int KEYS = W * KB * 32;
+};
 
 struct FusedArgs {
     BwdArgs a;
     bf16_t* dqpart;       // [B][H][nslab][S][32] bf16 (fp32 sums over the slab's keys, rounded once: see k_attn_dq_reduce)
     int nslab;
+    int lab;              // measurement switches (GAOT_ATTN_BWD_LAB): bits 0-1 priority mode, see the kernel
 };
 
-template <bool DROP, int FB_WAVES>
-__global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(FusedArgs fa) {
-    constexpr int FB_KEYS = fb_keys(FB_WAVES), FB_OFF_DS = fb_off_ds(FB_WAVES), FB_OFF_SLOT = fb_off_slot(FB_WAVES);
+// FB_WAVES x FB_KB = 16 key blocks (512 keys) per workgroup either way: 8 waves x 2 blocks run two waves per SIMD in 256
+// registers each; 4 waves x 4 blocks run ONE wave per SIMD with the whole 512-register file (K^T fragments of the dQ product
+// kept in registers, one read of a Q / dO fragment or row constant serves four units, four slots to reduce instead of eight).
+// PK (dropout only): the row words arrive packed per PAIR of queries (the two consecutive queries of an accumulator register
+// pair), so one xor makes the uniform 16-bit values of both and the two compares read its halves directly (SDWA): 2.5
+// mask-generation instructions per pair instead of 4, and half the row-word reads.
+template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false>
+__global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 : 2)) void k_attn_bwd_fused(FusedArgs fa) {
+    using L = FusedLds<FB_WAVES, FB_KB, FB_NT>;
+    constexpr int FB_QS = L::QS, FB_OFF_STAGE = L::STAGE, FB_OFF_LSE = L::LSE, FB_OFF_DEL = L::DEL, FB_OFF_AW = L::AW, FB_OFF_K = L::K;
+    constexpr int FB_KEYS = L::KEYS, FB_OFF_DS = L::DS, FB_OFF_SLOT = L::SLOT;
+    constexpr bool KT_REGS = FB_KB >= 4;          // the wave's K^T fragments (A operand of the dQ product) live in registers
     constexpr int NTHR = 64 * FB_WAVES;
     const BwdArgs& a = fa.a;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -1091,6 +1105,13 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.x % a.HKV, b = blockIdx.z, slab = blockIdx.x / a.HKV;   // head-fastest: one (kv) head per XCD
     const int rep = a.H / a.HKV;
+    // priority between the two waves of a SIMD (lab): 0 = s_setprio flips around the S / dP MFMA cluster of every tile (both
+    // waves alike), 1 = waves >= W/2 at static priority 1 and no flips, 2 = waves < W/2 at static priority 1, 3 = none
+    const int prio_mode = fa.lab & 3;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x) >> 6;
+        if ((prio_mode == 1 && wv >= FB_WAVES / 2) || (prio_mode == 2 && wv < FB_WAVES / 2)) __builtin_amdgcn_s_setprio(1);
+    }
     const int64_t key0 = (int64_t)slab * FB_KEYS + wave * (32 * FB_KB);
     const int64_t rowbase = (int64_t)b * a.S;
     char* ktile = lds + FB_OFF_K + wave * FB_KB * TILE_BYTES;
@@ -1119,10 +1140,22 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
     for (int kb = 0; kb < FB_KB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkt[kb][r] = 0.f; dvt[kb][r] = 0.f; }
+    // loop-invariant K^T fragments (the A operand of dQ^T = K^T dS^T): read back once from the wave's own tile when the
+    // register file has room for them (one wave per SIMD), else re-read per tile (two waves per SIMD, 256 registers)
+    bf16x8 ktf[KT_REGS ? FB_KB : 1][2];
+    if constexpr (KT_REGS) {
+#pragma unroll
+        for (int kb = 0; kb < FB_KB; ++kb) {
+            ktf[kb][0] = frag_cols(ktile + kb * TILE_BYTES, lane, 0);
+            ktf[kb][1] = frag_cols(ktile + kb * TILE_BYTES, lane, 1);
+        }
+    }
 
-    // staging: 512 16-byte chunks per stage (tile t of Q0 Q1 dO0 dO1, row r, chunk c), NST per thread
-    constexpr int NST = 512 / NTHR;
-    // slot reduction: 512 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NST per thread
+    // staging: 2 NT 128 16-byte chunks per stage (tile t of Q0.. dO0.., row r, chunk c), NST per thread
+    constexpr int NST = 2 * FB_NT * 128 / NTHR;
+    // slot reduction: NT 256 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NRS per thread
+    constexpr int NRS = FB_NT * 256 / NTHR;
+    static_assert(NST >= 1 && NRS >= 1 && FB_QS <= NTHR, "stage shape vs workgroup size");
 
     for (int hr = 0; hr < rep; ++hr) {
         const int head = hkv * rep + hr;
@@ -1135,9 +1168,9 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
                 const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
-                const int64_t row = q0 + 32 * (st_t & 1) + st_r;
+                const int64_t row = q0 + 32 * (st_t % FB_NT) + st_r;
                 uint4 val = make_uint4(0, 0, 0, 0);
-                if (row < a.S) val = (st_t < 2) ? *reinterpret_cast<const uint4*>(qp + row * a.ld + 8 * st_c)
+                if (row < a.S) val = (st_t < FB_NT) ? *reinterpret_cast<const uint4*>(qp + row * a.ld + 8 * st_c)
                                                 : *reinterpret_cast<const uint4*>(dop + row * (int64_t)(a.H * D) + 8 * st_c);
                 rg[it] = val;
             }
@@ -1151,7 +1184,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
         };
         auto reduce_slots = [&](int64_t q0) {    // sum the waves' dQ^T partials of the stage that started at q0, wave order
 #pragma unroll
-            for (int it = 0; it < NST; ++it) {
+            for (int it = 0; it < NRS; ++it) {
                 const int idx = threadIdx.x + it * NTHR, rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
                 const int64_t q = q0 + 32 * rt + rq;
                 const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
@@ -1183,14 +1216,27 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                 const int64_t ki = key0 + 32 * kb + l31;
                 const uint32_t bw = gdrop::col_word(ck, (uint32_t)(ki >> 1));
                 bsel[kb] = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
+                if constexpr (PK) bsel[kb] |= bsel[kb] << 16;
             }
         }
+        const uint32_t thr_v = a.drop.thr;
         for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
             __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
             if (q0 > 0) reduce_slots(q0 - FB_QS);
             stage_store(regs);
             if (threadIdx.x < FB_QS) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
-            if constexpr (DROP) stage_row_words<FB_QS>(aw_s, rk, q0);
+            if constexpr (DROP && !PK) stage_row_words<FB_QS>(aw_s, rk, q0);
+            if constexpr (DROP && PK) {
+                // packed form: copy c (key parity), word ((t 2 + hf) 4 + g4) 2 + j = halfword c of the row words of queries
+                // 32 t + 8 g4 + 4 hf + 2 j (low half) and + 1 (high half): a lane's 8 words of a tile are 32 contiguous bytes
+                if (threadIdx.x < FB_QS / 2) {
+                    const int u = threadIdx.x, st = u >> 4, sh = (u >> 3) & 1, sg = (u >> 1) & 3, sj = u & 1;
+                    const uint32_t qe = (uint32_t)q0 + 32 * st + 8 * sg + 4 * sh + 2 * sj;
+                    const uint32_t w0 = gdrop::row_word(rk, qe), w1 = gdrop::row_word(rk, qe + 1);
+                    aw_s[u] = (w0 & 0xffffu) | (w1 << 16);
+                    aw_s[FB_QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
+                }
+            }
             __syncthreads();     // B
             if (q0 + FB_QS < a.S) {
                 stage_load(regs, q0 + FB_QS);
@@ -1211,7 +1257,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                 const bf16x8 qa0 = frag_rows(qt, l31, hf, 0), da0 = frag_rows(dt, l31, hf, 0);
                 const bf16x8 qa1 = frag_rows(qt, l31, hf, 1), da1 = frag_rows(dt, l31, hf, 1);
                 f32x16 sc[FB_KB], dp[FB_KB];
-                __builtin_amdgcn_s_setprio(1);
+                if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[kb][0], lc, 0, 0, 0);
@@ -1219,10 +1265,37 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[kb][1], sc[kb], 0, 0, 0);
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
-                if constexpr (DROP) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
+                if constexpr (DROP && PK) {
+                    const uint4* awp = reinterpret_cast<const uint4*>(aw_s + (l31 & 1) * (FB_QS / 2 + 4) + (t * 2 + hf) * 8);
+                    const uint4 wa = awp[0], wb = awp[1];
+                    const uint32_t w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                        for (int kb = 0; kb < FB_KB; ++kb)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int r0 = 4 * g4 + 2 * j, r1 = r0 + 1;
+                                uint32_t x;
+                                unsigned long long m0, m1;
+                                asm("v_xor_b32 %0, %3, %4\n\t"
+                                    "v_cmp_ge_u32_sdwa %1, %0, %5 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                                    "v_cmp_ge_u32_sdwa %2, %0, %5 src0_sel:WORD_1 src1_sel:DWORD"
+                                    : "=&v"(x), "=&s"(m0), "=&s"(m1) : "v"(w8[2 * g4 + j]), "v"(bsel[kb]), "v"(thr_v));
+                                const float p0 = __builtin_amdgcn_exp2f(sc[kb][r0]), p1 = __builtin_amdgcn_exp2f(sc[kb][r1]);
+                                float pm0, pm1, t0, t1;
+                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm0) : "v"(p0), "s"(m0));
+                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t0) : "v"(dc[r0]), "v"(dp[kb][r0]), "s"(m0));
+                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm1) : "v"(p1), "s"(m1));
+                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1) : "v"(dc[r1]), "v"(dp[kb][r1]), "s"(m1));
+                                sc[kb][r0] = pm0; sc[kb][r1] = pm1;
+                                dp[kb][r0] = p0 * t0; dp[kb][r1] = p1 * t1;
+                            }
+                }
+                if constexpr (DROP && !PK) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
                     // which would put block 0's MFMAs under block 1's mask work, is 7 % slower)
                     const uint32_t* awp = aw_s + (l31 & 1) * (FB_QS + 4) + 32 * t + 4 * hf;
                     // the row words of group g4 + 1 are requested before group g4 is worked on (left alone the compiler loads
@@ -1284,10 +1357,15 @@ __global__ __launch_bounds__(64 * FB_WAVES, 8 / FB_WAVES) void k_attn_bwd_fused(
                 for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
-                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 0),
-                                                                 frag_cols(dstile + kb * TILE_BYTES, lane, 0), dq, 0, 0, 0);
-                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 1),
-                                                                 frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
+                    if constexpr (KT_REGS) {
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kb][0], frag_cols(dstile + kb * TILE_BYTES, lane, 0), dq, 0, 0, 0);
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kb][1], frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
+                    } else {
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 0),
+                                                                     frag_cols(dstile + kb * TILE_BYTES, lane, 0), dq, 0, 0, 0);
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ktile + kb * TILE_BYTES, lane, 1),
+                                                                     frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
+                    }
                 }
                 // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
                 char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
@@ -1518,11 +1596,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need ceil(S/512)*HKV*B >= 128 workgroups and <= 1 GiB of dQ slab partials; use phases 2 and 4");
             return GAOT_ERR_UNSUPPORTED;
         }
-        const int nslab = (int)ceil_div(S, fb_keys(8));
+        const int nslab = (int)ceil_div(S, 512);      // 512 keys per workgroup in every variant
         bf16_t* dqpart = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(parts) + bwd_parts_bytes(B, S, H, HKV));
         BwdArgs af = a;
         af.dqkv = dqkv;
-        FusedArgs fa{af, dqpart, nslab};
+        static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();
+        FusedArgs fa{af, dqpart, nslab, lab};
         const dim3 gf((unsigned)(nslab * HKV), 1, (unsigned)B);
         auto go = [&](auto kern, int lds_bytes, int nthr) -> int {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1534,7 +1613,19 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             return GAOT_OK;
         };
         if (phase_mask & 16) {
-            const int rc = drop ? go(k_attn_bwd_fused<true, 8>, fb_lds(8), 512) : go(k_attn_bwd_fused<false, 8>, fb_lds(8), 512);
+            // lab switch (measurement only): GAOT_ATTN_BWD_VARIANT = 0 (8 waves x 2 key blocks, 64-query stages: the shipped
+            // form), 1 (4 waves x 4 key blocks, one wave per SIMD, 64-query stages), 2 (the same with 128-query stages),
+            // 3 (the shipped shape with packed row words + SDWA compares)
+            static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
+            int rc;
+            if (variant == 1)
+                rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
+            else if (variant == 2)
+                rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 4>, FusedLds<4, 4, 4>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 4>, FusedLds<4, 4, 4>::TOTAL, 256);
+            else if (variant == 3 && drop)
+                rc = go(k_attn_bwd_fused<true, 8, 2, 2, true>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
         }
         const float qsc = drop ? scale * a.drop.inv_keep : scale;

@@ -785,8 +785,14 @@ extern "C" int gaot_axpy(const float* a, const float* b, float alpha, float* out
 
 // float4 streaming copy: the measured HBM ceiling the bench line quotes next to the 8 TB/s spec figure
 __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    // four independent 16-byte loads in flight per thread and trip
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 extern "C" int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream) {
@@ -796,7 +802,7 @@ extern "C" int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_
     GAOT_CHECK_ARG(src && dst && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte aligned device pointers");
     const int64_t n4 = bytes / 16;
     const int64_t blocks = (n4 + 255) / 256;
-    GAOT_KLAUNCH(k_stream_copy, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+    GAOT_KLAUNCH(k_stream_copy, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
                  (const float4*)src, (float4*)dst, n4);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
