@@ -1079,6 +1079,7 @@ struct FusedArgs {
     bf16_t* dqpart;       // [B][H][nslab][S][32] bf16 (fp32 sums over the slab's keys, rounded once: see k_attn_dq_reduce)
     int nslab;
     int lab;              // measurement switches (GAOT_ATTN_BWD_LAB): bits 0-1 priority mode, see the kernel
+    unsigned long long* stamps;   // ORD == 2 (diagnostic build, GAOT_ATTN_BWD_STAMPS=1): 16 cycle sums per wave, else NULL
 };
 
 // FB_WAVES x FB_KB = 16 key blocks (512 keys) per workgroup either way: 8 waves x 2 blocks run two waves per SIMD in 256
@@ -1087,7 +1088,9 @@ struct FusedArgs {
 // PK (dropout only): the row words arrive packed per PAIR of queries (the two consecutive queries of an accumulator register
 // pair), so one xor makes the uniform 16-bit values of both and the two compares read its halves directly (SDWA): 2.5
 // mask-generation instructions per pair instead of 4, and half the row-word reads.
-template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false>
+// ORD (with PK): 0 = all of a tile's exp / mask work, then all of its dV / dK products; 1 = key block by key block (block 0's
+// dV / dK MFMAs are in flight under block 1's exp / mask stream)
+template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0>
 __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 : 2)) void k_attn_bwd_fused(FusedArgs fa) {
     using L = FusedLds<FB_WAVES, FB_KB, FB_NT>;
     constexpr int FB_QS = L::QS, FB_OFF_STAGE = L::STAGE, FB_OFF_LSE = L::LSE, FB_OFF_DEL = L::DEL, FB_OFF_AW = L::AW, FB_OFF_K = L::K;
@@ -1105,6 +1108,23 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.x % a.HKV, b = blockIdx.z, slab = blockIdx.x / a.HKV;   // head-fastest: one (kv) head per XCD
     const int rep = a.H / a.HKV;
+    // in-kernel stamps (ORD == 2 only: a diagnostic instantiation, never the product's): cycles between consecutive stamp
+    // points, summed per wave; index = the stamp that CLOSES the interval
+    unsigned long long st_acc[16], st_last = 0;
+    if constexpr (ORD == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_acc[i] = 0;
+        st_last = __builtin_amdgcn_s_memtime();
+    }
+    auto STAMP = [&](int i) {
+        if constexpr (ORD == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            st_acc[i] += t - st_last;
+            st_last = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // priority between the two waves of a SIMD (lab): 0 = s_setprio flips around the S / dP MFMA cluster of every tile (both
     // waves alike), 1 = waves >= W/2 at static priority 1 and no flips, 2 = waves < W/2 at static priority 1, 3 = none
     const int prio_mode = fa.lab & 3;
@@ -1201,11 +1221,20 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         };
         uint4 regs[NST];
         stage_load(regs, 0);
+        // -lse / -delta of the stage's queries: loaded RAW (clamped address, no arithmetic on the value) one stage ahead, so
+        // that the wait for them falls where they are stored -- a whole stage later -- and not right behind the load (an
+        // `if (q < S) x = -lse[q] * c` puts load, s_waitcnt vmcnt(0) and multiply into one block: wave 0 then sat out two
+        // dependent L2 round trips per stage, queued behind the stage's own tile loads, while seven waves waited at the barrier)
         float lt = 0.f, et = 0.f;
-        if (threadIdx.x < FB_QS) {
-            lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;
-            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;
-        }
+        auto load_consts = [&](int64_t qbase) {
+            if (threadIdx.x < FB_QS) {
+                int64_t qq = qbase + threadIdx.x;
+                qq = qq < a.S ? qq : (int64_t)a.S - 1;
+                lt = lsep[qq];
+                et = delp[qq];
+            }
+        };
+        load_consts(0);
         uint32_t rk = 0, bsel[FB_KB];
         if constexpr (DROP) {
             const int bh = b * a.H + head;
@@ -1221,10 +1250,17 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         }
         const uint32_t thr_v = a.drop.thr;
         for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
+            STAMP(0);            // end of the previous stage's tiles (incl. its slot stores)
             __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
-            if (q0 > 0) reduce_slots(q0 - FB_QS);
+            STAMP(1);            // wait at barrier A
+            // the tile loads issued a stage ago are waited for HERE, before this section's slab-partial store is issued (vmcnt
+            // counts stores too: behind the store the wait would cover its whole round trip)
             stage_store(regs);
-            if (threadIdx.x < FB_QS) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if (threadIdx.x < FB_QS) {
+                const bool in = q0 + threadIdx.x < a.S;
+                lse_s[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;     // staged NEGATED: the initial accumulator values
+                del_s[threadIdx.x] = in ? -et * dscale : 0.f;
+            }
             if constexpr (DROP && !PK) stage_row_words<FB_QS>(aw_s, rk, q0);
             if constexpr (DROP && PK) {
                 // packed form: copy c (key parity), word ((t 2 + hf) 4 + g4) 2 + j = halfword c of the row words of queries
@@ -1237,15 +1273,15 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     aw_s[FB_QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
                 }
             }
+            if (q0 > 0) reduce_slots(q0 - FB_QS);
+            STAMP(2);            // staging stores + slot reduction
             __syncthreads();     // B
+            STAMP(3);            // wait at barrier B
             if (q0 + FB_QS < a.S) {
                 stage_load(regs, q0 + FB_QS);
-                if (threadIdx.x < FB_QS) {
-                    const int64_t qq = q0 + FB_QS + threadIdx.x;
-                    lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
-                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
-                }
+                load_consts(q0 + FB_QS);
             }
+            STAMP(4);            // issue of the next stage's global loads
 #pragma unroll
             for (int t = 0; t < FB_NT; ++t) {
                 if (q0 + 32 * t >= a.S) break;
@@ -1266,35 +1302,41 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
                 }
                 if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
+                STAMP(5);        // row constants + row fragments read, S / dP MFMAs issued
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
+                uint32_t w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if constexpr (DROP && PK) {
                     const uint4* awp = reinterpret_cast<const uint4*>(aw_s + (l31 & 1) * (FB_QS / 2 + 4) + (t * 2 + hf) * 8);
                     const uint4 wa = awp[0], wb = awp[1];
-                    const uint32_t w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    w8[0] = wa.x; w8[1] = wa.y; w8[2] = wa.z; w8[3] = wa.w; w8[4] = wb.x; w8[5] = wb.y; w8[6] = wb.z; w8[7] = wb.w;
+                }
+                auto mask_pair = [&](int kb, int g4, int j) {     // two consecutive queries of key block kb: registers r0, r0 + 1
+                    const int r0 = 4 * g4 + 2 * j, r1 = r0 + 1;
+                    uint32_t x;
+                    unsigned long long m0, m1;
+                    asm("v_xor_b32 %0, %3, %4\n\t"
+                        "v_cmp_ge_u32_sdwa %1, %0, %5 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                        "v_cmp_ge_u32_sdwa %2, %0, %5 src0_sel:WORD_1 src1_sel:DWORD"
+                        : "=&v"(x), "=&s"(m0), "=&s"(m1) : "v"(w8[2 * g4 + j]), "v"(bsel[kb]), "v"(thr_v));
+                    const float p0 = __builtin_amdgcn_exp2f(sc[kb][r0]), p1 = __builtin_amdgcn_exp2f(sc[kb][r1]);
+                    float pm0, pm1, t0, t1;
+                    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm0) : "v"(p0), "s"(m0));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t0) : "v"(dc[r0]), "v"(dp[kb][r0]), "s"(m0));
+                    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm1) : "v"(p1), "s"(m1));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1) : "v"(dc[r1]), "v"(dp[kb][r1]), "s"(m1));
+                    sc[kb][r0] = pm0; sc[kb][r1] = pm1;
+                    dp[kb][r0] = p0 * t0; dp[kb][r1] = p1 * t1;
+                };
+                if constexpr (DROP && PK && ORD != 1) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
                         for (int kb = 0; kb < FB_KB; ++kb)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int r0 = 4 * g4 + 2 * j, r1 = r0 + 1;
-                                uint32_t x;
-                                unsigned long long m0, m1;
-                                asm("v_xor_b32 %0, %3, %4\n\t"
-                                    "v_cmp_ge_u32_sdwa %1, %0, %5 src0_sel:WORD_0 src1_sel:DWORD\n\t"
-                                    "v_cmp_ge_u32_sdwa %2, %0, %5 src0_sel:WORD_1 src1_sel:DWORD"
-                                    : "=&v"(x), "=&s"(m0), "=&s"(m1) : "v"(w8[2 * g4 + j]), "v"(bsel[kb]), "v"(thr_v));
-                                const float p0 = __builtin_amdgcn_exp2f(sc[kb][r0]), p1 = __builtin_amdgcn_exp2f(sc[kb][r1]);
-                                float pm0, pm1, t0, t1;
-                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm0) : "v"(p0), "s"(m0));
-                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t0) : "v"(dc[r0]), "v"(dp[kb][r0]), "s"(m0));
-                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(pm1) : "v"(p1), "s"(m1));
-                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1) : "v"(dc[r1]), "v"(dp[kb][r1]), "s"(m1));
-                                sc[kb][r0] = pm0; sc[kb][r1] = pm1;
-                                dp[kb][r0] = p0 * t0; dp[kb][r1] = p1 * t1;
-                            }
+                            for (int j = 0; j < 2; ++j) mask_pair(kb, g4, j);
                 }
+                STAMP(6);        // wait for the MFMA results + exp / mask stream (PK)
                 if constexpr (DROP && !PK) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
                     // which would put block 0's MFMAs under block 1's mask work, is 7 % slower)
                     const uint32_t* awp = aw_s + (l31 & 1) * (FB_QS + 4) + 32 * t + 4 * hf;
@@ -1326,6 +1368,12 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 }
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
+                    if constexpr (DROP && PK && ORD == 1) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mask_pair(kb, g4, j);
+                    }
                     if constexpr (!DROP) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -1349,6 +1397,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 2) + 8 * hf) = make_uint2(hi.x, hi.y);
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
                 }
+                STAMP(7);        // conversions, dV / dK MFMAs issued, dS tile stored
                 // dQ^T[d][q] of this wave's 64 keys: K^T (A, transposed read of the K tile) x dS^T (B, transposed read of
                 // the tile just written: same LDS object, so the compiler keeps the order, and LDS operations of one wave
                 // complete in order)
@@ -1368,15 +1417,23 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     }
                 }
                 // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
+                STAMP(8);        // dS round trip through LDS + dQ MFMAs issued
                 char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
                         make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+                STAMP(9);        // wait for the dQ MFMAs + slot stores
             }
         }
         __syncthreads();
         reduce_slots(((a.S - 1) / FB_QS) * (int64_t)FB_QS);
+    }
+    if constexpr (ORD == 2) {
+        if (fa.stamps && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) fa.stamps[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * FB_WAVES + wave) * 16 + i] = st_acc[i];
+        }
     }
     const float vsc = DROP ? a.drop.inv_keep : 1.f;
     const float ksc = vsc / LOG2E;
@@ -1601,7 +1658,10 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         BwdArgs af = a;
         af.dqkv = dqkv;
         static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();
-        FusedArgs fa{af, dqpart, nslab, lab};
+        FusedArgs fa{af, dqpart, nslab, lab, nullptr};
+        static const bool want_stamps = [] { const char* e = getenv("GAOT_ATTN_BWD_STAMPS"); return e && atoi(e) != 0; }();
+        static unsigned long long* stamp_buf = nullptr;
+        const size_t stamp_n = (size_t)nslab * HKV * B * 8 * 16;
         const dim3 gf((unsigned)(nslab * HKV), 1, (unsigned)B);
         auto go = [&](auto kern, int lds_bytes, int nthr) -> int {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1613,19 +1673,38 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             return GAOT_OK;
         };
         if (phase_mask & 16) {
-            // lab switch (measurement only): GAOT_ATTN_BWD_VARIANT = 0 (8 waves x 2 key blocks, 64-query stages: the shipped
-            // form), 1 (4 waves x 4 key blocks, one wave per SIMD, 64-query stages), 2 (the same with 128-query stages),
-            // 3 (the shipped shape with packed row words + SDWA compares)
+            // lab switch (measurement only): GAOT_ATTN_BWD_VARIANT = 0 (the shipped form: 8 waves x 2 key blocks, 64-query stages,
+            // packed row words + SDWA compares), 1 (4 waves x 4 key blocks, one wave per SIMD), 7 (round-3 mask arithmetic);
+            // GAOT_ATTN_BWD_STAMPS=1: the diagnostic instantiation with in-kernel cycle stamps (results unchanged, slower)
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
-            if (variant == 1)
+            if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
-            else if (variant == 2)
-                rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 4>, FusedLds<4, 4, 4>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 4>, FusedLds<4, 4, 4>::TOTAL, 256);
-            else if (variant == 3 && drop)
-                rc = go(k_attn_bwd_fused<true, 8, 2, 2, true>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (variant == 7 && drop)   // round-3 mask arithmetic (row words per query, xor + compare per element)
+                rc = go(k_attn_bwd_fused<true, 8, 2, 2, false>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (want_stamps && drop) {    // diagnostic build: cycles per phase of the PK kernel, printed to stderr
+                if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, stamp_n * 8);
+                fa.stamps = stamp_buf;
+                rc = go(k_attn_bwd_fused<true, 8, 2, 2, true, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
+                if (rc == GAOT_OK && stamp_buf) {
+                    (void)hipStreamSynchronize(st);
+                    unsigned long long* h = (unsigned long long*)malloc(stamp_n * 8);
+                    (void)hipMemcpy(h, stamp_buf, stamp_n * 8, hipMemcpyDeviceToHost);
+                    double sum[16] = {0}, lo[16] = {0}, hi[16] = {0};   // all waves / waves 0-3 / waves 4-7
+                    const size_t nw = stamp_n / 16;
+                    for (size_t w = 0; w < nw; ++w)
+                        for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; ((w & 7) < 4 ? lo : hi)[i] += (double)h[w * 16 + i]; }
+                    double tot = 0;
+                    for (int i = 0; i < 16; ++i) tot += sum[i];
+                    fprintf(stderr, "[attn_bwd stamps] mean cycles per wave %.0f;", tot / nw);
+                    for (int i = 0; i < 10; ++i) fprintf(stderr, " s%d %.1f%% (w0-3 %.1f%% w4-7 %.1f%%)", i, 100 * sum[i] / tot, 200 * lo[i] / tot, 200 * hi[i] / tot);
+                    fprintf(stderr, "\n");
+                    free(h);
+                }
+            }
+
             else
-                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
         }
         const float qsc = drop ? scale * a.drop.inv_keep : scale;

@@ -228,6 +228,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int a_vec, int b_ve
             const int64_t n = bn + (wc * NT + j) * 32 + l31;
             if (n >= g.N) continue;
             const float bv = (g.splits <= 1 && g.bias) ? g.bias[n] : 0.f;
+            // residual values of the tile requested together, waited for once (see gemm_bf16.hip)
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (g.splits <= 1 && g.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int64_t m = bm + (wr * MT + i) * 32 + mfma32_row(r, hf);
+                    m = m < g.M ? m : g.M - 1;
+                    rv[r] = g.residual[m * g.ldr + n];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = bm + (wr * MT + i) * 32 + mfma32_row(r, hf);
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g, int a_vec, int b_ve
                     v += bv;
                     if (g.preact) g.preact[m * g.ldc + n] = v;
                     v = apply_act(v, g.act);
-                    if (g.residual) v += g.residual[m * g.ldr + n];
+                    v += rv[r];
                     g.C[m * g.ldc + n] = v;
                 }
             }

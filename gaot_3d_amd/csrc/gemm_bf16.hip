@@ -328,6 +328,20 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
             const int64_t n = bn + (wc * 2 + j) * 32 + l31;
             if (n >= g.N) continue;
             const float bv = (g.splits <= 1 && g.bias) ? g.bias[n] : 0.f;
+            // the tile's 16 residual values are requested TOGETHER (clamped row, no branch per element) and waited for once:
+            // `if (g.residual) v += g.residual[..]` inside the loop put every load, its s_waitcnt vmcnt(0) and the add into a
+            // block of their own -- 16 x MT x 2 serialised L2 round trips per lane at the end of every workgroup
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (g.splits <= 1 && g.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int64_t m = bm + (wr * MT + i) * 32 + mfma32_row(r, hf);
+                    m = m < g.M ? m : g.M - 1;
+                    rv[r] = g.residual[m * g.ldr + n];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = bm + (wr * MT + i) * 32 + mfma32_row(r, hf);
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(256, OCC) void k_gemm_bf16(GArgs g, int a_vec, int 
                     v += bv;
                     if (g.preact) g.preact[m * g.ldc + n] = v;
                     v = act_apply(v, g.act);
-                    if (g.residual) v += g.residual[m * g.ldr + n];
+                    v += rv[r];
                     if constexpr (C16) ((bf16_t*)g.C)[m * g.ldc + n] = __builtin_bit_cast(bf16_t, (__bf16)v);
                     else ((float*)g.C)[m * g.ldc + n] = v;
                 }

@@ -375,6 +375,25 @@ __global__ __launch_bounds__(256, 1) void k_gemm_tn_n256(const bf16_t* __restric
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+    // the residual rows of this lane's outputs are requested HERE, before the first DMA piece: they are the oldest entries of
+    // the in-order vmcnt queue (the counted waits of the K loop are unaffected) and have landed long before the epilogue.  In the
+    // epilogue (`if (ok) v += *R`) every one of the 8 MT loads sat in a block of its own with an s_waitcnt vmcnt(0) behind it:
+    // 8 MT serialised L2 round trips per workgroup.
+    f32x4 rres[HAS_RES ? MT : 1][2][4];
+    if constexpr (HAS_RES) {
+        const int64_t rbytes = (int64_t)M * ldr * 4;
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + 32 * i + l31;
+            const unsigned roff = m < M ? (unsigned)m * (unsigned)ldr * 4u : 0x80000000u;     // past M: out of range -> zeros
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rres[i][jt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0));
+        }
+    }
     const int nsteps = K / 64;
     // NB LDS buffers: NB - 1 steps of DMA in flight (each wave issues MT + 8 pieces per step; the kernel is bound by the latency
     // of these loads -- ~12 B/clk per CU with one step in flight -- so depth pays: 2 -> 3 buffers -0.18 ms per step)
@@ -419,12 +438,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_tn_n256(const bf16_t* __restric
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + 32 * jt + 8 * q + 4 * hf;
                 f32x4 v = {acc[jt][i][4 * q], acc[jt][i][4 * q + 1], acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]};
-                if constexpr (HAS_RES) {
-                    if (ok) {
-                        const float4 rr = *reinterpret_cast<const float4*>(R + (int64_t)m * ldr + n);
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                    }
-                }
+                if constexpr (HAS_RES) v += rres[i][jt][q];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), crs, rowoff + n * 4, 0, 0);
             }
     }

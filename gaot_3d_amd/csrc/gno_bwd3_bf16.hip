@@ -226,18 +226,23 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
             const bool valid = v_nx;
             const int s = s_nx, q = q_nx;
             bin0 = bin_nx[0]; bin1 = bin_nx[1];
-            fetch_ids(tb + (int64_t)gridDim.x * 8);
             idv = valid ? s : -1;
             s_raw = s;
             q_raw = q;
-            if (valid) {
-                rbv = rowptr_src[s];
-                rev = rowptr_src[s + 1];
-            }
-            // input tile [k][e] bf16 (rows 0..5 = coordinates, row 6 = ones -> db_0, row 7 = 0)
+            // input tile [k][e] bf16 (rows 0..5 = coordinates, row 6 = ones -> db_0, row 7 = 0).  Consumes the coordinates
+            // requested at the end of the previous iteration BEFORE anything new is requested: vmcnt retires in order, so a wait
+            // for them placed behind fresh requests would sit out those requests' whole round trip.
             *reinterpret_cast<bf16_t*>(inT + tile_off(g, n >> 3) + ((n & 7) << 1)) = f2bf(bin0);
             *reinterpret_cast<bf16_t*>(inT + tile_off(4 + g, n >> 3) + ((n & 7) << 1)) =
                 g < 2 ? f2bf(bin1) : (g == 2 ? (bf16_t)0x3F80 : (bf16_t)0);
+            asm volatile("" ::: "memory");
+            // UNCONDITIONAL loads (s = 0 for an edge past E: a valid row), selected afterwards: inside `if (valid)` the loads, their
+            // s_waitcnt vmcnt(0) and the merge sit in one block at the top of the iteration
+            rbv = rowptr_src[s];
+            rev = rowptr_src[s + 1];
+            rbv = valid ? rbv : 0;
+            rev = valid ? rev : 0;
+            fetch_ids(tb + (int64_t)gridDim.x * 8);
         }
         // ---- gather f[src] / g[dst] rows now (lane = channel 16 nb + n, reg = edge 4 g + r): they are needed after the MLP
         //      recompute.  Unconditional loads (edges past E carry endpoint 0, a valid row); zeroed at their use.
