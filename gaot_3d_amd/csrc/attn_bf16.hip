@@ -260,7 +260,9 @@ __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf
 // grows" ~40 % of the tiles of a wave went through the rescale path at S = 16 384 on random scores; now a handful do.
 // o = acc / l and lse = m ln2 + log l do not depend on where m sits.
 constexpr float RESCALE_SUM = 64.0f;
-template <int OCC, int TPM, bool DROP, bool FAST>
+// FSB: schedule pins of the bound-based (FAST) tile, bit i = __builtin_amdgcn_sched_barrier(0) at 1: the start of a tile,
+// 2: after the exp stream (before packing / row sums / mask), 4: before the P V products
+template <int OCC, int TPM, bool DROP, bool FAST, int FSB = 0>
 __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TPM * TILE_BYTES];  // K tiles, then V tiles
     __shared__ __attribute__((aligned(16))) uint32_t bw_s[DROP ? 16 * TPM : 4];
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                 }
             };
             if constexpr (FAST) {
+                if constexpr ((FSB & 1) != 0) __builtin_amdgcn_sched_barrier(0);
                 f32x16 zero;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                 }
     #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+                if constexpr ((FSB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
                 bf16x8 p0, p1;
                 acc_to_frags(sc, p0, p1);
                 {   // l stays undropped; two chains (a ones-row MFMA with the packed P was measured: 2-4 % slower than these adds)
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                     l += q0 + q1;
                 }
                 if constexpr (DROP) drop_packed(p0, p1, aw, bw_s + 16 * t, hf, tpk);
+                if constexpr ((FSB & 4) != 0) __builtin_amdgcn_sched_barrier(0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 0), p0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vt, lane, 1), p1, acc, 0, 0, 0);
                 return;
@@ -1069,8 +1074,10 @@ struct FusedLds {
     static constexpr int AW = DEL + QS * 4;                          // uint32[2 * QS + 4] (+ pad to 16 B)
     static constexpr int K = AW + (2 * QS + 8) * 4;                  // per wave KB K tiles
     static constexpr int DS = K + W * KB * TILE_BYTES;               // per wave KB dS tiles
-    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32
-    static constexpr int TOTAL = SLOT + NT * W * 4096;
+    static constexpr bool SLOT16 = NT >= 4;                          // 128-query stages: the waves' dQ partials as bf16 (LDS budget)
+    static constexpr int SLOT_BYTES = SLOT16 ? 2048 : 4096;
+    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32 (or bf16)
+    static constexpr int TOTAL = SLOT + NT * W * SLOT_BYTES;
     static constexpr int KEYS = W * KB * 32;
 };
 
@@ -1078,7 +1085,7 @@ struct FusedArgs {
     BwdArgs a;
     bf16_t* dqpart;       // [B][H][nslab][S][32] bf16 (fp32 sums over the slab's keys, rounded once: see k_attn_dq_reduce)
     int nslab;
-    int lab;              // measurement switches (GAOT_ATTN_BWD_LAB): bits 0-1 priority mode, see the kernel
+    int lab;              // measurement switch (GAOT_ATTN_BWD_LAB): selects the SB instantiation on the host side
     unsigned long long* stamps;   // ORD == 2 (diagnostic build, GAOT_ATTN_BWD_STAMPS=1): 16 cycle sums per wave, else NULL
 };
 
@@ -1090,7 +1097,9 @@ struct FusedArgs {
 // mask-generation instructions per pair instead of 4, and half the row-word reads.
 // ORD (with PK): 0 = all of a tile's exp / mask work, then all of its dV / dK products; 1 = key block by key block (block 0's
 // dV / dK MFMAs are in flight under block 1's exp / mask stream)
-template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0>
+// PRIO: 0 = s_setprio 1 / 0 around the S / dP cluster of every tile, all waves alike; 1 = the same with waves >= W/2 one
+// level higher throughout (2 / 1; base 1); 2 = waves >= W/2 at static priority 1, no flips; 3 = no priority at all
+template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0, int SB = 0, int PRIO = 0>
 __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 : 2)) void k_attn_bwd_fused(FusedArgs fa) {
     using L = FusedLds<FB_WAVES, FB_KB, FB_NT>;
     constexpr int FB_QS = L::QS, FB_OFF_STAGE = L::STAGE, FB_OFF_LSE = L::LSE, FB_OFF_DEL = L::DEL, FB_OFF_AW = L::AW, FB_OFF_K = L::K;
@@ -1127,11 +1136,15 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     };
     // priority between the two waves of a SIMD (lab): 0 = s_setprio flips around the S / dP MFMA cluster of every tile (both
     // waves alike), 1 = waves >= W/2 at static priority 1 and no flips, 2 = waves < W/2 at static priority 1, 3 = none
-    const int prio_mode = fa.lab & 3;
-    {
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x) >> 6;
-        if ((prio_mode == 1 && wv >= FB_WAVES / 2) || (prio_mode == 2 && wv < FB_WAVES / 2)) __builtin_amdgcn_s_setprio(1);
+    const bool lead = (__builtin_amdgcn_readfirstlane(threadIdx.x) >> 6) < FB_WAVES / 2;
+    if constexpr (PRIO == 1 || PRIO == 2) {
+        if (!lead) __builtin_amdgcn_s_setprio(1);
     }
+    // (measured and removed, profiles/r4_b / r4_e: static priority for either half of the waves +1.5 ... +8 %, no priority
+    // +1.4 %, priority for one half inside its MFMA clusters only: no gain; RUNTIME-conditional s_setprio splits the basic
+    // blocks around the clusters and changed the dropout kernel's schedule by +30 %: the flips below are unconditional)
+    // SB: bit i = __builtin_amdgcn_sched_barrier(0) at phase boundary i (1: after the S / dP cluster, 2: after the exp / mask
+    // stream, 4: after the dV / dK products, 8: after the dQ products) -- pins the compiler's schedule at those points
     const int64_t key0 = (int64_t)slab * FB_KEYS + wave * (32 * FB_KB);
     const int64_t rowbase = (int64_t)b * a.S;
     char* ktile = lds + FB_OFF_K + wave * FB_KB * TILE_BYTES;
@@ -1174,7 +1187,8 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     // staging: 2 NT 128 16-byte chunks per stage (tile t of Q0.. dO0.., row r, chunk c), NST per thread
     constexpr int NST = 2 * FB_NT * 128 / NTHR;
     // slot reduction: NT 256 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NRS per thread
-    constexpr int NRS = FB_NT * 256 / NTHR;
+    constexpr bool SLOT16 = L::SLOT16;
+    constexpr int NRS = (SLOT16 ? FB_NT * 128 : FB_NT * 256) / NTHR;    // bf16 slots: 8 d per 16-byte item
     static_assert(NST >= 1 && NRS >= 1 && FB_QS <= NTHR, "stage shape vs workgroup size");
 
     for (int hr = 0; hr < rep; ++hr) {
@@ -1205,18 +1219,42 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         auto reduce_slots = [&](int64_t q0) {    // sum the waves' dQ^T partials of the stage that started at q0, wave order
 #pragma unroll
             for (int it = 0; it < NRS; ++it) {
-                const int idx = threadIdx.x + it * NTHR, rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
-                const int64_t q = q0 + 32 * rt + rq;
-                const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
-                float4 acc = *reinterpret_cast<const float4*>(sp);
+                const int idx = threadIdx.x + it * NTHR;
+                if constexpr (!SLOT16) {
+                    const int rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
+                    const int64_t q = q0 + 32 * rt + rq;
+                    const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
+                    float4 acc = *reinterpret_cast<const float4*>(sp);
 #pragma unroll
-                for (int w = 1; w < FB_WAVES; ++w) {
-                    const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    for (int w = 1; w < FB_WAVES; ++w) {
+                        const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                    if (q < a.S)
+                        *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
+                            make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
+                } else {
+                    // bf16 slots: [q][32 d] rows of 64 bytes, 16-byte chunk c (8 d) at chunk c ^ ((q >> 2) & 3); fp32 sum in wave order
+                    const int rt = idx >> 7, rq = (idx >> 2) & 31, rc = idx & 3;
+                    const int64_t q = q0 + 32 * rt + rq;
+                    const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 2048 + rq * 64 + ((rc ^ ((rq >> 2) & 3)) << 4);
+                    float acc[8];
+#pragma unroll
+                    for (int w = 0; w < FB_WAVES; ++w) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(sp + w * 2048);
+                        const uint32_t pk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = __uint_as_float(pk[j] << 16), hi = __uint_as_float(pk[j] & 0xffff0000u);
+                            acc[2 * j] = w == 0 ? lo : acc[2 * j] + lo;
+                            acc[2 * j + 1] = w == 0 ? hi : acc[2 * j + 1] + hi;
+                        }
+                    }
+                    if (q < a.S)
+                        *reinterpret_cast<uint4*>(part + q * D + 8 * rc) =
+                            make_uint4((unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16), (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16),
+                                       (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16), (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16));
                 }
-                if (q < a.S)
-                    *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
-                        make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
             }
         };
         uint4 regs[NST];
@@ -1282,9 +1320,10 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 load_consts(q0 + FB_QS);
             }
             STAMP(4);            // issue of the next stage's global loads
-#pragma unroll
+#pragma unroll(FB_NT >= 4 ? 1 : FB_NT)
             for (int t = 0; t < FB_NT; ++t) {
                 if (q0 + 32 * t >= a.S) break;
+                if constexpr ((SB & 16) != 0) __builtin_amdgcn_sched_barrier(0);
                 const char* qt = lds + FB_OFF_STAGE + t * TILE_BYTES;
                 const char* dt = lds + FB_OFF_STAGE + (FB_NT + t) * TILE_BYTES;
                 f32x16 lc, dc;
@@ -1293,7 +1332,8 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 const bf16x8 qa0 = frag_rows(qt, l31, hf, 0), da0 = frag_rows(dt, l31, hf, 0);
                 const bf16x8 qa1 = frag_rows(qt, l31, hf, 1), da1 = frag_rows(dt, l31, hf, 1);
                 f32x16 sc[FB_KB], dp[FB_KB];
-                if (prio_mode == 0) __builtin_amdgcn_s_setprio(1);
+                if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1);
+                if constexpr (PRIO == 1) { if (lead) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[kb][0], lc, 0, 0, 0);
@@ -1301,7 +1341,9 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[kb][1], sc[kb], 0, 0, 0);
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
                 }
-                if (prio_mode == 0) __builtin_amdgcn_s_setprio(0);
+                if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+                if constexpr (PRIO == 1) { if (lead) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                if constexpr ((SB & 1) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(5);        // row constants + row fragments read, S / dP MFMAs issued
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
                 const bf16x8 qc0 = frag_cols(qt, lane, 0), qc1 = frag_cols(qt, lane, 1);
@@ -1336,6 +1378,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
 #pragma unroll
                             for (int j = 0; j < 2; ++j) mask_pair(kb, g4, j);
                 }
+                if constexpr ((SB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(6);        // wait for the MFMA results + exp / mask stream (PK)
                 if constexpr (DROP && !PK) {   // row words read 4 at a time: the two key blocks share them (measured: key-block-outer order,
                     // which would put block 0's MFMAs under block 1's mask work, is 7 % slower)
@@ -1397,6 +1440,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 2) + 8 * hf) = make_uint2(hi.x, hi.y);
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
                 }
+                if constexpr ((SB & 4) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(7);        // conversions, dV / dK MFMAs issued, dS tile stored
                 // dQ^T[d][q] of this wave's 64 keys: K^T (A, transposed read of the K tile) x dS^T (B, transposed read of
                 // the tile just written: same LDS object, so the compiler keeps the order, and LDS operations of one wave
@@ -1417,12 +1461,22 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     }
                 }
                 // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
+                if constexpr ((SB & 8) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(8);        // dS round trip through LDS + dQ MFMAs issued
-                char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
+                if constexpr (!SLOT16) {
+                    char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
-                        make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
+                            make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+                } else {   // bf16: d = 8 g + 4 hf .. + 3 -> 8 bytes at chunk g ^ ((q >> 2) & 3), half hf
+                    char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 2048 + l31 * 64 + 8 * hf;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<uint2*>(slot + ((g ^ ((l31 >> 2) & 3)) << 4)) =
+                            make_uint2((unsigned)f2bf(dq[4 * g]) | ((unsigned)f2bf(dq[4 * g + 1]) << 16),
+                                       (unsigned)f2bf(dq[4 * g + 2]) | ((unsigned)f2bf(dq[4 * g + 3]) << 16));
+                }
                 STAMP(9);        // wait for the dQ MFMAs + slot stores
             }
         }
@@ -1602,6 +1656,8 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // with the maximum-free tile path the kernels need ~150 registers: three waves per SIMD without scratch beat four with it
     // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
     // bound-based kernel (128 registers: 4 workgroups per CU), then the adaptive one for the workgroups it flagged
+    // (schedule pins inside the forward's tile -- start of tile / after the exp stream / before the P V products -- were
+    // measured: +-0.5 %, profiles/r4_g_attn_lab.txt; the template parameter stays at 0)
     if (a.drop.thr) {
         GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true>), fgrid, dim3(256), 0, st, a);
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true, false>), fgrid, dim3(256), 0, st, a);
@@ -1657,7 +1713,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
         bf16_t* dqpart = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(parts) + bwd_parts_bytes(B, S, H, HKV));
         BwdArgs af = a;
         af.dqkv = dqkv;
-        static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();
+        static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();   // 0..6
         FusedArgs fa{af, dqpart, nslab, lab, nullptr};
         static const bool want_stamps = [] { const char* e = getenv("GAOT_ATTN_BWD_STAMPS"); return e && atoi(e) != 0; }();
         static unsigned long long* stamp_buf = nullptr;
@@ -1680,12 +1736,14 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             int rc;
             if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
+            // (128-query stages with bf16 slots -- FB_NT = 4 -- measured 1.07 / 0.81 ms against 0.90 / 0.76: spills in the
+            // dropout variant, profiles/r4_g_attn_lab.txt; the layout code stays, the instantiation is gone)
             else if (variant == 7 && drop)   // round-3 mask arithmetic (row words per query, xor + compare per element)
-                rc = go(k_attn_bwd_fused<true, 8, 2, 2, false>, FusedLds<8, 2, 2>::TOTAL, 512);
+                rc = go(k_attn_bwd_fused<true, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             else if (want_stamps && drop) {    // diagnostic build: cycles per phase of the PK kernel, printed to stderr
                 if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, stamp_n * 8);
                 fa.stamps = stamp_buf;
-                rc = go(k_attn_bwd_fused<true, 8, 2, 2, true, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
+                rc = go(k_attn_bwd_fused<true, 8, 2, 2, true, 2, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
                 if (rc == GAOT_OK && stamp_buf) {
                     (void)hipStreamSynchronize(st);
                     unsigned long long* h = (unsigned long long*)malloc(stamp_n * 8);
@@ -1703,8 +1761,16 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                 }
             }
 
-            else
-                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (lab == 100)      // no schedule pins (the round-3 / r4_d schedule)
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (lab == 201)
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 1>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 1>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (lab == 202)
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 2>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else if (lab == 203)
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 3>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 3>, FusedLds<8, 2, 2>::TOTAL, 512);
+            else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
         }
         const float qsc = drop ? scale * a.drop.inv_keep : scale;

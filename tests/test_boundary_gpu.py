@@ -88,8 +88,13 @@ def test_activations_as_callables_and_channel_first_layout():
     from gaot_3d_amd.model.layers.mlp import ChannelMLP, LinearChannelMLP, activation_name
     gaot_3d_amd.set_precision("fp32")
     assert activation_name(F.gelu) == "gelu" and activation_name(F.relu) == "relu" and activation_name(torch.nn.SiLU()) == "silu"
+    # the reference's activation_fn(name) surface (mlp.py:27-35): any F.<name>, "swish", "none"
+    assert activation_name(torch.tanh) == "tanh" and activation_name("swish") == "silu" and activation_name(F.leaky_relu) == "leaky_relu"
+    assert activation_name(torch.nn.ELU()) == "elu" and activation_name(None) == "none"
     with pytest.raises(NotImplementedError):
-        activation_name(torch.tanh)
+        activation_name(torch.nn.ELU(alpha=0.5))       # only torch's default parameters have a kernel
+    with pytest.raises(NotImplementedError):
+        activation_name(lambda x: x)                    # an anonymous callable cannot be recognised: pass "none"
     meta, g = gio.load("ops")
     tag = "it_linear_noattn"
     it = IntegralTransform(channel_mlp_layers=[6, 64, 64, 32], channel_mlp_non_linearity=F.gelu, transform_type="linear",
@@ -102,7 +107,8 @@ def test_activations_as_callables_and_channel_first_layout():
     close("it_callable_gelu/out", it(y_pos=pos, x_pos=lat, edge_index=ei, f_y=f), g["out"][f"{tag}/out"], 1e-4, 1e-5)
 
     torch.manual_seed(3)
-    for act, tact in ((F.gelu, F.gelu), (F.relu, F.relu), ("silu", F.silu)):
+    for act, tact in ((F.gelu, F.gelu), (F.relu, F.relu), ("silu", F.silu), (torch.tanh, torch.tanh), (F.elu, F.elu),
+                      ("leaky_relu", F.leaky_relu), (torch.nn.Mish(), F.mish), ("none", lambda t: t)):
         mlp = ChannelMLP(in_channels=12, out_channels=5, hidden_channels=24, n_layers=3, n_dim=1, non_linearity=act)
         x = torch.randn(12, 301)
 
