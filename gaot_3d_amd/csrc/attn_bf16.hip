@@ -1763,12 +1763,8 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
 
             else if (lab == 100)      // no schedule pins (the round-3 / r4_d schedule)
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512);
-            else if (lab == 201)
-                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 1>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 1>, FusedLds<8, 2, 2>::TOTAL, 512);
-            else if (lab == 202)
-                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 2>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 2>, FusedLds<8, 2, 2>::TOTAL, 512);
-            else if (lab == 203)
-                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, 3>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, 3>, FusedLds<8, 2, 2>::TOTAL, 512);
+            // (compile-time priority variants on the pinned schedule -- waves >= W/2 one level higher, static priority without
+            // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/r4_h_attn_bwd_prio_stamps.txt)
             else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
