@@ -1071,7 +1071,7 @@ struct FusedLds {
     static constexpr int STAGE = 0;                                  // Q tiles, then dO tiles
     static constexpr int LSE = STAGE + 2 * NT * TILE_BYTES;          // float[QS]
     static constexpr int DEL = LSE + QS * 4;                         // float[QS]
-    static constexpr int AW = DEL + QS * 4;                          // uint32[2 * QS + 4] (+ pad to 16 B)
+    static constexpr int AW = DEL + QS * 4;                          // uint32[2 * QS + 8]
     static constexpr int K = AW + (2 * QS + 8) * 4;                  // per wave KB K tiles
     static constexpr int DS = K + W * KB * TILE_BYTES;               // per wave KB dS tiles
     static constexpr bool SLOT16 = NT >= 4;                          // 128-query stages: the waves' dQ partials as bf16 (LDS budget)
@@ -1108,9 +1108,6 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     constexpr int NTHR = 64 * FB_WAVES;
     const BwdArgs& a = fa.a;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    float* lse_s = reinterpret_cast<float*>(lds + FB_OFF_LSE);
-    float* del_s = reinterpret_cast<float*>(lds + FB_OFF_DEL);
-    uint32_t* aw_s = reinterpret_cast<uint32_t*>(lds + FB_OFF_AW);
     const float dscale = DROP ? a.drop.keep : 1.f;   // see k_attn_bwd_dkv_bf16
     unsigned long long seed = 0;
     if constexpr (DROP) seed = *a.drop.seed;
@@ -1185,7 +1182,8 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     }
 
     // staging: 2 NT 128 16-byte chunks per stage (tile t of Q0.. dO0.., row r, chunk c), NST per thread
-    constexpr int NST = 2 * FB_NT * 128 / NTHR;
+    constexpr int NSTG = NTHR;
+    constexpr int NST = 2 * FB_NT * 128 / NSTG;
     // slot reduction: NT 256 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NRS per thread
     constexpr bool SLOT16 = L::SLOT16;
     constexpr int NRS = (SLOT16 ? FB_NT * 128 : FB_NT * 256) / NTHR;    // bf16 slots: 8 d per 16-byte item
@@ -1201,7 +1199,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         auto stage_load = [&](uint4 (&rg)[NST], int64_t q0) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
-                const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+                const int idx = threadIdx.x + it * NSTG, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
                 const int64_t row = q0 + 32 * (st_t % FB_NT) + st_r;
                 uint4 val = make_uint4(0, 0, 0, 0);
                 if (row < a.S) val = (st_t < FB_NT) ? *reinterpret_cast<const uint4*>(qp + row * a.ld + 8 * st_c)
@@ -1209,11 +1207,11 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 rg[it] = val;
             }
         };
-        auto stage_store = [&](const uint4 (&rg)[NST]) {
+        auto stage_store = [&](const uint4 (&rg)[NST], char* sb) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
-                const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
-                *reinterpret_cast<uint4*>(lds + FB_OFF_STAGE + st_t * TILE_BYTES + tile_off(st_r, st_c)) = rg[it];
+                const int idx = threadIdx.x + it * NSTG, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+                *reinterpret_cast<uint4*>(sb + FB_OFF_STAGE + st_t * TILE_BYTES + tile_off(st_r, st_c)) = rg[it];
             }
         };
         auto reduce_slots = [&](int64_t q0) {    // sum the waves' dQ^T partials of the stage that started at q0, wave order
@@ -1287,19 +1285,18 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             }
         }
         const uint32_t thr_v = a.drop.thr;
-        for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
-            STAMP(0);            // end of the previous stage's tiles (incl. its slot stores)
-            __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
-            STAMP(1);            // wait at barrier A
-            // the tile loads issued a stage ago are waited for HERE, before this section's slab-partial store is issued (vmcnt
-            // counts stores too: behind the store the wait would cover its whole round trip)
-            stage_store(regs);
+        // everything a stage needs besides the tiles: row constants (staged NEGATED: the initial accumulator values) and the
+        // dropout row words of queries q0 ..; written by the first FB_QS (FB_QS / 2) threads into stage buffer sb
+        auto stage_consts = [&](char* sb, int64_t q0) {
+            float* lse_w = reinterpret_cast<float*>(sb + FB_OFF_LSE);
+            float* del_w = reinterpret_cast<float*>(sb + FB_OFF_DEL);
+            uint32_t* aw_w = reinterpret_cast<uint32_t*>(sb + FB_OFF_AW);
             if (threadIdx.x < FB_QS) {
                 const bool in = q0 + threadIdx.x < a.S;
-                lse_s[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;     // staged NEGATED: the initial accumulator values
-                del_s[threadIdx.x] = in ? -et * dscale : 0.f;
+                lse_w[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;
+                del_w[threadIdx.x] = in ? -et * dscale : 0.f;
             }
-            if constexpr (DROP && !PK) stage_row_words<FB_QS>(aw_s, rk, q0);
+            if constexpr (DROP && !PK) stage_row_words<FB_QS>(aw_w, rk, q0);
             if constexpr (DROP && PK) {
                 // packed form: copy c (key parity), word ((t 2 + hf) 4 + g4) 2 + j = halfword c of the row words of queries
                 // 32 t + 8 g4 + 4 hf + 2 j (low half) and + 1 (high half): a lane's 8 words of a tile are 32 contiguous bytes
@@ -1307,25 +1304,40 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     const int u = threadIdx.x, st = u >> 4, sh = (u >> 3) & 1, sg = (u >> 1) & 3, sj = u & 1;
                     const uint32_t qe = (uint32_t)q0 + 32 * st + 8 * sg + 4 * sh + 2 * sj;
                     const uint32_t w0 = gdrop::row_word(rk, qe), w1 = gdrop::row_word(rk, qe + 1);
-                    aw_s[u] = (w0 & 0xffffu) | (w1 << 16);
-                    aw_s[FB_QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
+                    aw_w[u] = (w0 & 0xffffu) | (w1 << 16);
+                    aw_w[FB_QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
                 }
             }
-            if (q0 > 0) reduce_slots(q0 - FB_QS);
-            STAMP(2);            // staging stores + slot reduction
-            __syncthreads();     // B
-            STAMP(3);            // wait at barrier B
-            if (q0 + FB_QS < a.S) {
-                stage_load(regs, q0 + FB_QS);
-                load_consts(q0 + FB_QS);
+        };
+        char* const sbuf = lds;
+        const float* lse_s = reinterpret_cast<const float*>(sbuf + FB_OFF_LSE);
+        const float* del_s = reinterpret_cast<const float*>(sbuf + FB_OFF_DEL);
+        const uint32_t* aw_s = reinterpret_cast<const uint32_t*>(sbuf + FB_OFF_AW);
+        for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
+            {
+                STAMP(0);            // end of the previous stage's tiles (incl. its slot stores)
+                __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
+                STAMP(1);            // wait at barrier A
+                // the tile loads issued a stage ago are waited for HERE, before this section's slab-partial store is issued (vmcnt
+                // counts stores too: behind the store the wait would cover its whole round trip)
+                stage_store(regs, sbuf);
+                stage_consts(sbuf, q0);
+                if (q0 > 0) reduce_slots(q0 - FB_QS);
+                STAMP(2);            // staging stores + slot reduction
+                __syncthreads();     // B
+                STAMP(3);            // wait at barrier B
+                if (q0 + FB_QS < a.S) {
+                    stage_load(regs, q0 + FB_QS);
+                    load_consts(q0 + FB_QS);
+                }
             }
             STAMP(4);            // issue of the next stage's global loads
 #pragma unroll(FB_NT >= 4 ? 1 : FB_NT)
             for (int t = 0; t < FB_NT; ++t) {
                 if (q0 + 32 * t >= a.S) break;
                 if constexpr ((SB & 16) != 0) __builtin_amdgcn_sched_barrier(0);
-                const char* qt = lds + FB_OFF_STAGE + t * TILE_BYTES;
-                const char* dt = lds + FB_OFF_STAGE + (FB_NT + t) * TILE_BYTES;
+                const char* qt = sbuf + FB_OFF_STAGE + t * TILE_BYTES;
+                const char* dt = sbuf + FB_OFF_STAGE + (FB_NT + t) * TILE_BYTES;
                 f32x16 lc, dc;
                 load_row_consts(lc, lse_s + 32 * t, hf);
                 load_row_consts(dc, del_s + 32 * t, hf);
@@ -1765,6 +1777,8 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512);
             // (compile-time priority variants on the pinned schedule -- waves >= W/2 one level higher, static priority without
             // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/r4_h_attn_bwd_prio_stamps.txt)
+            // (double-buffered stage tiles filled by the first half of the waves before the stage barrier -- to use their 17 % of
+            // barrier idle time -- measured 0.97 / 0.795 ms against 0.89 / 0.786: profiles/r4_i_attn_bwd_double_buffer_lab.txt; removed)
             else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
