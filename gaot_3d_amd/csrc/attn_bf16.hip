@@ -567,12 +567,18 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         uint4 regs[2];
         const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
         stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, lo, a.S);
+        // row constants loaded RAW one stage ahead (clamped address, no arithmetic on the value: the wait then falls at the
+        // store a stage later, not right behind the load -- see k_attn_bwd_fused); negated and scaled when staged
         float lt = 0.f, et = 0.f;
-        if (threadIdx.x < 64) {
-            const int64_t qq = lo + threadIdx.x;
-            lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;   // staged NEGATED: they are the
-            et = (qq < a.S) ? -delp[qq] * dscale : 0.f;         // initial accumulator values
-        }
+        auto load_consts = [&](int64_t qbase) {
+            if (threadIdx.x < 64) {
+                int64_t qq = qbase + threadIdx.x;
+                qq = qq < a.S ? qq : (int64_t)a.S - 1;
+                lt = lsep[qq];
+                et = delp[qq];
+            }
+        };
+        load_consts(lo);
         uint32_t rk = 0, bsel = 0;
         if constexpr (DROP) {
             const int bh = b * a.H + head;
@@ -583,16 +589,16 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         for (int64_t q0 = lo; q0 < hi; q0 += 64) {
             __syncthreads();
             stage_store<4>(regs, lds);
-            if (threadIdx.x < 64) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if (threadIdx.x < 64) {
+                const bool in = q0 + threadIdx.x < a.S;
+                lse_s[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;   // staged NEGATED: they are the
+                del_s[threadIdx.x] = in ? -et * dscale : 0.f;         // initial accumulator values
+            }
             if constexpr (DROP) stage_row_words<64>(aw_s, rk, q0);
             __syncthreads();
             if (q0 + 64 < hi) {
                 stage_load4(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + 64, a.S);
-                if (threadIdx.x < 64) {
-                    const int64_t qq = q0 + 64 + threadIdx.x;
-                    lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
-                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
-                }
+                load_consts(q0 + 64);
             }
 #pragma unroll 1
             for (int t = 0; t < 2; ++t) {
@@ -728,11 +734,16 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
         const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
         uint4 regs[NT];
         stage_loadN<NT>(regs, qp, a.ld, dop, (int64_t)a.H * D, 0, a.S);
-        float lt = 0.f, et = 0.f;
-        if (threadIdx.x < QS) {
-            lt = (threadIdx.x < a.S) ? -lsep[threadIdx.x] * LOG2E : -INFINITY;
-            et = (threadIdx.x < a.S) ? -delp[threadIdx.x] * dscale : 0.f;
-        }
+        float lt = 0.f, et = 0.f;     // raw, one stage ahead (see k_attn_bwd_dkv_bf16)
+        auto load_consts = [&](int64_t qbase) {
+            if (threadIdx.x < QS) {
+                int64_t qq = qbase + threadIdx.x;
+                qq = qq < a.S ? qq : (int64_t)a.S - 1;
+                lt = lsep[qq];
+                et = delp[qq];
+            }
+        };
+        load_consts(0);
         uint32_t rk = 0, bsel[KB];
         if constexpr (DROP) {
             const int bh = b * a.H + head;
@@ -748,16 +759,16 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
         for (int64_t q0 = 0; q0 < a.S; q0 += QS) {
             __syncthreads();
             stage_storeN<NT>(regs, lds);
-            if (threadIdx.x < QS) { lse_s[threadIdx.x] = lt; del_s[threadIdx.x] = et; }
+            if (threadIdx.x < QS) {
+                const bool in = q0 + threadIdx.x < a.S;
+                lse_s[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;
+                del_s[threadIdx.x] = in ? -et * dscale : 0.f;
+            }
             if constexpr (DROP) stage_row_words<QS>(aw_s, rk, q0);
             __syncthreads();
             if (q0 + QS < a.S) {
                 stage_loadN<NT>(regs, qp, a.ld, dop, (int64_t)a.H * D, q0 + QS, a.S);
-                if (threadIdx.x < QS) {
-                    const int64_t qq = q0 + QS + threadIdx.x;
-                    lt = (qq < a.S) ? -lsep[qq] * LOG2E : -INFINITY;
-                    et = (qq < a.S) ? -delp[qq] * dscale : 0.f;
-                }
+                load_consts(q0 + QS);
             }
 #pragma unroll 1
             for (int t = 0; t < NT; ++t) {
