@@ -1108,9 +1108,7 @@ struct FusedArgs {
 // mask-generation instructions per pair instead of 4, and half the row-word reads.
 // ORD (with PK): 0 = all of a tile's exp / mask work, then all of its dV / dK products; 1 = key block by key block (block 0's
 // dV / dK MFMAs are in flight under block 1's exp / mask stream)
-// PRIO: 0 = s_setprio 1 / 0 around the S / dP cluster of every tile, all waves alike; 1 = the same with waves >= W/2 one
-// level higher throughout (2 / 1; base 1); 2 = waves >= W/2 at static priority 1, no flips; 3 = no priority at all
-template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0, int SB = 0, int PRIO = 0>
+template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0, int SB = 0>
 __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 : 2)) void k_attn_bwd_fused(FusedArgs fa) {
     using L = FusedLds<FB_WAVES, FB_KB, FB_NT>;
     constexpr int FB_QS = L::QS, FB_OFF_STAGE = L::STAGE, FB_OFF_LSE = L::LSE, FB_OFF_DEL = L::DEL, FB_OFF_AW = L::AW, FB_OFF_K = L::K;
@@ -1144,13 +1142,10 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     };
     // priority between the two waves of a SIMD (lab): 0 = s_setprio flips around the S / dP MFMA cluster of every tile (both
     // waves alike), 1 = waves >= W/2 at static priority 1 and no flips, 2 = waves < W/2 at static priority 1, 3 = none
-    const bool lead = (__builtin_amdgcn_readfirstlane(threadIdx.x) >> 6) < FB_WAVES / 2;
-    if constexpr (PRIO == 1 || PRIO == 2) {
-        if (!lead) __builtin_amdgcn_s_setprio(1);
-    }
-    // (measured and removed, profiles/r4_b / r4_e: static priority for either half of the waves +1.5 ... +8 %, no priority
-    // +1.4 %, priority for one half inside its MFMA clusters only: no gain; RUNTIME-conditional s_setprio splits the basic
-    // blocks around the clusters and changed the dropout kernel's schedule by +30 %: the flips below are unconditional)
+    // (measured and removed, profiles/r4_b / r4_e / r4_h: static priority for either half of the waves, priority for one half
+    // inside its MFMA clusters only, one half a level higher throughout, no priority at all: within +-1.5 % at compile time;
+    // RUN-TIME-conditional s_setprio splits the basic blocks around the clusters and changed the dropout kernel's schedule by
+    // +30 %: the flips around the S / dP cluster are unconditional)
     // SB: bit i = __builtin_amdgcn_sched_barrier(0) at phase boundary i (1: after the S / dP cluster, 2: after the exp / mask
     // stream, 4: after the dV / dK products, 8: after the dQ products) -- pins the compiler's schedule at those points
     const int64_t key0 = (int64_t)slab * FB_KEYS + wave * (32 * FB_KB);
@@ -1355,8 +1350,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 const bf16x8 qa0 = frag_rows(qt, l31, hf, 0), da0 = frag_rows(dt, l31, hf, 0);
                 const bf16x8 qa1 = frag_rows(qt, l31, hf, 1), da1 = frag_rows(dt, l31, hf, 1);
                 f32x16 sc[FB_KB], dp[FB_KB];
-                if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(1);
-                if constexpr (PRIO == 1) { if (lead) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[kb][0], lc, 0, 0, 0);
@@ -1364,8 +1358,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[kb][1], sc[kb], 0, 0, 0);
                     dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[kb][1], dp[kb], 0, 0, 0);
                 }
-                if constexpr (PRIO == 0) __builtin_amdgcn_s_setprio(0);
-                if constexpr (PRIO == 1) { if (lead) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                __builtin_amdgcn_s_setprio(0);
                 if constexpr ((SB & 1) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(5);        // row constants + row fragments read, S / dP MFMAs issued
                 const bf16x8 dc0 = frag_cols(dt, lane, 0), dc1 = frag_cols(dt, lane, 1);
@@ -1790,6 +1783,8 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/r4_h_attn_bwd_prio_stamps.txt)
             // (double-buffered stage tiles filled by the first half of the waves before the stage barrier -- to use their 17 % of
             // barrier idle time -- measured 0.97 / 0.795 ms against 0.89 / 0.786: profiles/r4_i_attn_bwd_double_buffer_lab.txt; removed)
+            // (all S products before the dP products, with and without a pin behind the cluster, and a pin after the dV / dK block:
+            // within +-1 % -- profiles/r4_k_attn_bwd_cluster_order_lab.txt)
             else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
