@@ -1085,10 +1085,8 @@ struct FusedLds {
     static constexpr int AW = DEL + QS * 4;                          // uint32[2 * QS + 8]
     static constexpr int K = AW + (2 * QS + 8) * 4;                  // per wave KB K tiles
     static constexpr int DS = K + W * KB * TILE_BYTES;               // per wave KB dS tiles
-    static constexpr bool SLOT16 = NT >= 4;                          // 128-query stages: the waves' dQ partials as bf16 (LDS budget)
-    static constexpr int SLOT_BYTES = SLOT16 ? 2048 : 4096;
-    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32 (or bf16)
-    static constexpr int TOTAL = SLOT + NT * W * SLOT_BYTES;
+    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32
+    static constexpr int TOTAL = SLOT + NT * W * 4096;
     static constexpr int KEYS = W * KB * 32;
 };
 
@@ -1140,8 +1138,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // priority between the two waves of a SIMD (lab): 0 = s_setprio flips around the S / dP MFMA cluster of every tile (both
-    // waves alike), 1 = waves >= W/2 at static priority 1 and no flips, 2 = waves < W/2 at static priority 1, 3 = none
+    // priority between the two waves of a SIMD: s_setprio flips around the S / dP MFMA cluster of every tile, both waves alike
     // (measured and removed, profiles/r4_b / r4_e / r4_h: static priority for either half of the waves, priority for one half
     // inside its MFMA clusters only, one half a level higher throughout, no priority at all: within +-1.5 % at compile time;
     // RUN-TIME-conditional s_setprio splits the basic blocks around the clusters and changed the dropout kernel's schedule by
@@ -1191,8 +1188,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     constexpr int NSTG = NTHR;
     constexpr int NST = 2 * FB_NT * 128 / NSTG;
     // slot reduction: NT 256 (tile, query, 16-byte chunk) items per stage -> 4 consecutive d each, NRS per thread
-    constexpr bool SLOT16 = L::SLOT16;
-    constexpr int NRS = (SLOT16 ? FB_NT * 128 : FB_NT * 256) / NTHR;    // bf16 slots: 8 d per 16-byte item
+    constexpr int NRS = FB_NT * 256 / NTHR;
     static_assert(NST >= 1 && NRS >= 1 && FB_QS <= NTHR, "stage shape vs workgroup size");
 
     for (int hr = 0; hr < rep; ++hr) {
@@ -1224,41 +1220,18 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
 #pragma unroll
             for (int it = 0; it < NRS; ++it) {
                 const int idx = threadIdx.x + it * NTHR;
-                if constexpr (!SLOT16) {
-                    const int rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
-                    const int64_t q = q0 + 32 * rt + rq;
-                    const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
-                    float4 acc = *reinterpret_cast<const float4*>(sp);
+                const int rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
+                const int64_t q = q0 + 32 * rt + rq;
+                const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
+                float4 acc = *reinterpret_cast<const float4*>(sp);
 #pragma unroll
-                    for (int w = 1; w < FB_WAVES; ++w) {
-                        const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
-                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                    }
-                    if (q < a.S)
-                        *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
-                            make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
-                } else {
-                    // bf16 slots: [q][32 d] rows of 64 bytes, 16-byte chunk c (8 d) at chunk c ^ ((q >> 2) & 3); fp32 sum in wave order
-                    const int rt = idx >> 7, rq = (idx >> 2) & 31, rc = idx & 3;
-                    const int64_t q = q0 + 32 * rt + rq;
-                    const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 2048 + rq * 64 + ((rc ^ ((rq >> 2) & 3)) << 4);
-                    float acc[8];
-#pragma unroll
-                    for (int w = 0; w < FB_WAVES; ++w) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(sp + w * 2048);
-                        const uint32_t pk[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float lo = __uint_as_float(pk[j] << 16), hi = __uint_as_float(pk[j] & 0xffff0000u);
-                            acc[2 * j] = w == 0 ? lo : acc[2 * j] + lo;
-                            acc[2 * j + 1] = w == 0 ? hi : acc[2 * j + 1] + hi;
-                        }
-                    }
-                    if (q < a.S)
-                        *reinterpret_cast<uint4*>(part + q * D + 8 * rc) =
-                            make_uint4((unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16), (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16),
-                                       (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16), (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16));
+                for (int w = 1; w < FB_WAVES; ++w) {
+                    const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
+                if (q < a.S)
+                    *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
+                        make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
             }
         };
         uint4 regs[NST];
@@ -1338,7 +1311,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 }
             }
             STAMP(4);            // issue of the next stage's global loads
-#pragma unroll(FB_NT >= 4 ? 1 : FB_NT)
+#pragma unroll
             for (int t = 0; t < FB_NT; ++t) {
                 if (q0 + 32 * t >= a.S) break;
                 if constexpr ((SB & 16) != 0) __builtin_amdgcn_sched_barrier(0);
@@ -1479,20 +1452,11 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 // slot [q = l31][32 d] fp32, 16-byte chunk index (2 g + hf) XOR (q & 7): conflict-free stores and reduction reads
                 if constexpr ((SB & 8) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(8);        // dS round trip through LDS + dQ MFMAs issued
-                if constexpr (!SLOT16) {
-                    char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
+                char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 4096 + l31 * 128;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
-                            make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
-                } else {   // bf16: d = 8 g + 4 hf .. + 3 -> 8 bytes at chunk g ^ ((q >> 2) & 3), half hf
-                    char* slot = lds + FB_OFF_SLOT + (t * FB_WAVES + wave) * 2048 + l31 * 64 + 8 * hf;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<uint2*>(slot + ((g ^ ((l31 >> 2) & 3)) << 4)) =
-                            make_uint2((unsigned)f2bf(dq[4 * g]) | ((unsigned)f2bf(dq[4 * g + 1]) << 16),
-                                       (unsigned)f2bf(dq[4 * g + 2]) | ((unsigned)f2bf(dq[4 * g + 3]) << 16));
-                }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(slot + (((2 * g + hf) ^ (l31 & 7)) << 4)) =
+                        make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
                 STAMP(9);        // wait for the dQ MFMAs + slot stores
             }
         }
@@ -1753,7 +1717,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
             // (128-query stages with bf16 slots -- FB_NT = 4 -- measured 1.07 / 0.81 ms against 0.90 / 0.76: spills in the
-            // dropout variant, profiles/r4_g_attn_lab.txt; the layout code stays, the instantiation is gone)
+            // dropout variant, profiles/r4_g_attn_lab.txt; removed)
             else if (variant == 7 && drop)   // round-3 mask arithmetic (row words per query, xor + compare per element)
                 rc = go(k_attn_bwd_fused<true, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             else if (want_stamps && drop) {    // diagnostic build: cycles per phase of the PK kernel, printed to stderr

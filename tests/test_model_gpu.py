@@ -235,8 +235,17 @@ if E("GAOT_TEST_SEGMENTED") == "1":
     torch.cuda.synchronize()
     loss = sg.result
     worst = max(float((p.grad - eager[k_]).abs().max()) for k_, p in model.named_parameters() if p.grad is not None)
+    # device-time split of one more replay and of one eager step (comm.ExchangeProfile: what bench.py --gpus N reports)
+    prof = sg.replay_profiled(1)
+    with comm.eager_profile() as ep:
+        one()
+    torch.cuda.synchronize()
+    eprof = ep.summary(1)
     extra = {"segments": sg.num_segments, "exchanges": sg.num_exchanges, "replay_vs_eager_max_abs": worst,
-             "replay_loss_minus_eager": float(loss) - eager_loss}
+             "replay_loss_minus_eager": float(loss) - eager_loss,
+             "profile": {k_: prof[k_] for k_ in ("step_device_ms", "exchange_device_ms", "compute_device_ms")},
+             "profile_kinds": {k_: [v_["count"], v_["bytes"]] for k_, v_ in prof["kinds"].items()},
+             "eager_profile_kinds": sorted(eprof["kinds"])}
 if rank == 0:
     out = {"loss": float(loss), "grads": {k_: p.grad.detach().cpu().double().flatten()[:64].tolist() for k_, p in model.named_parameters() if p.grad is not None},
            "norms": {k_: float(p.grad.detach().double().norm()) for k_, p in model.named_parameters() if p.grad is not None}, **extra}
@@ -425,6 +434,14 @@ def test_segmented_graph_replay_equals_eager_one_gpu(tmp_path, prec, parallel):
           f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
     assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
     assert got["segments"] == got["exchanges"] + 1 and got["segments"] + got["exchanges"] <= 60    # L = 2
+    # the device-time split bench.py --gpus N reports (comm.ExchangeProfile): every exchange is accounted for under its kind,
+    # with its payload, and the two parts add up to the step
+    pr, kinds = got["profile"], got["profile_kinds"]
+    assert sum(int(round(c)) for c, _ in kinds.values()) == got["exchanges"]
+    assert abs(pr["exchange_device_ms"] + pr["compute_device_ms"] - pr["step_device_ms"]) <= 1e-2 and pr["compute_device_ms"] > 0
+    want = {"all_reduce", "grad_bucket_issue", "grad_bucket_wait"} | ({"all_to_all"} if parallel == "seq" else {"all_gather"})
+    assert want <= set(kinds) and want <= set(got["eager_profile_kinds"]), (sorted(kinds), got["eager_profile_kinds"])
+    assert all(b > 0 for k_, (c, b) in kinds.items() if k_ not in ("grad_bucket_wait",))
 
 
 def test_segmented_graph_replay_over_rccl_one_rank(tmp_path):
