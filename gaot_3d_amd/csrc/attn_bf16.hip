@@ -1121,6 +1121,11 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     const int hkv = blockIdx.x % a.HKV, b = blockIdx.z, slab = blockIdx.x / a.HKV;   // head-fastest: one (kv) head per XCD
     const int rep = a.H / a.HKV;
+    // query range of this workgroup (blockIdx.y): few heads per launch -- the heads of one rank of a sharded step -- leave
+    // S/512 * heads workgroups, too few for 256 CUs; the queries are then split over P parts of `chunk` rows (a multiple of the
+    // stage), every part keeps dK / dV partials of its own (dqkv + part * dqkv_part, summed in part order by k_sum_cols) and
+    // writes the slab partials of ITS queries
+    const int64_t q_lo = (int64_t)blockIdx.y * a.chunk, q_hi = min((int64_t)a.S, q_lo + a.chunk);
     // in-kernel stamps (ORD == 2 only: a diagnostic instantiation, never the product's): cycles between consecutive stamp
     // points, summed per wave; index = the stamp that CLOSES the interval
     unsigned long long st_acc[16], st_last = 0;
@@ -1235,7 +1240,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             }
         };
         uint4 regs[NST];
-        stage_load(regs, 0);
+        stage_load(regs, q_lo);
         // -lse / -delta of the stage's queries: loaded RAW (clamped address, no arithmetic on the value) one stage ahead, so
         // that the wait for them falls where they are stored -- a whole stage later -- and not right behind the load (an
         // `if (q < S) x = -lse[q] * c` puts load, s_waitcnt vmcnt(0) and multiply into one block: wave 0 then sat out two
@@ -1249,7 +1254,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 et = delp[qq];
             }
         };
-        load_consts(0);
+        load_consts(q_lo);
         uint32_t rk = 0, bsel[FB_KB];
         if constexpr (DROP) {
             const int bh = b * a.H + head;
@@ -1292,7 +1297,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         const float* lse_s = reinterpret_cast<const float*>(sbuf + FB_OFF_LSE);
         const float* del_s = reinterpret_cast<const float*>(sbuf + FB_OFF_DEL);
         const uint32_t* aw_s = reinterpret_cast<const uint32_t*>(sbuf + FB_OFF_AW);
-        for (int64_t q0 = 0; q0 < a.S; q0 += FB_QS) {
+        for (int64_t q0 = q_lo; q0 < q_hi; q0 += FB_QS) {
             {
                 STAMP(0);            // end of the previous stage's tiles (incl. its slot stores)
                 __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
@@ -1301,11 +1306,11 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 // counts stores too: behind the store the wait would cover its whole round trip)
                 stage_store(regs, sbuf);
                 stage_consts(sbuf, q0);
-                if (q0 > 0) reduce_slots(q0 - FB_QS);
+                if (q0 > q_lo) reduce_slots(q0 - FB_QS);
                 STAMP(2);            // staging stores + slot reduction
                 __syncthreads();     // B
                 STAMP(3);            // wait at barrier B
-                if (q0 + FB_QS < a.S) {
+                if (q0 + FB_QS < q_hi) {
                     stage_load(regs, q0 + FB_QS);
                     load_consts(q0 + FB_QS);
                 }
@@ -1313,7 +1318,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             STAMP(4);            // issue of the next stage's global loads
 #pragma unroll
             for (int t = 0; t < FB_NT; ++t) {
-                if (q0 + 32 * t >= a.S) break;
+                if (q0 + 32 * t >= q_hi) break;
                 if constexpr ((SB & 16) != 0) __builtin_amdgcn_sched_barrier(0);
                 const char* qt = sbuf + FB_OFF_STAGE + t * TILE_BYTES;
                 const char* dt = sbuf + FB_OFF_STAGE + (FB_NT + t) * TILE_BYTES;
@@ -1461,12 +1466,12 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             }
         }
         __syncthreads();
-        reduce_slots(((a.S - 1) / FB_QS) * (int64_t)FB_QS);
+        reduce_slots(q_lo + ((q_hi - 1 - q_lo) / FB_QS) * (int64_t)FB_QS);
     }
     if constexpr (ORD == 2) {
         if (fa.stamps && lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) fa.stamps[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * FB_WAVES + wave) * 16 + i] = st_acc[i];
+            for (int i = 0; i < 16; ++i) fa.stamps[((int64_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * FB_WAVES + wave) * 16 + i] = st_acc[i];
         }
     }
     const float vsc = DROP ? a.drop.inv_keep : 1.f;
@@ -1475,8 +1480,8 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     for (int kb = 0; kb < FB_KB; ++kb) {
         const int64_t ki = key0 + 32 * kb + l31;
         if (ki < a.S) {
-            float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
-            float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+            float* dkp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+            float* dvp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 t = make_float4(dkt[kb][4 * g] * ksc, dkt[kb][4 * g + 1] * ksc, dkt[kb][4 * g + 2] * ksc, dkt[kb][4 * g + 3] * ksc);
@@ -1552,6 +1557,22 @@ __global__ void k_sum_parts(const float* __restrict__ parts, int P, int64_t part
     reinterpret_cast<float4*>(out)[i] = acc;
 }
 
+// out[row][col0 .. col0 + ncols) = sum_p parts[p][row][col0 ..)  (fixed order; ncols % 4 == 0): the dK / dV columns of the
+// query-range parts of the fused backward -- the dq columns of the parts are never written
+__global__ void k_sum_cols(const float* __restrict__ parts, int P, int64_t part, int64_t rows, int ld, int col0, int ncols,
+                           float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = ncols / 4;
+    if (i >= rows * c4) return;
+    const int64_t off = (i / c4) * ld + col0 + 4 * (i % c4);
+    float4 acc = *reinterpret_cast<const float4*>(parts + off);
+    for (int p = 1; p < P; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(parts + p * part + off);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + off) = acc;
+}
+
 // number of range parts for a launch whose unsplit grid has `wgs` workgroups: aim at eight workgroups per CU,
 // keep at least 1024 streamed rows per part
 int split_parts(int64_t wgs, int S) {
@@ -1584,12 +1605,21 @@ extern "C" size_t gaot_attn_bf16_image_bytes(int B, int S, int H, int HKV) {
 // ... and when its dQ slab partials -- B * H * ceil(S/512) * S * 32 bf16, QUADRATIC in S: 268 MB at S = 16 384, 4.3 GB at
 // S = 65 536 -- stay under 1 GiB; longer sequences keep the two-pass form, whose scratch is O(S)
 static size_t fused_dqpart_bytes(int B, int S, int H) { return (size_t)B * H * (size_t)ceil_div(S, 512) * (size_t)S * D * sizeof(bf16_t); }
+// query-range parts of the fused backward: the smallest power of two that brings its grid to one workgroup per CU, at most 8,
+// at least 1024 queries per part
+static int fused_parts(int B, int S, int HKV) {
+    const int64_t wgs = (int64_t)ceil_div(S, 512) * HKV * B;
+    int p = 1;
+    while (wgs * p < 256 && p < 8 && S / (2 * p) >= 1024) p *= 2;
+    return p;
+}
+static int fused_chunk(int S, int P) { return (int)(ceil_div(ceil_div(S, P), 64) * 64); }
 static bool fused_bwd_ok(int B, int S, int H, int HKV) {
-    return (int64_t)ceil_div(S, 512) * HKV * B >= 128 && fused_dqpart_bytes(B, S, H) <= ((size_t)1 << 30);
+    return (int64_t)ceil_div(S, 512) * HKV * B * fused_parts(B, S, HKV) >= 128 && fused_dqpart_bytes(B, S, H) <= ((size_t)1 << 30);
 }
 extern "C" int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV) { return fused_bwd_ok(B, S, H, HKV) ? 1 : 0; }
-static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {
-    const int P = split_parts(ceil_div(S, 128) * H * B, S);
+static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {   // range parts of the two-pass kernels or of the fused one
+    const int P = std::max(split_parts(ceil_div(S, 128) * H * B, S), fused_bwd_ok(B, S, H, HKV) ? fused_parts(B, S, HKV) : 1);
     return P > 1 ? align256((size_t)P * (size_t)B * S * (H + 2 * HKV) * D * sizeof(float)) : 0;
 }
 extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV) {
@@ -1686,19 +1716,23 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                            S, H);
     if (phase_mask & (16 | 32)) {   // 16: dK / dV and dQ slab partials from one pass over the score tiles; 32: the slab reduction
         if (!fused_bwd_ok(B, S, H, HKV)) {
-            gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need ceil(S/512)*HKV*B >= 128 workgroups and <= 1 GiB of dQ slab partials; use phases 2 and 4");
+            gaot_set_error("gaot_attn_bwd_bf16: phases 16 / 32 (fused backward) need >= 128 workgroups (ceil(S/512)*HKV*B times up to 8 query parts of >= 1024 rows) and <= 1 GiB of dQ slab partials; use phases 2 and 4");
             return GAOT_ERR_UNSUPPORTED;
         }
         const int nslab = (int)ceil_div(S, 512);      // 512 keys per workgroup in every variant
         bf16_t* dqpart = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(parts) + bwd_parts_bytes(B, S, H, HKV));
+        const int Pf = fused_parts(B, S, HKV), chunk_f = Pf > 1 ? fused_chunk(S, Pf) : S;
+        const unsigned nyf = (unsigned)(Pf > 1 ? ceil_div(S, chunk_f) : 1);
         BwdArgs af = a;
-        af.dqkv = dqkv;
-        static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();   // 0..6
+        af.dqkv = Pf > 1 ? parts : dqkv;      // dK / dV of a query part go to its own copy, summed below
+        af.chunk = chunk_f;
+        af.dqkv_part = dqkv_part;
+        static const int lab = [] { const char* e = getenv("GAOT_ATTN_BWD_LAB"); return e ? atoi(e) : 0; }();   // lab: schedule pins
         FusedArgs fa{af, dqpart, nslab, lab, nullptr};
         static const bool want_stamps = [] { const char* e = getenv("GAOT_ATTN_BWD_STAMPS"); return e && atoi(e) != 0; }();
         static unsigned long long* stamp_buf = nullptr;
-        const size_t stamp_n = (size_t)nslab * HKV * B * 8 * 16;
-        const dim3 gf((unsigned)(nslab * HKV), 1, (unsigned)B);
+        const size_t stamp_n = (size_t)nslab * HKV * B * nyf * 8 * 16;
+        const dim3 gf((unsigned)(nslab * HKV), nyf, (unsigned)B);
         auto go = [&](auto kern, int lds_bytes, int nthr) -> int {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) {
@@ -1753,6 +1787,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;
         }
+        if ((phase_mask & 16) && Pf > 1)   // dK / dV columns: sum of the query parts, part order
+            GAOT_KLAUNCH(k_sum_cols, dim3((unsigned)ceil_div((int64_t)B * S * (2 * HKV * D / 4), 256)), dim3(256), 0, st, parts, (int)nyf,
+                         dqkv_part, (int64_t)B * S, ld, H * D, 2 * HKV * D, dqkv);
         const float qsc = drop ? scale * a.drop.inv_keep : scale;
         if (phase_mask & 32)
             GAOT_KLAUNCH(k_attn_dq_reduce, dim3((unsigned)ceil_div((int64_t)B * H * S * 8, 256)), dim3(256), 0, st, dqpart, nslab, B, S, H,

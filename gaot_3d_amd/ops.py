@@ -494,7 +494,8 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b:
     doimg = do_image if do_image is not None else attn_bwd_scratch(b, s, h, hkv, dev)
     can_fuse = bool(lib.gaot_attn_bwd_bf16_fused_eligible(b, s, h, hkv))
     if fused and not can_fuse:
-        raise GaotError("attn_bwd_bf16: the fused backward needs ceil(S/512) * hkv * b >= 128 workgroups")
+        raise GaotError("attn_bwd_bf16: the fused backward needs >= 128 workgroups (ceil(S/512) * hkv * b, times up to 8 query "
+                        "parts of >= 1024 rows) and <= 1 GiB of dQ slab partials")
     phases = ((("attn_bwd", 16), ("attn_bwd_dq_reduce", 32)) if (can_fuse if fused is None else fused)
               else (("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)))
     for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1),) + phases:

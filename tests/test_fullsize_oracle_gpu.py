@@ -145,10 +145,13 @@ def test_attention_fused_backward_vs_fp64_oracle(p):
         PAR.close_peak(f"{tag}/{nm} vs fp64", got, want, 2e-2)   # achieved ~8e-3 (2e-2 of peak)
 
 
-@pytest.mark.parametrize("b,s,h,hkv,p", [(8, 2085, 8, 4, 0.1), (2, 4133, 8, 8, 0.0), (1, 16384 - 37, 8, 4, 0.1)])
+@pytest.mark.parametrize("b,s,h,hkv,p", [(8, 2085, 8, 4, 0.1), (2, 4133, 8, 8, 0.0), (1, 16384 - 37, 8, 4, 0.1),
+                                         (1, 16384, 1, 1, 0.1), (1, 16384, 2, 1, 0.0), (1, 9000 + 13, 2, 2, 0.1), (1, 16384, 4, 4, 0.1)])
 def test_attention_fused_backward_ragged_gqa_batches(b, s, h, hkv, p):
     """ragged sequence lengths (keys and queries past S inside the last slab / stage), grouped-query heads (a workgroup loops
-    over the heads of its kv head) and batches: fused against the two-pass kernels on the same image"""
+    over the heads of its kv head), batches, and FEW heads per launch (the heads one rank of a sharded step owns: the queries
+    are split into up to eight parts whose dK / dV partials are summed in part order): fused against the two-pass kernels on
+    the same image"""
     from gaot_3d_amd import ops
     g = torch.Generator().manual_seed(s)
     qkv = (torch.randn(b * s, (h + 2 * hkv) * 32, generator=g) * 0.7).to(DEV)
@@ -158,9 +161,11 @@ def test_attention_fused_backward_ragged_gqa_batches(b, s, h, hkv, p):
     scale = 32 ** -0.5
     o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, p, st)
     a = ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, hkv, scale, p, st, freqs=freqs, fused=True)
+    a2 = ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, hkv, scale, p, st, freqs=freqs, fused=True)
     r = ops.attn_bwd_bf16(img, o, d_o, lse, b, s, h, hkv, scale, p, st, freqs=freqs, fused=False)
     torch.cuda.synchronize()
     assert torch.isfinite(a).all()
+    assert torch.equal(a, a2)          # fixed summation orders (slabs, waves, query parts): bit-identical reruns
     for nm, lo, hi in (("dq", 0, h * 32), ("dk", h * 32, (h + hkv) * 32), ("dv", (h + hkv) * 32, (h + 2 * hkv) * 32)):
         PAR.cosine(f"attn_fused_ragged_b{b}_s{s}/{nm}", a[:, lo:hi], r[:, lo:hi], 0.99999)
         PAR.close_peak(f"attn_fused_ragged_b{b}_s{s}/{nm}", a[:, lo:hi], r[:, lo:hi], 1e-2)
