@@ -679,9 +679,11 @@ int bwd_grid(int64_t E) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_tiles, 4), 256));
 }
 
-bool mlp_supported(const gaot_mlp_t* m, bool backward) {
-    // backward keeps h_1..h_NH of four 32-edge tiles in LDS: NH = 4 would need 172 KB (> 160 KB/CU)
-    return m && m->channels == 32 && (m->hidden == 64) && m->n_hidden >= 1 && m->n_hidden <= (backward ? 3 : 4);
+bool mlp_supported(const gaot_mlp_t* m, bool backward, int precision = 0) {
+    // the exact-fp32 backward keeps h_1..h_NH of four 32-edge tiles in LDS: NH = 4 would need 172 KB (> 160 KB/CU); the bf16
+    // backward reads its operand fragments from L2 at four hidden layers (gno_bwd3_bf16.hip) and takes them
+    return m && m->channels == 32 && (m->hidden == 64) && m->n_hidden >= 1 &&
+           m->n_hidden <= (backward ? (precision == 1 ? 4 : 3) : 4);
 }
 
 }  // namespace
@@ -765,8 +767,8 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
                             int precision, void* workspace, size_t workspace_bytes, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(mlp && grads, "null mlp");
-    if (!mlp_supported(mlp, true)) {
-        gaot_set_error("gaot_gno_bwd: unsupported MLP shape (n_hidden=%d hidden=%d channels=%d)", mlp->n_hidden,
+    if (!mlp_supported(mlp, true, precision)) {
+        gaot_set_error("gaot_gno_bwd: unsupported MLP shape (n_hidden=%d hidden=%d channels=%d; four hidden layers in bf16 mode only)", mlp->n_hidden,
                        mlp->hidden, mlp->channels);
         return GAOT_ERR_UNSUPPORTED;
     }

@@ -90,7 +90,10 @@ struct Lds3 {
     static constexpr int img_bytes = 2 * ((NH - 1) * per_hidden + per_last);   // fw[1..NH-1], fw[NH], bw[1..NH-1], bw[NH]
     static constexpr int fw(int l) { return (l - 1) * per_hidden; }            // l = 1..NH (NH = last)
     static constexpr int bw(int l) { return (NH - 1) * per_hidden + per_last + (l - 1) * per_hidden; }
-    static constexpr int w0t = img_bytes;                       // float [8][64] (rows 6, 7 zero)
+    // four hidden layers: 56 KB of images + eight waves' tiles (8 x 18.5 KB) do not fit 160 KB -- the fragments are then read
+    // from the image buffer in global memory (1 KB per wave instruction, coalesced, L2 resident) instead of LDS
+    static constexpr bool GIMG = NH >= 4;
+    static constexpr int w0t = GIMG ? 0 : img_bytes;             // float [8][64] (rows 6, 7 zero)
     static constexpr int bias = w0t + 8 * H * 4;                // float NH*64 + 32
     static constexpr int tiles = (bias + (NH * H + C) * 4 + 15) & ~15;
     static constexpr int h(int l) { return l * 2048; }          // per-wave offsets: [16 e][64 f] bf16
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4, l31 = lane & 31, hf = lane >> 5;
 
     // ---- resident operands: fragment images (k_prep_bwd3_images), layer-0 weight, biases ------------------------------
-    for (int i = threadIdx.x; i < L::img_bytes / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = images[i];
+    if constexpr (!L::GIMG)
+        for (int i = threadIdx.x; i < L::img_bytes / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = images[i];
     {
         float* w0 = reinterpret_cast<float*>(lds + L::w0t);
         for (int i = threadIdx.x; i < 8 * H; i += 512) w0[i] = (i < IN0 * H) ? w0t_g[i] : 0.f;
@@ -163,7 +167,10 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
     __syncthreads();
     const float* w0 = reinterpret_cast<const float*>(lds + L::w0t);
     const float* bias_l = reinterpret_cast<const float*>(lds + L::bias);
-    auto img = [&](int off_bytes, int frag) { return reinterpret_cast<const bf16x8*>(lds + off_bytes)[frag * 64 + lane]; };
+    auto img = [&](int off_bytes, int frag) {
+        if constexpr (L::GIMG) return reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(images) + off_bytes)[frag * 64 + lane];
+        else return reinterpret_cast<const bf16x8*>(lds + off_bytes)[frag * 64 + lane];
+    };
     auto wave_base = [&](int w) { return lds + L::tiles + w * L::per_wave; };
     char* mine = wave_base(wave);
     char* dkT = mine + L::dk;
@@ -174,14 +181,18 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
     //   X(x): x = 0, 1: dW_L[:, 32 x..] (+ db_L on x = 0);  x = 2, 3: dW_0[32 (x-2).., :] (column 6 = the ones row = db_0)
     // NH = 3: every wave one H job and one X job over half of the tiles; NH = 2: waves 0-3 H, waves 4-7 X, all tiles;
     // NH = 1: X over half of the tiles.  Halves are added in the epilogue (waves 4-7 into 0-3), a fixed order.
-    const bool has_h = (NH == 3) || (NH == 2 && wave < 4);
-    const bool has_x = (NH != 2) || wave >= 4;
-    const int hl = (NH == 3) ? 1 + (wave >> 2) : 1, hjb = (wave >> 1) & 1, hkb = wave & 1;
+    // NH = 4 (sixteen jobs, two per wave over all tiles): every wave H(l = 1 + (wave >> 2), jb, kb); waves 0-3 also H(3, jb, kb),
+    // waves 4-7 the X jobs.  The bias gradients of all of a wave's jobs share `bacc`: job (layer l) lands in column l.
+    const bool has_h = (NH >= 3) || (NH == 2 && wave < 4);
+    const bool has_h2 = (NH == 4) && wave < 4;
+    const bool has_x = (NH == 1 || NH == 3) || wave >= 4;
+    const int hl = (NH >= 3) ? 1 + (wave >> 2) : 1, hjb = (wave >> 1) & 1, hkb = wave & 1;
     const int xj = wave & 3;
-    const int xt0 = (NH == 2) ? 0 : 4 * (wave >> 2), xt1 = (NH == 2) ? 8 : xt0 + 4;
-    f32x16 acc_h, acc_x, bacc;
+    const bool x_all = NH == 2 || NH == 4;
+    const int xt0 = x_all ? 0 : 4 * (wave >> 2), xt1 = x_all ? 8 : xt0 + 4;
+    f32x16 acc_h, acc_x, bacc, acc_h2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc_h[r] = 0.f; acc_x[r] = 0.f; bacc[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc_h[r] = 0.f; acc_x[r] = 0.f; bacc[r] = 0.f; acc_h2[r] = 0.f; }
     auto sel = [&](int col) {   // one-hot selector fragment: B[e][n] = (n == col)
         bf16x8 f;
         const short one = (l31 == col) ? (short)0x3F80 : (short)0;
@@ -446,6 +457,11 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
                 acc_h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_cols16(wb + L::h(hl - 1) + hkb * 1024, lane), acc_h, 0, 0, 0);
                 if (hkb == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, sel(hl), bacc, 0, 0, 0);
             }
+            if (NH == 4 && has_h2) {
+                const bf16x8 a = frag_cols16(wb + L::dz(NH - 1) + hjb * 1024, lane);
+                acc_h2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_cols16(wb + L::h(NH - 2) + hkb * 1024, lane), acc_h2, 0, 0, 0);
+                if (hkb == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, sel(NH - 1), bacc, 0, 0, 0);
+            }
             if (has_x && t >= xt0 && t < xt1) {
                 if (xj < 2) {
                     // dW_L[c][k] += sum_e dk[c][e] h_{NH-1}[k][e] (k-block = xj); db_L rides on xj = 0
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
     }
 
     // ---- halves of the X jobs (and of db_L): waves 4-7 hand theirs to waves 0-3 through LDS, added in that order -----------
-    if (NH != 2) {
+    if (NH == 1 || NH == 3) {
         float* xs = reinterpret_cast<float*>(mine);   // 16 x 64 floats per wave (4 KB of its tile area)
         float* bs = reinterpret_cast<float*>(lds);    // bacc of wave 4: the image area is free now (>= 8 KB)
         if (wave >= 4) {
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
 
     // ---- workgroup partial (reduced over workgroups in fixed order by k_reduce_params) ---------------------------------------
     float* wp = wpart + (int64_t)blockIdx.x * PL::total;
-    if (has_x && (NH == 2 || wave < 4)) {
+    if (has_x && (x_all || wave < 4)) {
         if (xj < 2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) wp[PL::w_off(NH) + mfma32_row(r, hf) * H + 32 * xj + l31] = acc_x[r];
@@ -514,6 +530,15 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
         if (hkb == 0 && l31 == hl) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) wp[PL::b_off(hl) + 32 * hjb + mfma32_row(r, hf)] = bacc[r];
+        }
+    }
+    if (NH == 4 && has_h2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            wp[PL::w_off(NH - 1) + (32 * hjb + mfma32_row(r, hf)) * H + 32 * hkb + l31] = acc_h2[r];
+        if (hkb == 0 && l31 == NH - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[PL::b_off(NH - 1) + 32 * hjb + mfma32_row(r, hf)] = bacc[r];
         }
     }
 }
@@ -547,7 +572,7 @@ int gaot_gno_bwd3_bf16_launch(int n_hidden, void* images, const float* w0t, cons
                               const float* y_pos, const float* x_pos, const float* f_y, const float* gs,
                               const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* rowptr_src,
                               int64_t num_edges, float* grad_f, float* part, float* wpart, int grid, hipStream_t st) {
-    if (n_hidden < 1 || n_hidden > 3) {      // before anything indexes w / b / MlpPtrs with it
+    if (n_hidden < 1 || n_hidden > 4) {      // before anything indexes w / b / MlpPtrs with it
         gaot_set_error("gaot_gno_bwd (bf16): unsupported n_hidden %d", n_hidden);
         return GAOT_ERR_UNSUPPORTED;
     }
@@ -557,6 +582,7 @@ int gaot_gno_bwd3_bf16_launch(int n_hidden, void* images, const float* w0t, cons
     switch (n_hidden) {
         case 1: return launch_bwd3<1>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
         case 2: return launch_bwd3<2>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
-        default: return launch_bwd3<3>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
+        case 3: return launch_bwd3<3>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
+        default: return launch_bwd3<4>(images, w0t, p, y_pos, x_pos, f_y, gs, src_sorted, dst_sorted, rowptr_src, num_edges, grad_f, part, wpart, grid, st);
     }
 }

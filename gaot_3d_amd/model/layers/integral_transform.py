@@ -79,7 +79,7 @@ class IntegralTransform(nn.Module):
     def _fused_plan(self, fcs, f_y, y_pos):
         """(coord_dim, channels) when the fused kernels (csrc/gno*.hip: coordinates of dimension 3, hidden width 64, 32
         channels per pass) can evaluate this transform EXACTLY, possibly through zero padding; None -> general path.
-        Kernel MLP coord-pair -> 64 (x 1..3, forward-only: 4) -> C with GELU, 'linear' transform, mean reduction:
+        Kernel MLP coord-pair -> 64 (x 1..4; with gradients in fp32 mode: 1..3) -> C with GELU, 'linear' transform, mean reduction:
           * coord_dim 1 / 2 (the reference's default is 2, magno.py:28): coordinates padded with zeros to 3-D and the first
             layer's weight given zero columns for them -- the products that are added are exactly 0;
           * C != 32 (the reference's default is 16, magno.py:25): the last layer / f_y / the output are cut into blocks of 32
@@ -87,8 +87,11 @@ class IntegralTransform(nn.Module):
             C = 32 costs and C = 64 two passes (the hidden layers are recomputed), still without a per-edge tensor in HBM."""
         if self.use_attn or self.transform_type != "linear" or f_y is None:
             return None
-        # backward keeps the hidden activations of 128 edges in LDS: three hidden layers at most when gradients are needed
-        max_fcs = 4 if (torch.is_grad_enabled() and (f_y.requires_grad or any(fc.weight.requires_grad for fc in fcs))) else 5
+        # the exact-fp32 backward keeps the hidden activations of 128 edges in LDS: three hidden layers at most when gradients
+        # are needed in fp32 mode; the bf16 backward takes four (its operand fragments then come from L2, gno_bwd3_bf16.hip)
+        need_grad = torch.is_grad_enabled() and (f_y.requires_grad or any(fc.weight.requires_grad for fc in fcs))
+        from ... import ops as _ops
+        max_fcs = 4 if (need_grad and _ops.get_precision() != "bf16") else 5
         if activation_name(getattr(self.channel_mlp, "non_linearity", "gelu")) != "gelu" or not (2 <= len(fcs) <= max_fcs):
             return None
         if self.training and getattr(self.channel_mlp, "dropout_p", 0.0) > 0.0:

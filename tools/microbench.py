@@ -104,13 +104,14 @@ elif what == "gno":
     n, m = 500000, tokens.shape[0]
     tokens = tokens.to(dev)
     for nh, ei, ns, nd, yp, xp in ((3, batch.encoder_edge_index_s0, n, m, batch.pos, tokens),
-                                   (2, batch.decoder_edge_index_s0, m, n, tokens, batch.pos)):
+                                   (2, batch.decoder_edge_index_s0, m, n, tokens, batch.pos),
+                                   (4, batch.encoder_edge_index_s0, n, m, batch.pos, tokens)):
         ws = [torch.randn(64, 6, device=dev) * 0.3] + [torch.randn(64, 64, device=dev) * 0.1 for _ in range(nh - 1)] + [torch.randn(32, 64, device=dev) * 0.1]
         bs = [torch.zeros(w.shape[0], device=dev) for w in ws]
         timeit(lambda: ops.build_graph(ei, ns, nd), f"csr x2 (E={ei.shape[1]})")
         g = ops.build_graph(ei, ns, nd)
         f = torch.randn(ns, 32, device=dev); go = torch.randn(nd, 32, device=dev)
         e = ei.shape[1]
-        fl = e * (21280 if nh == 3 else 13088)
+        fl = e * {2: 13088, 3: 21280, 4: 29472}[nh]
         timeit(lambda: ops.gno_forward(ws, bs, yp, xp, f, g), f"gno_fwd nh={nh}", fl)
         timeit(lambda: ops.gno_backward(ws, bs, yp, xp, f, go, g), f"gno_bwd nh={nh}", 3 * fl)
