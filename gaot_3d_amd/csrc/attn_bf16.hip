@@ -1781,6 +1781,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/r4_h_attn_bwd_prio_stamps.txt)
             // (double-buffered stage tiles filled by the first half of the waves before the stage barrier -- to use their 17 % of
             // barrier idle time -- measured 0.97 / 0.795 ms against 0.89 / 0.786: profiles/r4_i_attn_bwd_double_buffer_lab.txt; removed)
+            // (the mask stream of a register group -- 4 xor, 8 exp, 8 SDWA compares, 16 selects, 8 multiplies -- as ONE asm statement,
+            // which removes the s_nop the compiler puts behind every asm boundary (60 per stage): 0.856 -> 0.969 ms, exp-first order or
+            // not; the nops are not what the stream waits on -- profiles/r4_o_attn_bwd_asm_group_lab.txt; removed)
             // (all S products before the dP products, with and without a pin behind the cluster, and a pin after the dV / dK block:
             // within +-1 % -- profiles/r4_k_attn_bwd_cluster_order_lab.txt)
             else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
