@@ -72,15 +72,22 @@ elif what == "gemm16":
         fl = 2 * m * n * k
         timeit(lambda: ops.gemm(a, w, m, n, k, k, w.shape[1], False, bt), name, fl)
 elif what == "wgrad":
-    # weight gradients of one block at configs[1]: dW = dy^T x over 16384 tokens, both operands bf16 in memory
+    # weight gradients of one block at configs[1]: dW = dy^T x over 16384 tokens, both operands bf16 in memory.  MB_SETS > 1
+    # rotates through that many operand sets (6 x 75 MB do not fit the 256-MB Infinity Cache: operands come from HBM, as in the step)
     rows = 16384
+    nsets = int(os.environ.get("MB_SETS", 1))
     for (m, n, name) in ((2048, 256, "w1|w3"), (256, 1024, "w2"), (768, 256, "q|k|v"), (256, 256, "o_proj"), (256, 512, "skip_proj")):
-        a = (torch.randn(rows, m, device=dev) * 0.5).bfloat16()
-        b = (torch.randn(rows, n, device=dev) * 0.5).bfloat16()
+        sets = [((torch.randn(rows, m, device=dev) * 0.5).bfloat16(), (torch.randn(rows, n, device=dev) * 0.5).bfloat16()) for _ in range(nsets)]
+        a, b = sets[0]
         c = ops.gemm(a, b, m, n, rows, m, n, True, False)
         ref = a.float().t() @ b.float()
         err = (c - ref).abs().max().item() / ref.abs().max().item()
-        timeit(lambda: ops.gemm(a, b, m, n, rows, m, n, True, False), f"dW {name:9s} [{m} x {n}] rel err {err:.1e}", 2 * rows * m * n)
+        it = [0]
+        def run():
+            x, y = sets[it[0] % nsets]
+            it[0] += 1
+            return ops.gemm(x, y, m, n, rows, m, n, True, False)
+        timeit(run, f"dW {name:9s} [{m} x {n}] rel err {err:.1e}", 2 * rows * m * n)
 elif what == "graph":
     # device graph construction at configs[1]: 500 000 surface points against the 64x64x32 token grid
     from gaot_3d_amd import graph
