@@ -180,6 +180,42 @@ def algorithmic_work(n_pts, m_lat, e_enc, e_dec, s_tok, layers, heads=8, dh=32, 
     }
 
 
+def dump_graph_structure(graph, path):
+    """diagnostic (GAOT_BENCH_GRAPH_DOT): node types and the nodes whose in / out degree is not 1, through the HIP graph API"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    g = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    hip.hipGraphGetNodes(g, None, C.byref(n))
+    nodes = (C.c_void_p * n.value)()
+    hip.hipGraphGetNodes(g, nodes, C.byref(n))
+    ne = C.c_size_t(0)
+    hip.hipGraphGetEdges(g, None, None, C.byref(ne))
+    fr, to = (C.c_void_p * ne.value)(), (C.c_void_p * ne.value)()
+    hip.hipGraphGetEdges(g, fr, to, C.byref(ne))
+    idx = {nodes[i]: i for i in range(n.value)}
+    types = []
+    for i in range(n.value):
+        t = C.c_int(-1)
+        hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t))
+        types.append(t.value)
+    indeg, outdeg = [0] * n.value, [0] * n.value
+    edges = []
+    for i in range(ne.value):
+        a, b = idx[fr[i]], idx[to[i]]
+        outdeg[a] += 1; indeg[b] += 1
+        edges.append((a, b))
+    import collections
+    with open(path, "w") as f:
+        f.write(f"nodes {n.value} edges {ne.value} types {dict(collections.Counter(types))}\n")
+        f.write(f"indegree histogram {dict(collections.Counter(indeg))} outdegree histogram {dict(collections.Counter(outdeg))}\n")
+        for i in range(n.value):
+            if indeg[i] != 1 or outdeg[i] != 1 or types[i] != 0:
+                f.write(f"node {i} type {types[i]} in {indeg[i]} out {outdeg[i]}\n")
+        f.write("non-consecutive edges: " + " ".join(f"{a}->{b}" for a, b in edges if b != a + 1) + "\n")
+    graph.instantiate()
+
+
 def step_roofline_ms(n_pts, m_lat, e_enc, e_dec, s_tok, layers, precision, d=256, f=1024, c=32, out=1):
     """t_roof = sum over stages of max(bytes / HBM rate, flops / matrix rate of the arithmetic used).
     Transformer per layer forward 8 S d^2 + 4 S^2 d + 6 S d F (+ 4 S d^2 skip_proj in the decoder half), backward 2x;
@@ -452,11 +488,14 @@ def main(argv=None):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             try:
-                graph = torch.cuda.CUDAGraph()
+                dot = os.environ.get("GAOT_BENCH_GRAPH_DOT")    # diagnostic: node / edge structure of the captured step
+                graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
                 # N>1: ProcessGroupNCCL's watchdog thread polls events of earlier collectives while this thread captures;
                 # under the default "global" capture mode that query is an error that aborts the process
                 with torch.cuda.graph(graph, capture_error_mode="global" if world == 1 else "thread_local"):
                     loss = step()
+                if dot:
+                    dump_graph_structure(graph, dot)
             except Exception as ex:  # capture is a launch optimisation only; fall back to eager launches
                 print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
                 graph = None

@@ -234,6 +234,7 @@ __device__ __forceinline__ void drop_select(f32x16& v, const f32x16& other, uint
 // shift (sign -> 0xFFFF) and one and-not -- 2 VALU ops per element instead of compare + select on fp32.
 // awf = row word ^ 0x80008000 (halfwords as signed), tpk = (thr - 32768) in both halves.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf, const uint32_t* bw_tile, int hf, s16x2 tpk) {
     const uint4 w0 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8);
     const uint4 w1 = *reinterpret_cast<const uint4*>(bw_tile + hf * 8 + 4);
@@ -1203,15 +1204,29 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         const float* lsep = a.lse + ((int64_t)b * a.H + head) * a.S;
         const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
         bf16_t* part = fa.dqpart + (((int64_t)b * a.H + head) * fa.nslab + slab) * (int64_t)a.S * D;
+        // the stage's Q / dO rows through buffer resources of this (batch, head): one 32-bit lane offset per load and a scalar row
+        // offset instead of 64-bit lane addresses (they were spilled: the kernel then needs scratch, and a scratch kernel costs
+        // ~10 us of idle queue on either side of its launch -- profiles/r4_q_gaps.txt); rows past S read as zeros in hardware
+        const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((int64_t)a.S * a.ld * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t do_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dop, 0, (int)((int64_t)a.S * a.H * D * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc((void*)lsep, 0, a.S * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t del_rs = __builtin_amdgcn_make_buffer_rsrc((void*)delp, 0, a.S * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (int)((int64_t)a.S * D * 2), 0x00020000);
+        static_assert(NSTG % 128 == 0, "a wave stages rows of one tile");
+        const int st_tw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+        int st_voff[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = threadIdx.x + it * NSTG, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+            const int row = 32 * (st_t % FB_NT) + st_r;
+            st_voff[it] = (st_t < FB_NT) ? row * (int)a.ld * 2 + 16 * st_c : row * (a.H * D * 2) + 16 * st_c;
+        }
         auto stage_load = [&](uint4 (&rg)[NST], int64_t q0) {
 #pragma unroll
             for (int it = 0; it < NST; ++it) {
-                const int idx = threadIdx.x + it * NSTG, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
-                const int64_t row = q0 + 32 * (st_t % FB_NT) + st_r;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (row < a.S) val = (st_t < FB_NT) ? *reinterpret_cast<const uint4*>(qp + row * a.ld + 8 * st_c)
-                                                : *reinterpret_cast<const uint4*>(dop + row * (int64_t)(a.H * D) + 8 * st_c);
-                rg[it] = val;
+                const int st_t = st_tw + ((it * NSTG) >> 7);          // wave-uniform (a scalar branch)
+                if (st_t < FB_NT) rg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, st_voff[it], (int)q0 * (int)a.ld * 2, 0));
+                else rg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(do_rs, st_voff[it], (int)q0 * (a.H * D * 2), 0));
             }
         };
         auto stage_store = [&](const uint4 (&rg)[NST], char* sb) {
@@ -1226,7 +1241,6 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
             for (int it = 0; it < NRS; ++it) {
                 const int idx = threadIdx.x + it * NTHR;
                 const int rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
-                const int64_t q = q0 + 32 * rt + rq;
                 const char* sp = lds + FB_OFF_SLOT + rt * FB_WAVES * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
                 float4 acc = *reinterpret_cast<const float4*>(sp);
 #pragma unroll
@@ -1234,9 +1248,10 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
-                if (q < a.S)
-                    *reinterpret_cast<uint2*>(part + q * D + 4 * rc) =
-                        make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16));
+                // rows past S fall outside the resource: the store is dropped in hardware
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(u32x2_t, make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16))),
+                    part_rs, (32 * rt + rq) * (D * 2) + 8 * rc, (int)q0 * (D * 2), 0);
             }
         };
         uint4 regs[NST];
@@ -1247,11 +1262,9 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         // dependent L2 round trips per stage, queued behind the stage's own tile loads, while seven waves waited at the barrier)
         float lt = 0.f, et = 0.f;
         auto load_consts = [&](int64_t qbase) {
-            if (threadIdx.x < FB_QS) {
-                int64_t qq = qbase + threadIdx.x;
-                qq = qq < a.S ? qq : (int64_t)a.S - 1;
-                lt = lsep[qq];
-                et = delp[qq];
+            if (threadIdx.x < FB_QS) {     // rows past S: zeros in hardware (staged as -inf / 0 below)
+                lt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse_rs, threadIdx.x * 4, (int)qbase * 4, 0));
+                et = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(del_rs, threadIdx.x * 4, (int)qbase * 4, 0));
             }
         };
         load_consts(q_lo);
@@ -1615,7 +1628,9 @@ static int fused_parts(int B, int S, int HKV) {
 }
 static int fused_chunk(int S, int P) { return (int)(ceil_div(ceil_div(S, P), 64) * 64); }
 static bool fused_bwd_ok(int B, int S, int H, int HKV) {
-    return (int64_t)ceil_div(S, 512) * HKV * B * fused_parts(B, S, HKV) >= 128 && fused_dqpart_bytes(B, S, H) <= ((size_t)1 << 30);
+    // (the kernel addresses one batch entry's rows through 31-bit buffer offsets)
+    return (int64_t)ceil_div(S, 512) * HKV * B * fused_parts(B, S, HKV) >= 128 && fused_dqpart_bytes(B, S, H) <= ((size_t)1 << 30) &&
+           (int64_t)S * (H + 2 * HKV) * D * 2 < 0x7fffffff;
 }
 extern "C" int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV) { return fused_bwd_ok(B, S, H, HKV) ? 1 : 0; }
 static size_t bwd_parts_bytes(int B, int S, int H, int HKV) {   // range parts of the two-pass kernels or of the fused one

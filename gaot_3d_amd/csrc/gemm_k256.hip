@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(cbytes > 0x7fffffff ? 0x7fffffff : cbytes), 0x00020000);
     const int64_t ubytes = MODE == OUT_SWIGLU ? (int64_t)M * im.F * 2 : 0;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(MODE == OUT_SWIGLU ? im.u : C, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == OUT_QKV_IMAGE ? im.table : nullptr), 0,
+                                                                         MODE == OUT_QKV_IMAGE && im.table ? im.S * 128 : 0, 0x00020000);
     auto stage = [&](int t, int buf) {
         const int lh = lane >> 5;
 #pragma unroll
@@ -141,12 +143,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                     const bool rope = im.table && head < im.nq + im.nk;
                     const float sc = head < im.nq ? im.qscale : 1.0f;
                     const int mm = m < M ? m : M - 1;
-                    const float* trow = im.table + (int64_t)(mm % im.S) * 32 + 4 * hf;
+                    // (a buffer resource + one 32-bit offset: the 64-bit row pointer cost the two registers this mode spilled, and a
+                    // kernel that needs scratch pays ~5 us of idle queue on either side of every launch -- profiles/r4_q_gaps.txt)
+                    const int toff = (mm % im.S) * 128 + 16 * hf;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v0 = acc[jt][i][4 * q], v1 = acc[jt][i][4 * q + 1], v2 = acc[jt][i][4 * q + 2], v3 = acc[jt][i][4 * q + 3];
                         if (rope) {
-                            const float4 t = *reinterpret_cast<const float4*>(trow + 8 * q);   // cos, sin, cos, sin
+                            const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(trs, toff + 32 * q, 0, 0));   // cos, sin, cos, sin
                             const float r0 = v0 * t.x - v1 * t.y, r1 = v1 * t.x + v0 * t.y;
                             const float r2 = v2 * t.z - v3 * t.w, r3 = v3 * t.z + v2 * t.w;
                             v0 = r0; v1 = r1; v2 = r2; v3 = r3;
