@@ -6,6 +6,10 @@
 
 namespace {
 
+__global__ void k_zero_flags(int* __restrict__ p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 // *unsorted != 0 when some key is smaller than its predecessor
 template <typename IDX>
 __global__ void k_check_sorted(const IDX* __restrict__ keys, int64_t E, int* __restrict__ unsorted) {
@@ -243,7 +247,9 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     int* table = ibuf1 + E;                 // [tn + 1]
     int* tscan = table + tn + 1;            // [tn + 1]
     int* bsum = tscan + tn + 1;             // [nbt + 1]
-    (void)hipMemsetAsync(flags, 0, sizeof(int) * 4, st);
+    // (a kernel, not hipMemsetAsync: in a replayed hipGraph a memset node costs ~10 us of idle queue on either side of it --
+    // profiles/r4_q_graph_replay_gaps.txt)
+    GAOT_KLAUNCH(k_zero_flags, dim3(1), dim3(64), 0, st, flags, 4);
     if (E == 0) {
         (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);
         return GAOT_OK;
