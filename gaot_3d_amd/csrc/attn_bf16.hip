@@ -1683,6 +1683,10 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // bound-based kernel (128 registers: 4 workgroups per CU), then the adaptive one for the workgroups it flagged
     // (schedule pins inside the forward's tile -- start of tile / after the exp stream / before the P V products -- were
     // measured: +-0.5 %, profiles/r4_g_attn_lab.txt; the template parameter stays at 0)
+    // (a keep-bit image -- the forward also writing one 32-bit word of keep bits per (query, 32-key tile) for the backward to read
+    // through scalar loads -- measured as its two halves, profiles/r4_w_keep_bit_image_lab.txt: WRITING the words (8 and-or steps,
+    // one cross-half combine, one 128-byte store per wave and tile) costs the forward 0.516 -> 0.599 ms; the backward with its masks
+    // for FREE (no xor, no compares, selects kept) gains 0.834 -> 0.810 ms at most.  Not built.)
     // (K / V stages by LDS-DMA into two stage buffers -- no register staging, no ds_write, ONE barrier per 128 keys, 103 instead
     // of 112 registers -- measured 0.538 / 0.431 ms against 0.524 / 0.424 with / without dropout: the staging is not what the
     // forward waits on; profiles/r4_t_attn_fwd_dma_lab.txt; removed)
