@@ -772,15 +772,17 @@ def main(argv=None):
                         traffic=None, avg_ms=round(d["avg_ms"], 4))
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pass.sh); they are reported only
             # when the committed file was measured on exactly these kernel sources, otherwise null
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            # (one file per workload: the GNO kernels' bytes depend on the graph)
+            pmc_name = "pmc_traffic.json" if args.workload == "cfg1" else f"pmc_traffic_{args.workload}.json"
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
             try:
                 pj = json.load(open(pmc))
                 src = pj.get("_source", {})
                 if src.get("csrc_sha16") == csrc_sha16() and world == 1:
                     roof["traffic"] = pj.get(dom, {}).get("bytes_per_launch")
-                    roof["traffic_source"] = f"profiles/pmc_traffic.json (tag {src.get('tag')}, csrc {src.get('csrc_sha16')})"
+                    roof["traffic_source"] = f"profiles/{pmc_name} (tag {src.get('tag')}, csrc {src.get('csrc_sha16')})"
                 else:
-                    roof["traffic_source"] = "profiles/pmc_traffic.json is from other kernel sources or another N: not reported"
+                    roof["traffic_source"] = f"profiles/{pmc_name} is from other kernel sources or another N: not reported"
             except Exception:
                 pass
         troof = step_roofline_ms(n_total // world, m_lat, e_enc, e_dec, s_tok, args.layers, args.precision, out=wl_out)
