@@ -29,6 +29,41 @@ def test_library_exports_every_declared_symbol():
     assert lib.gaot_abi_version() == 8
 
 
+
+def test_hot_path_kernels_need_no_scratch(tmp_path):
+    """No kernel of the shipped path may need scratch memory (spilled registers / private arrays): the code objects' metadata is
+    read from the built library.  Known exceptions are variants off the default path (lab / fallback instantiations)."""
+    import re, shutil, subprocess
+    from gaot_3d_amd import _lib
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not installed")
+    _lib.load()
+    so = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "lib", "libgaot3d_hip.so")
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(so, work / "lib.so")
+    subprocess.run([objdump, "--offloading", str(work / "lib.so")], check=True, capture_output=True, cwd=work)
+    objs = sorted(f for f in os.listdir(work) if "gfx950" in f)
+    assert objs, "no gfx950 code object found in the library"
+    allowed = ("k_attn_bwd_fusedILb1ELi4ELi4E",          # one-wave-per-SIMD lab variant (GAOT_ATTN_BWD_VARIANT=1)
+               "k_attn_bwd_dkv_bf16ILi4E", "k_attn_bwd_dq_bf16ILi4E",   # two-pass fallback, four workgroups per CU
+               "k_gno_bwdILi3ELi64E",                      # fp32-mode GNO backward, three hidden layers
+               "k_gno_bwd3_bf16ILi4E")                      # four hidden layers: fragments from L2, 85 spilled registers
+    seen, offenders = 0, []
+    for f in objs:
+        notes = subprocess.run([readelf, "--notes", str(work / f)], check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.private_segment_fixed_size:\s+(\d+)", notes, re.S):
+            name, between, scratch = m.group(1), m.group(2), int(m.group(3))
+            if ".name:" in between:      # the size belongs to another entry
+                continue
+            seen += 1
+            if scratch and not any(a in name for a in allowed):
+                offenders.append((name, scratch))
+    assert seen > 100, seen
+    assert not offenders, offenders
+
+
 @pytest.mark.parametrize("case", ["model_knn_abs", "model_radius_rope", "model_channel_multiscale"])
 def test_state_dict_layout_matches_reference(case):
     from test_model_gpu import product_config
