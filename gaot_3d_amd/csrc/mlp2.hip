@@ -9,7 +9,10 @@
 // tiles (tile32.h).  Two accumulator orientations are used, each the B operand of what follows it:
 //   P: z[j][n] (hidden on registers, row on lanes)  -> out[c][n] and d_x^T[k][n]  (contract over hidden)
 //   Q: z^T[n][j] (row on registers, hidden on lanes) -> d_W1^T[k][j], d_W2, d_b1    (contract over rows)
-// The backward evaluates both (the K = 32 product is cheap); GELU / GELU' share one exp (gelu_e2_pair, common.h).
+// The backward computes dz ONCE, in the Q orientation (GELU / GELU' share one exp: gelu_e2_pair, common.h), and hands its bf16
+// rounding to the d_x product through a wave-private [hidden][row] LDS tile read back transposed (ds_read_b64_tr_b16) -- the
+// round-3 kernel recomputed z and GELU' in the P orientation (2 MFMAs, 8 more exponentials and 16 OC fused multiply-adds per
+// 32 x 32 block); the K = 32 product was cheap, the second activation pass was not.
 #include "common.h"
 #include "tile32.h"
 
@@ -137,12 +140,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
     char* xt = smem;                                                        // 4 x-tiles
     char* w1t = xt + 4 * TILE_BYTES;                                        // W1 as bf16 tiles [ob][32 hidden][32 feature]
     float* b1s = reinterpret_cast<float*>(w1t + NOB * TILE_BYTES);          // [H]
-    float* w2s = b1s + H;                                                   // [OC][H]
-    float* dos = w2s + OC * H;                                              // d_out tile [row][c]
+    float* dos = b1s + H;                                                   // d_out tile [row][c]
     float (*dxp)[32][MLP_ROWS + 1] = reinterpret_cast<float (*)[32][MLP_ROWS + 1]>(dos + MLP_ROWS * OC);  // per-wave d_x^T partials
+    char* dzt_all = reinterpret_cast<char*>(dxp + 4);                       // per wave: dz tile [32 hidden][32 rows] bf16
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     for (int i = threadIdx.x; i < H; i += 256) b1s[i] = a.b1[i];
-    for (int i = threadIdx.x; i < OC * H; i += 256) w2s[i] = a.w2[i];
+    char* dzt = dzt_all + wave * TILE_BYTES;
     for (int ch = threadIdx.x; ch < H * 4; ch += 256) {   // W1 -> LDS tiles, 8 elements per chunk
         const int j = ch >> 2, c = ch & 3;
         const float* p = a.w1 + (int64_t)j * MLP_IN + 8 * c;
@@ -191,15 +194,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
             f32x16 dxt;   // d_x^T [feature][row] of this 32-row sub-tile, over this wave's hidden units
 #pragma unroll
             for (int r = 0; r < 16; ++r) dxt[r] = 0.f;
-            float dol[OC];   // d_out of the row on this lane (P orientation)
+            // d_out of the 16 rows of this lane's accumulator registers (rows 32 t + mfma32_row(r, hf)): read once per sub-tile,
+            // shared by the wave's hidden blocks (the round-3 kernel re-read them from LDS inside every block)
+            float dor[16][OC];
 #pragma unroll
-            for (int c = 0; c < OC; ++c) dol[c] = dos[(32 * t + l31) * OC + c];
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < OC; ++c) dor[r][c] = dos[(32 * t + mfma32_row(r, hf)) * OC + c];
 #pragma unroll
             for (int o = 0; o < OBW; ++o) {
                 const int ob = wave * OBW + o;
                 if (ob >= NOB) continue;
                 const bf16x8 xr0 = frag_rows(xtile, l31, hf, 0), xr1 = frag_rows(xtile, l31, hf, 1);
-                // ---- Q: z^T[n][j] -> d_W1^T, d_W2, d_b1 --------------------------------------------------------
+                // ---- z^T[n][j] (row on registers, hidden on lanes) -> dz -> d_W1^T, d_W2, d_b1 -------------------------
                 f32x16 zq;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zq[r] = b1l[o];
@@ -213,13 +220,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int r = r2 + u;
-                        const int n = 32 * t + mfma32_row(r, hf);
                         float dy = 0.f;
 #pragma unroll
                         for (int c = 0; c < OC; ++c) {
-                            const float d = dos[n * OC + c];
-                            dy = fmaf(d, w2l[o][c], dy);
-                            dw2[o][c] = fmaf(d, y2[u], dw2[o][c]);
+                            dy = fmaf(dor[r][c], w2l[o][c], dy);
+                            dw2[o][c] = fmaf(dor[r][c], y2[u], dw2[o][c]);
                         }
                         const float dz = dy * gd2[u];
                         s1 += dz;
@@ -227,38 +232,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp2_bwd(Mlp2Args a, const float* __
                     }
                 }
                 db1[o] += s1;
+                bf16x8 f0, f1;
+                acc_to_frags(zq, f0, f1);
+                dw1t[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(xtile, lane, 0), f0, dw1t[o], 0, 0, 0);
+                dw1t[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(xtile, lane, 1), f1, dw1t[o], 0, 0, 0);
+                // ---- d_x^T[k][n] += sum_j W1[j][k] dz[n][j]: the same bf16 dz, as the tile [hidden = l31][row] (the lane's four runs
+                //      of four consecutive rows = 8-byte stores), read back transposed: lane = row, elements = hidden in the
+                //      accumulator-as-operand order.  LDS operations of one wave complete in order.
                 {
-                    bf16x8 f0, f1;
-                    acc_to_frags(zq, f0, f1);
-                    dw1t[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(xtile, lane, 0), f0, dw1t[o], 0, 0, 0);
-                    dw1t[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(xtile, lane, 1), f1, dw1t[o], 0, 0, 0);
-                }
-                // ---- P: z[j][n] -> d_x^T ---------------------------------------------------------------------------
-                f32x16 zp;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 bv = *reinterpret_cast<const float4*>(&b1s[32 * ob + 8 * g4 + 4 * hf]);
-                    zp[4 * g4] = bv.x; zp[4 * g4 + 1] = bv.y; zp[4 * g4 + 2] = bv.z; zp[4 * g4 + 3] = bv.w;
-                }
-                zp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][0], xr0, zp, 0, 0, 0);
-                zp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[o][1], xr1, zp, 0, 0, 0);
-#pragma unroll
-                for (int r2 = 0; r2 < 16; r2 += 2) {
-                    const f32v2 gd2 = gelu_e2_grad2(f32v2{zp[r2], zp[r2 + 1]});
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int j = 32 * ob + mfma32_row(r2 + u, hf);
-                        float dy = 0.f;
-#pragma unroll
-                        for (int c = 0; c < OC; ++c) dy = fmaf(dol[c], w2s[c * H + j], dy);
-                        zp[r2 + u] = dy * gd2[u];
-                    }
-                }
-                {
-                    bf16x8 f0, f1;
-                    acc_to_frags(zp, f0, f1);
-                    dxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(w1t + ob * TILE_BYTES, lane, 0), f0, dxt, 0, 0, 0);
-                    dxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(w1t + ob * TILE_BYTES, lane, 1), f1, dxt, 0, 0, 0);
+                    const uint4 lo = __builtin_bit_cast(uint4, f0), hi = __builtin_bit_cast(uint4, f1);
+                    *reinterpret_cast<uint2*>(dzt + tile_off(l31, 0) + 8 * hf) = make_uint2(lo.x, lo.y);
+                    *reinterpret_cast<uint2*>(dzt + tile_off(l31, 1) + 8 * hf) = make_uint2(lo.z, lo.w);
+                    *reinterpret_cast<uint2*>(dzt + tile_off(l31, 2) + 8 * hf) = make_uint2(hi.x, hi.y);
+                    *reinterpret_cast<uint2*>(dzt + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
+                    dxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(w1t + ob * TILE_BYTES, lane, 0), frag_cols(dzt, lane, 0), dxt, 0, 0, 0);
+                    dxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(w1t + ob * TILE_BYTES, lane, 1), frag_cols(dzt, lane, 1), dxt, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -319,8 +307,8 @@ __global__ __launch_bounds__(256) void k_mlp2_reduce(const float* __restrict__ p
 }
 
 constexpr size_t bwd_lds_bytes(int nob, int oc) {
-    return (size_t)4 * TILE_BYTES + (size_t)nob * TILE_BYTES + sizeof(float) * (32 * nob + oc * 32 * nob + MLP_ROWS * oc) +
-           sizeof(float) * 4 * 32 * (MLP_ROWS + 1);
+    return (size_t)4 * TILE_BYTES + (size_t)nob * TILE_BYTES + sizeof(float) * (32 * nob + MLP_ROWS * oc) +
+           sizeof(float) * 4 * 32 * (MLP_ROWS + 1) + (size_t)4 * TILE_BYTES;
 }
 
 constexpr int MLP_BWD_GRID = 256;
