@@ -278,12 +278,17 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full):
             one_step()
             times.append(time.perf_counter() - t0)
         how = f"best of {len(times)} after 1 warm-up"
-    else:           # ONE step, timed from cold (thread-pool start-up is noise against ~100 s)
+    else:           # one warm-up step, then up to three timed ones while a 75 s budget lasts (at least one): the median
         t0 = time.perf_counter()
         one_step()
-        times.append(time.perf_counter() - t0)
-        how = "one step, no warm-up"
-    t = sorted(times)[0]
+        t_warm = time.perf_counter() - t0
+        t_begin = time.perf_counter()
+        while len(times) < 3 and (not times or time.perf_counter() - t_begin + t_warm < 75.0):
+            t0 = time.perf_counter()
+            one_step()
+            times.append(time.perf_counter() - t0)
+        how = f"median of {len(times)} after 1 warm-up"
+    t = sorted(times)[0] if mode == "sample" else sorted(times)[len(times) // 2]
     frac = "the same sample as the GPU step" if mode == "full" else "1/8 of the points and 1/8 of the latent grid: a REDUCED sample"
     return dict(value=n / t, unit="points/s", cores=cores, kind="port", reduced_sample=(mode != "full"), seconds_per_step=round(t, 2),
                 sample=f"oracle fwd+MSE+bwd on N={n} points, latent {latent[0]}x{latent[1]}x{latent[2]} ({frac}), k={k}, "
@@ -294,17 +299,17 @@ def cpu_baseline_auto(budget_s, layers, k, seed, atten_dropout, points, latent_f
     """the bounded sample first; then, when the host can take it, ONE step on the metric's own 500K-point sample as the
     reported value (same input), the bounded figure kept beside it"""
     red = cpu_baseline("sample", layers, k, seed, atten_dropout, points, latent_full)
-    # measured on 64 host threads in round 2: 5.5 s (bounded) vs 108 s (full): x20 (attention is quadratic in the tokens)
-    expect = 22.0 * red["seconds_per_step"]
+    # the bounded sample carries dropout masks (explicit attention weights), the full step runs without dropout through the
+    # reference's own F.scaled_dot_product_attention (no [S, S] weights in memory): measured x5-x8 of the bounded step on 64 threads
+    expect = 3.0 * 8.0 * red["seconds_per_step"]        # warm-up + up to two more steps
     try:
         import psutil
         free_gb = psutil.virtual_memory().available / 2 ** 30
     except Exception:
         free_gb = 0.0
-    if free_gb < 110.0 or expect > budget_s:
-        red["full_sample_skipped"] = (f"full 500K-point CPU step not run: {free_gb:.0f} GB free host memory (needs ~110), expected "
-                                      f"{expect:.0f} s against a budget of {budget_s:.0f} s; recorded on 64 threads in "
-                                      f"profiles/r2_h_bench_cpu_baseline_full_sample.json (108 s/step, 4.6 K points/s)")
+    if free_gb < 48.0 or expect > budget_s:
+        red["full_sample_skipped"] = (f"full 500K-point CPU step not run: {free_gb:.0f} GB free host memory (needs ~48), expected "
+                                      f"{expect:.0f} s against a budget of {budget_s:.0f} s")
         return red
     # in a child process: if the kernel kills it for memory, the bench line survives with the bounded figure
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--layers", str(layers), "--knn", str(k), "--seed", str(seed),

@@ -437,9 +437,13 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, keep: Optional[Tensor] = None, p_drop:
     """F.scaled_dot_product_attention(q, k, v, dropout_p) as the reference calls it (attn.py:122-127): non-causal, no mask,
     scale 1/sqrt(head_dim); ``keep`` = the Bernoulli mask of the training path (torch.dropout on the attention weights:
     mask and rescale by 1/(1-p)).  q, k, v: [B, H, S, d] (any float dtype: the full-size checks call it in fp64)."""
-    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1]), dim=-1)  # SDPA :126
-    if keep is not None:
-        att = att * keep.to(att.dtype) / (1.0 - p_drop)
+    if keep is None:
+        # the reference's own call (attn.py:126).  On the CPU this is torch's tiled kernel: no [S, S] weights in memory (8.6 GB per
+        # layer at S = 16 384, kept for the backward) and ~20x faster than the explicit form below, which it equals to fp32
+        # rounding (1e-7 on the output, 1e-6 on the gradients at S = 4 096)
+        return F.scaled_dot_product_attention(q, k, v)
+    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1]), dim=-1)  # the same, written out: the mask acts on the weights
+    att = att * keep.to(att.dtype) / (1.0 - p_drop)
     return att @ v
 
 
