@@ -54,8 +54,8 @@ SIGNATURES = {
     "gaot_gemm": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i, _p, _i64, _p, _i, _p, _sz, _p]),
     "gaot_gemm_ex": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _i, _p, _i64, _p, _i, _p,
                           _sz, _p]),
-    "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
-    "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _p]),
+    "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _p]),
+    "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _i, _p]),
     "gaot_attn_dropout_mask": (_i, [_p, _f, _i, _i, _i, _p, _p]),
     "gaot_dropout_seed_next": (_i, [_p, C.c_uint64, _p, _p]),
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
@@ -65,8 +65,8 @@ SIGNATURES = {
     "gaot_pack_heads": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p, _i, _i, _i, _p]),
     "gaot_attn_bwd_bf16_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_attn_bwd_bf16_fused_eligible": (_i, [_i, _i, _i, _i]),
-    "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
-    "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p]),
+    "gaot_attn_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _p]),
+    "gaot_attn_bwd_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _p]),
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
@@ -103,6 +103,7 @@ SIGNATURES = {
     "gaot_act_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
     "gaot_stream_copy": (_i, [_p, _p, _i64, _p]),
+    "gaot_stream_copy_ex": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_patchify": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gaot_mse_workspace_bytes": (_sz, []),
     "gaot_mse_fwd": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
@@ -134,7 +135,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 8:
+    if lib.gaot_abi_version() != 9:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_f32(AttnArgs a) {
     uint32_t aw = 0, ck = 0;
     if constexpr (DROP) {
         const unsigned long long seed = *a.drop.seed;
-        const int bh = b * a.H + head;
+        const int bh = a.drop.bh(b, head);
         aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31));
         ck = gdrop::col_key(seed, bh);
     }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_f32(AttnBwdArgs a) {
         }
         uint32_t rk = 0, bsel = 0;
         if constexpr (DROP) {
-            const int bh = b * a.H + head;
+            const int bh = a.drop.bh(b, head);
             rk = gdrop::row_key(seed, bh);
             const uint32_t bw = gdrop::col_word(gdrop::col_key(seed, bh), (uint32_t)(ki >> 1));
             bsel = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_f32(AttnBwdArgs a) {
     uint32_t aw = 0, ck = 0;
     if constexpr (DROP) {
         const unsigned long long seed = *a.drop.seed;
-        const int bh = b * a.H + head;
+        const int bh = a.drop.bh(b, head);
         aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
         ck = gdrop::col_key(seed, bh);
     }
@@ -426,8 +426,8 @@ bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) &&
 
 extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq,
                              int64_t ldk, int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim,
-                             float scale, float dropout_p, const unsigned long long* dropout_seed, int precision,
-                             gaot_stream_t stream) {
+                             float scale, float dropout_p, const unsigned long long* dropout_seed, int head0, int heads_total,
+                             int precision, gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_fwd: head_dim %d unsupported (only 32)", head_dim);
@@ -438,7 +438,8 @@ extern "C" int gaot_attn_fwd(const float* q, const float* k, const float* v, flo
     GAOT_CHECK_ARG(aligned16(q, ldq) && aligned16(k, ldk) && aligned16(v, ldv) && aligned16(o, ldo),
                    "q/k/v/o must be 16-byte aligned with row strides that are multiples of 4 floats");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
-    AttnArgs a{q, k, v, o, lse, ldq, ldk, ldv, ldo, B, S, H, HKV, scale, gdrop::make_drop(dropout_seed, dropout_p)};
+    GAOT_CHECK_ARG(heads_total == 0 || (head0 >= 0 && head0 + H <= heads_total), "head0 + H <= heads_total");
+    AttnArgs a{q, k, v, o, lse, ldq, ldk, ldv, ldo, B, S, H, HKV, scale, gdrop::make_drop(dropout_seed, dropout_p, H, head0, heads_total)};
     dim3 grid((unsigned)ceil_div(S, 128), (unsigned)H, (unsigned)B);
     if (a.drop.thr) GAOT_KLAUNCH(k_attn_fwd_f32<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else GAOT_KLAUNCH(k_attn_fwd_f32<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -450,8 +451,8 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
                              const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk,
                              int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B,
                              int S, int H, int HKV, int head_dim, float scale, float dropout_p,
-                             const unsigned long long* dropout_seed, int precision, int phase_mask,
-                             gaot_stream_t stream) {
+                             const unsigned long long* dropout_seed, int head0, int heads_total, int precision,
+                             int phase_mask, gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_bwd: head_dim %d unsupported (only 32)", head_dim);
@@ -464,7 +465,8 @@ extern "C" int gaot_attn_bwd(const float* q, const float* k, const float* v, con
                    "tensors must be 16-byte aligned with row strides that are multiples of 4 floats");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
     AttnBwdArgs a{q, k, v, o, d_o, lse, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, S, H, HKV, scale,
-                  gdrop::make_drop(dropout_seed, dropout_p)};
+                  gdrop::make_drop(dropout_seed, dropout_p, H, head0, heads_total)};
+    GAOT_CHECK_ARG(heads_total == 0 || (head0 >= 0 && head0 + H <= heads_total), "head0 + H <= heads_total");
     const bool drop = a.drop.thr != 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)B * S * H;
@@ -499,7 +501,7 @@ extern "C" int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, fl
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p in [0,1)");
     const int64_t n = (int64_t)B * H * S * S;
     GAOT_KLAUNCH(k_dropout_mask, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       gdrop::make_drop(dropout_seed, dropout_p), H, S, n, keep);
+                       gdrop::make_drop(dropout_seed, dropout_p, H), H, S, n, keep);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

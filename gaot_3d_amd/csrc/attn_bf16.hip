@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
     uint32_t aw = 0, ck = 0;
     if constexpr (DROP) {
         const unsigned long long seed = *a.drop.seed;
-        const int bh = b * a.H + head;
+        const int bh = a.drop.bh(b, head);
         aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31)) ^ 0x80008000u;
         ck = gdrop::col_key(seed, bh);
     }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_bf16(BwdArgs a) {
         load_consts(lo);
         uint32_t rk = 0, bsel = 0;
         if constexpr (DROP) {
-            const int bh = b * a.H + head;
+            const int bh = a.drop.bh(b, head);
             rk = gdrop::row_key(seed, bh);
             const uint32_t bw = gdrop::col_word(gdrop::col_key(seed, bh), (uint32_t)(ki >> 1));
             bsel = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dkv_kb(BwdArgs a) {
         load_consts(0);
         uint32_t rk = 0, bsel[KB];
         if constexpr (DROP) {
-            const int bh = b * a.H + head;
+            const int bh = a.drop.bh(b, head);
             rk = gdrop::row_key(seed, bh);
             const uint32_t ck = gdrop::col_key(seed, bh);
 #pragma unroll
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_bf16(BwdArgs a) {
     uint32_t aw = 0, ck = 0;
     if constexpr (DROP) {
         const unsigned long long seed = *a.drop.seed;
-        const int bh = b * a.H + head;
+        const int bh = a.drop.bh(b, head);
         aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
         ck = gdrop::col_key(seed, bh);
     }
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_bwd_dq_kb(BwdArgs a) {
         for (int r = 0; r < 16; ++r) { dqt[qb][r] = 0.f; negl[qb][r] = -lse2; negd[qb][r] = -del; }
         aw[qb] = 0;
         if constexpr (DROP) {
-            const int bh = b * a.H + head;
+            const int bh = a.drop.bh(b, head);
             aw[qb] = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)qi);
             ck = gdrop::col_key(seed, bh);
         }
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         load_consts(q_lo);
         uint32_t rk = 0, bsel[FB_KB];
         if constexpr (DROP) {
-            const int bh = b * a.H + head;
+            const int bh = a.drop.bh(b, head);
             rk = gdrop::row_key(seed, bh);
             const uint32_t ck = gdrop::col_key(seed, bh);
 #pragma unroll
@@ -1645,7 +1645,7 @@ extern "C" size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV)
 
 extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse,
                                   int B, int S, int H, int HKV, int head_dim, float scale, float dropout_p,
-                                  const unsigned long long* dropout_seed, gaot_stream_t stream) {
+                                  const unsigned long long* dropout_seed, int head0, int heads_total, gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_fwd_bf16: head_dim %d unsupported (only 32)", head_dim);
@@ -1655,6 +1655,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     GAOT_CHECK_ARG(qkv_image && o && lse, "null pointer");   // qkv == NULL: the image is already there (gaot_qkv_image)
     GAOT_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_image | (uintptr_t)o) & 15) == 0, "buffers must be 16-byte aligned");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
+    GAOT_CHECK_ARG(heads_total == 0 || (head0 >= 0 && head0 + H <= heads_total), "head0 + H <= heads_total");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
     const int64_t rows = (int64_t)B * S;
@@ -1674,7 +1675,7 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     const int64_t o_part = rows * H * D, lse_part = (int64_t)B * H * S;
     float* lse_parts = o_parts + (size_t)P * o_part;
     FwdArgs a{(const bf16_t*)qkv_image, P > 1 ? o_parts : o, P > 1 ? lse_parts : lse, ld, B, S, H, HKV,
-              gdrop::make_drop(dropout_seed, dropout_p), P > 1 ? split_chunk(S, P) : S, o_part, lse_part, kmax2, redo};
+              gdrop::make_drop(dropout_seed, dropout_p, H, head0, heads_total), P > 1 ? split_chunk(S, P) : S, o_part, lse_part, kmax2, redo};
     const dim3 fgrid((unsigned)(ceil_div(S, 128) * H), (unsigned)(P > 1 ? ceil_div(S, a.chunk) : 1), (unsigned)B);
     // (two query blocks per wave, the layout that pays for dK/dV and dQ, gains only 3 % here: the forward is bound by
     // its exp / sum / mask VALU work and loses more from the halved occupancy; a rolled 5-waves/SIMD variant was slower too)
@@ -1707,7 +1708,8 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
 extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse,
                                   void* do_image, float* delta, float* dqkv, const float* rope_freqs, int B, int S, int H,
                                   int HKV, int head_dim, float scale, float dropout_p,
-                                  const unsigned long long* dropout_seed, int phase_mask, gaot_stream_t stream) {
+                                  const unsigned long long* dropout_seed, int head0, int heads_total, int phase_mask,
+                                  gaot_stream_t stream) {
     GAOT_ENTER();
     if (head_dim != D) {
         gaot_set_error("gaot_attn_bwd_bf16: head_dim %d unsupported (only 32)", head_dim);
@@ -1716,6 +1718,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     GAOT_CHECK_ARG(B > 0 && S > 0 && H > 0 && HKV > 0 && H % HKV == 0, "bad shape");
     GAOT_CHECK_ARG(qkv_image && o && (d_o || !(phase_mask & 1)) && lse && do_image && delta && dqkv, "null pointer");
     GAOT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (dropout_p == 0.f || dropout_seed), "dropout_p in [0,1) and a seed");
+    GAOT_CHECK_ARG(heads_total == 0 || (head0 >= 0 && head0 + H <= heads_total), "head0 + H <= heads_total");
     hipStream_t st = (hipStream_t)stream;
     const int ld = (H + 2 * HKV) * D;
     // range split for small grids (see gaot_attn_fwd_bf16): part p of dK/dV covers queries, of dQ keys
@@ -1728,7 +1731,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
     const int64_t dqkv_part = (int64_t)B * S * ld;
     float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(do_image) + align256(sizeof(bf16_t) * (size_t)B * S * H * D + 64));
     BwdArgs a{(const bf16_t*)qkv_image, (const bf16_t*)do_image, lse, delta, P > 1 ? parts : dqkv, ld, B, S, H, HKV, scale,
-              gdrop::make_drop(dropout_seed, dropout_p), rope_freqs, chunk, dqkv_part};
+              gdrop::make_drop(dropout_seed, dropout_p, H, head0, heads_total), rope_freqs, chunk, dqkv_part};
     const bool drop = a.drop.thr != 0;
     const int64_t n = (int64_t)B * S * H;
     if (phase_mask & 8)        // do_image already holds the bf16 dO (sequence-parallel exchange): delta only

@@ -21,9 +21,13 @@ struct Drop {
     unsigned thr;                     // keep iff 16-bit uniform >= thr
     float inv_keep;                   // 1 / (1 - thr/65536)
     float keep;                       // 1 - thr/65536
+    int head0, heads_total;           // the launch's head 0 is head `head0` of `heads_total` (a rank of a head- / sequence-parallel
+                                      // step owns a slice of the heads): the mask is keyed by the GLOBAL head, so a head draws the
+                                      // same mask wherever it runs and a sharded step equals the unsharded one with dropout on
+    __host__ __device__ __forceinline__ int bh(int b, int head) const { return b * heads_total + head0 + head; }
 };
 
-inline Drop make_drop(const unsigned long long* seed, float p) {
+inline Drop make_drop(const unsigned long long* seed, float p, int H, int head0 = 0, int heads_total = 0) {
     long t = (long)(p * 65536.0 + 0.5);
     if (t < 0) t = 0;
     if (t > 65535) t = 65535;
@@ -32,6 +36,8 @@ inline Drop make_drop(const unsigned long long* seed, float p) {
     d.thr = (unsigned)t;
     d.keep = 1.0f - (float)t / 65536.0f;
     d.inv_keep = 1.0f / d.keep;
+    d.head0 = heads_total > 0 ? head0 : 0;
+    d.heads_total = heads_total > 0 ? heads_total : H;
     return d;
 }
 

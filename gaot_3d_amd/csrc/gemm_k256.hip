@@ -472,7 +472,8 @@ bool gaot_gemm_tn_n256_applicable(const void* A, const void* W, const void* C, c
                                   int64_t ldw, int64_t ldc, int64_t ldr) {
     return N == 256 && K >= 512 && K % 64 == 0 && M >= 1 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!R || ldr % 4 == 0) &&
            ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)R % 16) == 0 &&
-           M * lda * 2 < 0x7fffffff && 256 * ldw * 2 < 0x7fffffff && M * ldc * 4 < 0x7fffffff && lda >= K && ldw >= K;
+           M * lda * 2 < 0x7fffffff && 256 * ldw * 2 < 0x7fffffff && M * ldc * 4 < 0x7fffffff && (!R || M * ldr * 4 < 0x7fffffff) &&
+           lda >= K && ldw >= K;   // every operand is addressed through a buffer resource with 32-bit byte offsets
 }
 
 int gaot_gemm_tn_n256_launch(const void* A, const void* W, float* C, const float* R, int64_t M, int64_t K, int64_t lda, int64_t ldw,

@@ -783,29 +783,76 @@ extern "C" int gaot_axpy(const float* a, const float* b, float alpha, float* out
     return GAOT_OK;
 }
 
-// float4 streaming copy: the measured HBM ceiling the bench line quotes next to the 8 TB/s spec figure
-__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
-    // four independent 16-byte loads in flight per thread and trip
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+// float4 streaming copy: the measured HBM ceiling the bench line quotes next to the 8 TB/s spec figure.
+// VARIANT 0: grid-stride, four plain 16-byte loads in flight per thread (round 4: 4.5-4.9 TB/s).  The others move a CONTIGUOUS chunk per
+// workgroup with UNR loads in flight per thread: 1 = non-temporal loads and stores, 2 = plain loads + non-temporal stores, 3 = plain both
+// (the copy is read-once / write-once: non-temporal accesses keep it out of the way of the L2 / Infinity-Cache replacement)
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+template <int VARIANT, int UNR>
+__global__ __launch_bounds__(256) void k_stream_copy(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, int64_t n4, int64_t chunk4) {
+    if constexpr (VARIANT == 0) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const copy_f4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
+        for (; i < n4; i += stride) dst[i] = src[i];
+    } else {
+        const int64_t lo = (int64_t)blockIdx.x * chunk4, hi = lo + chunk4 < n4 ? lo + chunk4 : n4;
+        int64_t i = lo + threadIdx.x;
+        for (; i + (UNR - 1) * 256 < hi; i += UNR * 256) {
+            copy_f4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if constexpr (VARIANT == 1) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+                else v[u] = src[i + u * 256];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if constexpr (VARIANT == 3) dst[i + u * 256] = v[u];
+                else __builtin_nontemporal_store(v[u], dst + i + u * 256);
+            }
+        }
+        for (; i < hi; i += 256) dst[i] = src[i];
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
-extern "C" int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream) {
+static int stream_copy_variant = 1;    // the fastest measured on MI355X (profiles/r5_*_stream_copy_lab.txt)
+
+extern "C" int gaot_stream_copy_ex(const void* src, void* dst, int64_t bytes, int variant, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(bytes >= 0 && bytes % 16 == 0, "bytes must be a multiple of 16");
+    GAOT_CHECK_ARG(variant >= 0 && variant <= 6, "variant 0..6");
     if (bytes == 0) return GAOT_OK;
     GAOT_CHECK_ARG(src && dst && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte aligned device pointers");
     const int64_t n4 = bytes / 16;
-    const int64_t blocks = (n4 + 255) / 256;
-    GAOT_KLAUNCH(k_stream_copy, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
-                 (const float4*)src, (float4*)dst, n4);
+    const copy_f4* s4 = (const copy_f4*)src;
+    copy_f4* d4 = (copy_f4*)dst;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) {
+        const int64_t blocks = (n4 + 255) / 256;
+        GAOT_KLAUNCH((k_stream_copy<0, 4>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, s4, d4, n4, (int64_t)0);
+    } else {
+        // chunks of 64 KiB (4096 float4 = 16 per thread); variants 4-6: 256 KiB chunks with non-temporal / mixed / plain accesses
+        const int64_t chunk4 = variant <= 3 ? 4096 : 16384;
+        const int64_t blocks = (n4 + chunk4 - 1) / chunk4;
+        GAOT_CHECK_ARG(blocks < (int64_t)1 << 31, "copy too large for one launch");
+        switch (variant) {
+        case 1: GAOT_KLAUNCH((k_stream_copy<1, 8>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        case 2: GAOT_KLAUNCH((k_stream_copy<2, 8>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        case 3: GAOT_KLAUNCH((k_stream_copy<3, 8>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        case 4: GAOT_KLAUNCH((k_stream_copy<1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        case 5: GAOT_KLAUNCH((k_stream_copy<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        default: GAOT_KLAUNCH((k_stream_copy<3, 4>), dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, chunk4); break;
+        }
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
+}
+
+extern "C" int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream) {
+    return gaot_stream_copy_ex(src, dst, bytes, stream_copy_variant, stream);
 }
 
 extern "C" int gaot_patchify(const float* src, float* dst, int B, int Dd, int Hh, int Ww, int P, int C, int to_tokens,

@@ -277,7 +277,7 @@ class AttentionFn(Function):
 
     @staticmethod
     def forward(ctx, qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, dropout_p: float = 0.0,
-                head_group=None, seed_rank: int = 0):
+                head_group=None, head0: int = 0, heads_total: int = 0):
         """``head_group`` (extension, gaot_3d_amd/sharding.py): a process group whose ranks hold the SAME qkv (replicated
         Transformer of a point-sharded sample); rank r computes heads [r*h/G, (r+1)*h/G) only and the outputs are
         all-gathered, so the attention work -- 60 % of a 500 K-point step -- is divided by G instead of repeated G times."""
@@ -297,19 +297,22 @@ class AttentionFn(Function):
                 ctx.hp = (head_group, gsz, grk, h, hkv)
                 qkv = local_qkv(qkv, grk, gsz, h, hkv)
                 h, hkv = h // gsz, hkv // gsz
+        # ONE seed word for all ranks (same torch.manual_seed -> same device seed stream); the kernels key a head's mask by its
+        # GLOBAL index (head0 + local head of heads_total), so a head draws the same mask on whichever rank it runs and a
+        # sharded step reproduces the unsharded one with dropout on (head0 / heads_total: a sequence-parallel caller's slice)
         seed = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
-        if seed is not None and (ctx.hp is not None or seed_rank):
-            # the kernels key a head's mask by its LOCAL index: give every rank its own seed word so that the heads
-            # of different ranks do not share masks (seed_rank: the rank of a sequence-parallel caller)
-            seed = seed + (ctx.hp[2] if ctx.hp is not None else seed_rank) * 0x632BE59BD9B4E019 % (1 << 63)
+        if ctx.hp is not None:
+            head0, heads_total = ctx.hp[2] * h, ctx.hp[3]
+        ctx.heads = (int(head0), int(heads_total))
         if bf16:
-            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed, image=pre_img)
+            o, lse, img = ops.attn_fwd_bf16(qkv, freqs, b, s, h, hkv, scale, dropout_p, seed, image=pre_img, head0=head0,
+                                            heads_total=heads_total)
             keep = img
         else:
             if freqs is not None:
                 qkv = qkv.clone()
                 ops.rope_(qkv, b * s, qkv.shape[1], 0, h + hkv, s, freqs, False)  # q then k heads: adjacent columns
-            o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale, dropout_p, seed)
+            o, lse = ops.attn_fwd(qkv, b, s, h, hkv, scale, dropout_p, seed, head0, heads_total)
             keep = qkv
         empty = torch.empty(0, device=qkv.device)
         ctx.save_for_backward(keep, o, lse, freqs if freqs is not None else empty, seed if seed is not None else empty)
@@ -329,16 +332,17 @@ class AttentionFn(Function):
             d_o = d_o[:, grk * h * 32:(grk + 1) * h * 32]
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
         if bf16:   # inverse RoPE of dq / dk happens in the kernels' epilogues (-0.15 ms per step against a separate pass)
-            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed, freqs if rope else None)
+            dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed, freqs if rope else None,
+                                     head0=ctx.heads[0], heads_total=ctx.heads[1])
         else:
-            dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed)
+            dqkv = ops.attn_bwd(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed, ctx.heads[0], ctx.heads[1])
             if rope:
                 ops.rope_(dqkv, b * s, dqkv.shape[1], 0, h + hkv, s, freqs, True)
         if ctx.hp is not None:
             from .sharding import gather_qkv_grads
             group, gsz, grk, hg, kg = ctx.hp
             dqkv = gather_qkv_grads(dqkv, group, gsz, hg, kg)
-        return dqkv, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None
 
 
 class DropoutFn(Function):
@@ -346,10 +350,10 @@ class DropoutFn(Function):
     stream, regenerated for the gradient"""
 
     @staticmethod
-    def forward(ctx, x: Tensor, p: float, salt: int = 0):
+    def forward(ctx, x: Tensor, p: float, salt: int = 0, base_seed: Optional[Tensor] = None):
         xc = x if x.is_contiguous() else x.contiguous()
-        seed = next_dropout_seed(xc.device)
-        if salt:      # a rank of a sharded step draws its own masks from the common seed stream
+        seed = base_seed if base_seed is not None else next_dropout_seed(xc.device)
+        if salt:      # a sub-stream of the seed word: a rank of a sharded step, or a (global) head of one attention call
             seed = seed + salt * 0x632BE59BD9B4E019 % (1 << 63)
         ctx.save_for_backward(seed)
         ctx.p = p
@@ -358,11 +362,11 @@ class DropoutFn(Function):
     @staticmethod
     def backward(ctx, d: Tensor):
         (seed,) = ctx.saved_tensors
-        return ops.dropout(d if d.is_contiguous() else d.contiguous(), seed, ctx.p), None, None
+        return ops.dropout(d if d.is_contiguous() else d.contiguous(), seed, ctx.p), None, None, None
 
 
-def dropout(x: Tensor, p: float, training: bool, salt: int = 0) -> Tensor:
-    return DropoutFn.apply(x, float(p), int(salt)) if (training and p > 0.0) else x
+def dropout(x: Tensor, p: float, training: bool, salt: int = 0, base_seed: Optional[Tensor] = None) -> Tensor:
+    return DropoutFn.apply(x, float(p), int(salt), base_seed) if (training and p > 0.0) else x
 
 
 class MatmulFn(Function):
@@ -427,7 +431,7 @@ class RopeFn(Function):
 
 
 def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, head_dim: int,
-                      dropout_p: float = 0.0, seed_rank: int = 0) -> Tensor:
+                      dropout_p: float = 0.0, head0: int = 0, heads_total: int = 0) -> Tensor:
     """softmax(Q K^T / sqrt(d)) V for ANY head_dim (reference attn.py:110-127 accepts every hidden_size % num_heads == 0):
     the unfused general path -- per (batch, head) an S x S score matrix in HBM, exact-fp32 MFMA GEMMs, the row softmax and
     element dropout kernels, autograd by composition.  head_dim 32 (every shipped configuration) runs the flash kernels."""
@@ -438,6 +442,10 @@ def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: i
     scale = torch.full((s,), 1.0 / (head_dim ** 0.5), dtype=torch.float32, device=qkv.device)
     rep = h // hkv
     outs = []
+    # one word of the seed stream per attention call; (batch, GLOBAL head) selects its sub-stream, so a head of a head- /
+    # sequence-parallel rank (heads head0 .. of heads_total) draws the mask it draws in the unsharded step
+    base = next_dropout_seed(qkv.device) if dropout_p > 0.0 else None
+    htot = heads_total if heads_total > 0 else h
     for bi in range(b):
         blk = qkv[bi * s:(bi + 1) * s]
         heads = []
@@ -447,7 +455,7 @@ def attention_general(qkv: Tensor, freqs: Optional[Tensor], b: int, s: int, h: i
             k = blk[:, (h + kv) * head_dim:(h + kv + 1) * head_dim]
             v = blk[:, (h + hkv + kv) * head_dim:(h + hkv + kv + 1) * head_dim]
             p = RowSoftmaxFn.apply(MatmulFn.apply(q, k, True))
-            p = dropout(p, dropout_p, dropout_p > 0.0, seed_rank)
+            p = dropout(p, dropout_p, dropout_p > 0.0, 1 + bi * htot + head0 + hi, base)
             heads.append(MatmulFn.apply(p, v, False))
         outs.append(torch.cat(heads, dim=1))
     return outs[0] if b == 1 else torch.cat(outs, dim=0)

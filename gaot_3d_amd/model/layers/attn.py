@@ -119,7 +119,7 @@ class GroupQueryFlashAttention(nn.Module):
                 assert b == 1, "sequence-parallel attention splits ONE sample"
                 ql = SeqToHeadsFn.apply(qkv, seq_group, self.num_heads, self.num_kv_heads, hd)       # all rows, my heads
                 o = GF.attention_general(ql, freqs, b, s * g, self.num_heads // g, self.num_kv_heads // g, hd, dp,
-                                         dist.get_rank(seq_group))
+                                         dist.get_rank(seq_group) * (self.num_heads // g), self.num_heads)
                 o = HeadsToSeqFn.apply(o, seq_group)
             elif head_group is not None:
                 import torch.distributed as dist
@@ -129,7 +129,8 @@ class GroupQueryFlashAttention(nn.Module):
                     raise ValueError(f"head-parallel attention: {self.num_heads} / {self.num_kv_heads} heads do not divide over {g} ranks")
                 ql = LocalHeadsFn.apply(qkv, head_group, self.num_heads, self.num_kv_heads, hd)
                 o = GatherHeadsFn.apply(GF.attention_general(ql, freqs, b, s, self.num_heads // g, self.num_kv_heads // g, hd, dp,
-                                                             dist.get_rank(head_group)), head_group)
+                                                             dist.get_rank(head_group) * (self.num_heads // g), self.num_heads),
+                                        head_group)
             else:
                 o = GF.attention_general(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, hd, dp)
         elif seq_group is not None:
@@ -140,7 +141,8 @@ class GroupQueryFlashAttention(nn.Module):
             g, r = dist.get_world_size(seq_group), dist.get_rank(seq_group)
             assert b == 1, "sequence-parallel attention splits ONE sample"
             qkv = SeqToHeadsFn.apply(qkv, seq_group, self.num_heads, self.num_kv_heads)
-            o = GF.AttentionFn.apply(qkv, freqs, b, s * g, self.num_heads // g, self.num_kv_heads // g, dp, None, r)
+            o = GF.AttentionFn.apply(qkv, freqs, b, s * g, self.num_heads // g, self.num_kv_heads // g, dp, None,
+                                     r * (self.num_heads // g), self.num_heads)
             o = HeadsToSeqFn.apply(o, seq_group)
         else:
             o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp,

@@ -120,8 +120,10 @@ class IntegralTransform(nn.Module):
         if cd < 3:
             y3 = torch.nn.functional.pad(y_pos, (0, 3 - cd))
             x3 = torch.nn.functional.pad(x_pos, (0, 3 - cd))
-            cols = torch.tensor(list(range(cd)) + [3 + i for i in range(cd)], device=w0.device)
-            w0 = w0.new_zeros(64, 6).index_copy(1, cols, w0)       # [src coords | 0.. | query coords | 0..]
+            # [src coords | 0.. | query coords | 0..] by concatenation: no index tensor built on the host (a pageable
+            # host-to-device copy per forward is a synchronisation and is illegal inside a hipGraph capture)
+            z = w0.new_zeros(64, 3 - cd)
+            w0 = torch.cat([w0[:, :cd], z, w0[:, cd:2 * cd], z], dim=1)
         mid = []
         for fc in fcs[1:-1]:
             mid += [w2(fc), fc.bias]
@@ -157,9 +159,8 @@ class IntegralTransform(nn.Module):
         for i, fc in enumerate(fcs):                                                                        # :154
             w = fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight
             if i == 0 and cdp < 3:      # [src coords | query coords | features] -> [src, 0.. | query, 0.. | features]
-                nf = w.shape[1] - 2 * cdp
-                cols = torch.tensor(list(range(cdp)) + [3 + j for j in range(cdp)] + [6 + j for j in range(nf)], device=w.device)
-                w = w.new_zeros(w.shape[0], 6 + nf).index_copy(1, cols, w)
+                z = w.new_zeros(w.shape[0], 3 - cdp)
+                w = torch.cat([w[:, :cdp], z, w[:, cdp:2 * cdp], z, w[:, 2 * cdp:]], dim=1)
             k = GF.linear(k, w, fc.bias, act=act if i < len(fcs) - 1 else None)
             k = GF.dropout(k, pdrop, self.training)
         if f_y is not None and tt != "nonlinear_kernelonly":                                                # :156-157

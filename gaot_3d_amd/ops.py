@@ -279,18 +279,25 @@ def axpy(a: Tensor, b: Tensor, alpha: float = 1.0, period: Optional[int] = None)
     return out
 
 
-def stream_copy_gbps(nbytes: int = 1 << 30, reps: int = 10) -> float:
+def stream_copy_gbps(nbytes: int = 1 << 30, reps: int = 10, variant: Optional[int] = None) -> float:
     """measured float4 streaming-copy rate of this device in GB/s (read + written bytes over the HIP-event time of ``reps``
-    copies of ``nbytes``): the practical HBM ceiling quoted beside the 8 TB/s spec figure"""
+    copies of ``nbytes``): the practical HBM ceiling quoted beside the 8 TB/s spec figure.  ``variant``: a form of
+    gaot_stream_copy_ex (default: the library's fastest)"""
     lib = _lib.load()
     src = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
+
+    def go():
+        if variant is None:
+            check(lib.gaot_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "gaot_stream_copy")
+        else:
+            check(lib.gaot_stream_copy_ex(_ptr(src), _ptr(dst), nbytes, int(variant), _stream()), "gaot_stream_copy_ex")
     for _ in range(2):
-        check(lib.gaot_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "gaot_stream_copy")
+        go()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        check(lib.gaot_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "gaot_stream_copy")
+        go()
     b.record()
     torch.cuda.synchronize()
     return 2.0 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
@@ -383,8 +390,9 @@ def attn_dropout_mask(seed: Tensor, p: float, b: int, h: int, s: int) -> Tensor:
 
 
 def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float, dropout_p: float = 0.0,
-             seed: Optional[Tensor] = None):
-    """qkv: [B*S, (h + 2*hkv)*32] fused projection output (q | k | v column blocks)."""
+             seed: Optional[Tensor] = None, head0: int = 0, heads_total: int = 0):
+    """qkv: [B*S, (h + 2*hkv)*32] fused projection output (q | k | v column blocks).  ``head0`` / ``heads_total``: the h heads
+    are heads head0 .. of heads_total (a rank's slice): the dropout mask is keyed by the global head index"""
     lib = _lib.load()
     ld = qkv.shape[1]
     dev = qkv.device
@@ -395,12 +403,12 @@ def attn_fwd(qkv: Tensor, b: int, s: int, h: int, hkv: int, scale: float, dropou
     with _timed("attn_fwd"):
         dp, sp = _drop_args(dropout_p, seed)
         check(lib.gaot_attn_fwd(q, k, v, _ptr(o), _ptr(lse), ld, ld, ld, h * 32, b, s, h, hkv, 32, float(scale), dp, sp,
-                                _PRECISION["mode"], _stream()), "gaot_attn_fwd")
+                                int(head0), int(heads_total), _PRECISION["mode"], _stream()), "gaot_attn_fwd")
     return o, lse
 
 
 def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
-             dropout_p: float = 0.0, seed: Optional[Tensor] = None) -> Tensor:
+             dropout_p: float = 0.0, seed: Optional[Tensor] = None, head0: int = 0, heads_total: int = 0) -> Tensor:
     lib = _lib.load()
     dp, sp = _drop_args(dropout_p, seed)
     ld = qkv.shape[1]
@@ -414,12 +422,14 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
             check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
                                     _ptr(d_o), _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
                                     C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
-                                    float(scale), dp, sp, _PRECISION["mode"], mask, _stream()), "gaot_attn_bwd")
+                                    float(scale), dp, sp, int(head0), int(heads_total), _PRECISION["mode"], mask, _stream()),
+                  "gaot_attn_bwd")
     return dqkv
 
 
 def attn_fwd_bf16(qkv: Optional[Tensor], freqs: Optional[Tensor], b: int, s: int, h: int, hkv: int, scale: float,
-                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, image: Optional[Tensor] = None):
+                  dropout_p: float = 0.0, seed: Optional[Tensor] = None, image: Optional[Tensor] = None, head0: int = 0,
+                  heads_total: int = 0):
     """bf16 matrix-core attention on the fused fp32 projection; returns (o, lse, bf16 image kept for backward).
     ``image``: the projection already written as the kernels' image (qkv_image): qkv is then not read"""
     lib = _lib.load()
@@ -430,7 +440,7 @@ def attn_fwd_bf16(qkv: Optional[Tensor], freqs: Optional[Tensor], b: int, s: int
     with _timed("attn_fwd"):
         dp, sp = _drop_args(dropout_p, seed)
         check(lib.gaot_attn_fwd_bf16(_ptr(None if image is not None else qkv), _ptr(freqs), _ptr(img), _ptr(o), _ptr(lse), b, s,
-                                     h, hkv, 32, float(scale), dp, sp, _stream()), "gaot_attn_fwd_bf16")
+                                     h, hkv, 32, float(scale), dp, sp, int(head0), int(heads_total), _stream()), "gaot_attn_fwd_bf16")
     return o, lse, img
 
 
@@ -480,7 +490,7 @@ def attn_bwd_scratch(b: int, s: int, h: int, hkv: int, device) -> Tensor:
 
 def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
                   dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None,
-                  do_image: Optional[Tensor] = None, fused: Optional[bool] = None) -> Tensor:
+                  do_image: Optional[Tensor] = None, fused: Optional[bool] = None, head0: int = 0, heads_total: int = 0) -> Tensor:
     """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection.
     ``do_image`` (instead of d_o): an attn_bwd_scratch buffer whose head already holds the bf16 dO (sequence-parallel
     exchange): only delta is computed from it.
@@ -501,8 +511,8 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b:
     for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1),) + phases:
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
-                                         _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, mask, _stream()),
-                  "gaot_attn_bwd_bf16")
+                                         _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, int(head0), int(heads_total), mask,
+                                         _stream()), "gaot_attn_bwd_bf16")
     return dqkv
 
 

@@ -417,10 +417,11 @@ class SeqAttnFn(torch.autograd.Function):
         img = ops._ws(_lib_image_bytes(1, s_total, hl, kl), x.device)                 # image + the kernels' scratch behind it
         recv = img[:s_total * lw * 2].view(torch.bfloat16).view(world, r, lw)
         _all_to_all_into(recv, send, group)
-        seed = None
-        if dropout_p > 0.0:   # a head's mask is drawn by the rank that owns it: per-rank seed word from the common stream
-            seed = GF.next_dropout_seed(x.device) + rank * 0x632BE59BD9B4E019 % (1 << 63)
-        o, lse, _ = ops.attn_fwd_bf16(None, None, 1, s_total, hl, kl, scale, dropout_p, seed, image=img)
+        # ONE seed word for all ranks (the common stream); the kernels key a head's mask by its GLOBAL index, so the rank that
+        # owns a head draws the mask the unsharded step draws for it
+        seed = GF.next_dropout_seed(x.device) if dropout_p > 0.0 else None
+        o, lse, _ = ops.attn_fwd_bf16(None, None, 1, s_total, hl, kl, scale, dropout_p, seed, image=img, head0=rank * hl,
+                                      heads_total=h)
         ob = ops.cast_bf16(o)                                                         # [S, hl*32] = [world, r, hl*32] blocks
         orecv = torch.empty(world, r, hl * 32, dtype=torch.bfloat16, device=x.device)
         _all_to_all_into(orecv, ob.view(world, r, hl * 32), group)
@@ -447,7 +448,7 @@ class SeqAttnFn(torch.autograd.Function):
         dorecv = scratch[:s_total * hl * 32 * 2].view(torch.bfloat16).view(world, r, hl * 32)
         _all_to_all_into(dorecv, dsend, group)                                        # = the kernels' dO image of my heads
         dqkv = ops.attn_bwd_bf16(img, o, None, lse, 1, s_total, hl, kl, scale, dropout_p, seed if dropout_p > 0.0 else None,
-                                 freqs if freqs.numel() else None, do_image=scratch)
+                                 freqs if freqs.numel() else None, do_image=scratch, head0=rank * hl, heads_total=h)
         gsend = ops.cast_bf16(dqkv).view(world, r, lw)
         grecv = torch.empty(world, r, lw, dtype=torch.bfloat16, device=d.device)
         _all_to_all_into(grecv, gsend, group)
@@ -502,9 +503,12 @@ def allreduce_partial_grads(params: List[torch.nn.Parameter], group):
 
 class GradBuckets:
     """SUM all-reduce of the partial parameter gradients in buckets, each launched (asynchronously, on its own process
-    group = its own RCCL stream) as soon as backward has produced the last gradient of the bucket, so that the exchange of
-    the 45 MB of Transformer weight gradients of the sequence-parallel step runs under the remaining backward instead of
-    after it.  Buckets follow the order in which backward finishes parameters (reverse registration order).  After
+    group = its own RCCL stream) as soon as backward has produced the last gradient of the bucket AND every earlier bucket is
+    launched, so that the exchange of the 45 MB of Transformer weight gradients of the sequence-parallel step runs under
+    the remaining backward instead of after it.  Buckets follow the order in which backward finishes parameters (reverse
+    registration order) and are issued STRICTLY in index order on every rank: a rank whose shard produced no gradient for
+    one parameter of bucket i launches it (and every later one) in ``finish()`` while the other ranks launch it from the
+    hooks -- the sequence of collectives on the group is the same everywhere, only the time differs.  After
     ``finish()`` every ``p.grad`` is a view into its bucket's flat buffer holding the summed gradient."""
 
     def __init__(self, params: List[torch.nn.Parameter], group, bucket_bytes: int = 12 << 20):
@@ -522,7 +526,8 @@ class GradBuckets:
             self._add(cur)
         self._index = {}
         self._hooks = []
-        self._unused = None        # ids of parameters NO rank produces a gradient for (found at the first eager finish())
+        self._next = 0             # first bucket not launched yet: the only one a hook may launch
+        self._unused = None        # ids of parameters NO rank produces a gradient for (refreshed at every eager finish())
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[id(p)] = bi
@@ -543,7 +548,15 @@ class GradBuckets:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
-            b["pending"], b["launched"] = len(b["params"]), False
+            b["pending"], b["launched"] = self._expected(b), False
+        self._next = 0
+
+    def _expected(self, b):
+        """gradients a bucket waits for: its parameters minus those NO rank produces a gradient for (the same set on every
+        rank: it comes out of an all-reduce), so that an unused parameter (``skip_proj`` without long-range skips) does not
+        keep its bucket and every later one out of the backward pass"""
+        unused = self._unused or ()
+        return sum(1 for p in b["params"] if id(p) not in unused)
 
     def _on_grad(self, p):
         b = self.buckets[self._index[id(p)]]
@@ -552,22 +565,27 @@ class GradBuckets:
             # while its all-reduce may still be in flight on the other communicator: refuse instead of racing
             raise RuntimeError("GradBuckets: a gradient arrived for a bucket whose all-reduce is already launched; call "
                                "finish() (or reset()) between two backward passes")
-        b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        if id(p) not in (self._unused or ()):
+            b["pending"] -= 1
+        # index order: a complete bucket behind an incomplete one waits for it (finish() at the latest)
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] <= 0:
+            self._launch(self.buckets[self._next])
 
     def _launch(self, b):
         # EVERY parameter of the bucket ends up with p.grad = its view of the flat buffer -- also one that received no
         # gradient on this rank (a shard without an edge of that operator): its view is zero-filled here and holds the other
-        # ranks' sum afterwards, so the optimizer steps it on every rank alike and the replicas cannot drift apart
+        # ranks' sum afterwards, so the optimizer steps it on every rank alike and the replicas cannot drift apart.  A
+        # parameter NO rank has a gradient for keeps grad = None (``_unused``), its view is zeroed all the same so that a
+        # stale sum of an earlier step can never be added again
+        assert b is self.buckets[self._next]
         copy_dst, copy_src = [], []
         unused = self._unused or ()
         for p, v in zip(b["params"], b["views"]):
             g = p.grad
-            if g is None and id(p) in unused:
-                continue               # no rank has a gradient for it (e.g. skip_proj without long-range skips): stays None
             if g is None:
                 v.zero_()
+                if id(p) in unused:
+                    continue           # e.g. skip_proj without long-range skips: stays None, the optimizer skips it
             elif g.data_ptr() != v.data_ptr():
                 copy_dst.append(v)
                 copy_src.append(g)
@@ -580,15 +598,23 @@ class GradBuckets:
             b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         comm.run(issue, (flat,), "grad_bucket_issue")
         b["launched"] = True
+        self._next += 1
 
     def finish(self):
-        """launch what backward left incomplete (parameters that received no gradient), then wait for every bucket; after
-        it every ``p.grad`` of every bucket is a view into the flat buffer holding the sum over the ranks"""
-        if self._unused is None and not comm.capturing():
-            self._find_unused()
-        for b in self.buckets:
-            if not b["launched"]:
-                self._launch(b)
+        """launch what backward left incomplete (parameters that received no gradient) in index order, then wait for every
+        bucket; after it every ``p.grad`` of every bucket is a view into the flat buffer holding the sum over the ranks"""
+        eager = not comm.capturing()
+        if not eager and self._unused is None:
+            raise RuntimeError("GradBuckets: run one eager step before capturing (which parameters receive a gradient on "
+                               "no rank is found by an all-reduce that needs a host read)")
+        # which parameters have a LOCAL gradient this step (a launched bucket has re-pointed its gradients: read before)
+        had = None
+        if eager:
+            had = self._local_flags()
+        while self._next < len(self.buckets):
+            self._launch(self.buckets[self._next])
+        if eager:
+            self._find_unused(had)         # AFTER the last bucket: the same position in every rank's sequence
         buckets = self.buckets
 
         def wait():
@@ -598,17 +624,33 @@ class GradBuckets:
                     b["handle"] = None
         comm.run(wait, (), "grad_bucket_wait")
         for b in self.buckets:
-            b["pending"], b["launched"] = len(b["params"]), False
+            b["pending"], b["launched"] = self._expected(b), False
+        self._next = 0
 
-    def _find_unused(self):
-        """one tiny all-reduce at the first eager step: which parameters get a gradient on NO rank.  Those keep
-        ``grad = None`` as in an unsharded run (the optimizer skips them: reference semantics for ``skip_proj`` with
-        ``use_long_range_skip=False``, attn.py:321); a parameter that only THIS rank has no gradient for is zero-filled."""
+    def _local_flags(self):
+        """1.0 per parameter that holds a gradient on THIS rank after this backward, read before ``finish()`` launches the
+        rest: a bucket launched from the hooks had every expected gradient (its ``p.grad`` are views now, an unused
+        parameter's is still None), the others are as backward left them.  A gradient left over from an earlier step counts
+        exactly as an unsharded ``p.grad`` left over would (callers clear gradients between steps)."""
+        return [0.0 if p.grad is None else 1.0 for b in self.buckets for p in b["params"]]
+
+    def _find_unused(self, had):
+        """one tiny all-reduce per eager step, issued behind the last bucket on every rank: which parameters got a gradient
+        on NO rank.  Those keep ``grad = None`` as in an unsharded run (the optimizer skips them: reference semantics for
+        ``skip_proj`` with ``use_long_range_skip=False``, attn.py:321); a parameter that only THIS rank has no gradient for
+        was zero-filled and now holds the other ranks' sum.  Refreshed every eager step, so a parameter that starts to
+        receive gradients later is picked up by every rank in the same step."""
         ps = [p for b in self.buckets for p in b["params"]]
-        # a bucket launched from the hooks has already re-pointed its gradients: those parameters have one somewhere
-        flags = torch.tensor([0.0 if (p.grad is None) else 1.0 for p in ps], dtype=torch.float32, device=ps[0].device)
+        flags = torch.tensor(had, dtype=torch.float32, device=ps[0].device)
         dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
-        self._unused = {id(p) for p, f in zip(ps, flags.tolist()) if f == 0.0}
+        unused = {id(p) for p, f in zip(ps, flags.tolist()) if f == 0.0}
+        for b in self.buckets:
+            for p, v in zip(b["params"], b["views"]):
+                if id(p) in unused:
+                    p.grad = None          # (a zero-filled view while the set was not known yet)
+                elif p.grad is None:
+                    p.grad = v             # left None by an older set: the view holds the other ranks' sum
+        self._unused = unused
 
     def remove(self):
         for h in self._hooks:

@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 8
+#define GAOT_ABI_VERSION 9
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -149,15 +149,19 @@ int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, int64_t N, in
  * DEVICE pointer to one 64-bit word read when the kernel runs (so a captured hipGraph sees the value of each
  * replay); the backward must be given the value the forward saw.  torch's own Philox mask is not reproducible
  * outside torch; gaot_attn_dropout_mask materialises this one (keep[b][h][q][k], 1 byte each) for checks.
+ * head0 / heads_total (0, 0 = the launch holds all heads): the launch's H heads are heads head0 .. head0+H-1 of heads_total --
+ * one rank's slice in a head- / sequence-parallel step (no reference counterpart: stat.py:431-436 is sample-level DDP only);
+ * the mask is keyed by the GLOBAL head index b * heads_total + head0 + h, so all ranks share ONE seed word and a head draws
+ * the same mask wherever it runs.
  * ------------------------------------------------------------------------------------------- */
 int gaot_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int64_t ldq, int64_t ldk,
                   int64_t ldv, int64_t ldo, int B, int S, int H, int HKV, int head_dim, float scale, float dropout_p,
-                  const unsigned long long* dropout_seed, int precision, gaot_stream_t stream);
+                  const unsigned long long* dropout_seed, int head0, int heads_total, int precision, gaot_stream_t stream);
 int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                   float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                   int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
-                  float scale, float dropout_p, const unsigned long long* dropout_seed, int precision,
-                  int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */, gaot_stream_t stream);
+                  float scale, float dropout_p, const unsigned long long* dropout_seed, int head0, int heads_total,
+                  int precision, int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */, gaot_stream_t stream);
 int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout_p, int B, int H, int S,
                            unsigned char* keep, gaot_stream_t stream);
 /* the seed stream: *out = *state; *state += stride -- the word one dropout call uses, and the advance, in one launch */
@@ -205,11 +209,11 @@ size_t gaot_attn_bwd_bf16_scratch_bytes(int B, int S, int H, int HKV);
 int gaot_attn_bwd_bf16_fused_eligible(int B, int S, int H, int HKV);
 int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, void* qkv_image, float* o, float* lse, int B, int S,
                        int H, int HKV, int head_dim, float scale, float dropout_p,
-                       const unsigned long long* dropout_seed, gaot_stream_t stream);
+                       const unsigned long long* dropout_seed, int head0, int heads_total, gaot_stream_t stream);
 int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const float* d_o, const float* lse, void* do_image,
                        float* delta, float* dqkv, const float* rope_freqs, int B, int S, int H, int HKV, int head_dim,
-                       float scale, float dropout_p, const unsigned long long* dropout_seed, int phase_mask,
-                       gaot_stream_t stream);
+                       float scale, float dropout_p, const unsigned long long* dropout_seed, int head0, int heads_total,
+                       int phase_mask, gaot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row / element kernels (HBM-bound).
@@ -271,6 +275,10 @@ int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n
 /* dst = src as a float4 grid-stride copy: the streaming-copy rate bench.py reports beside the 8 TB/s spec figure
  * (SURVEY 8d "also report vs a measured streaming-copy peak"; no reference counterpart) */
 int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream);
+/* the same copy in a chosen form (measurement only): 0 = grid-stride plain; 1..3 = a contiguous 64-KiB chunk per workgroup,
+ * 8 loads in flight per thread, non-temporal loads + stores / plain loads + non-temporal stores / plain; 4..6 = the same with
+ * 256-KiB chunks and 4 loads in flight.  gaot_stream_copy runs the fastest form measured on MI355X. */
+int gaot_stream_copy_ex(const void* src, void* dst, int64_t bytes, int variant, gaot_stream_t stream);
 int gaot_patchify(const float* src, float* dst, int B, int D, int H, int W, int P, int C, int to_tokens,
                   gaot_stream_t stream);
 size_t gaot_mse_workspace_bytes(void);

@@ -441,7 +441,9 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, keep: Optional[Tensor] = None, p_drop:
         # the reference's own call (attn.py:126).  On the CPU this is torch's tiled kernel: no [S, S] weights in memory (8.6 GB per
         # layer at S = 16 384, kept for the backward) and ~20x faster than the explicit form below, which it equals to fp32
         # rounding (1e-7 on the output, 1e-6 on the gradients at S = 4 096)
-        return F.scaled_dot_product_attention(q, k, v)
+        # p_drop > 0 without a mask: torch draws the mask itself, exactly the reference's training-mode call (timing runs only:
+        # the draw cannot be replayed outside torch, parity runs pass ``keep``)
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=p_drop)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1]), dim=-1)  # the same, written out: the mask acts on the weights
     att = att * keep.to(att.dtype) / (1.0 - p_drop)
     return att @ v
@@ -503,8 +505,9 @@ def transformer_block(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, skip: Op
 
 
 def transformer(sd: SD, prefix: str, x: Tensor, tcfg, rope: bool, drop=None) -> Tensor:
-    """attn.py:298-325.  ``drop``: None, or (list of keep masks in block call order, p) for the training path."""
-    masks = iter(drop[0]) if drop is not None else None
+    """attn.py:298-325.  ``drop``: None, or (list of keep masks in block call order, p) for the training path, or
+    ("torch", p): SDPA draws its own mask (the reference's call as it stands; CPU-baseline timing)."""
+    masks = iter(drop[0]) if drop is not None and not isinstance(drop[0], str) else None
     pd = drop[1] if drop is not None else 0.0
     nxt = (lambda: next(masks)) if masks is not None else (lambda: None)
     if (prefix + "input_proj.weight") in sd:

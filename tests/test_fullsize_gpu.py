@@ -309,7 +309,9 @@ def test_configs3_radius_encoder_bidirectional_decoder_geoembed_both_sides(sampl
 def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
     """BASELINE configs[2] at full size: the 500 000-point sample (L = 10, bf16) split over two ranks (both on this GPU, gloo)
     -- points / edges by range, Transformer by token rows, attention by heads with the bf16 exchange -- against the unsharded
-    bf16 step on the same weights: loss, gradient norms of every tensor and leading gradient values."""
+    bf16 step on the same weights: loss, gradient norms of every tensor and leading gradient values.  Attention dropout 0.1
+    (training mode, the configuration `bench.py --gpus N` times): the masks are keyed by the global head index and all ranks
+    read one seed word, so both runs draw the same masks (VERDICT r4 #2)."""
     import gaot_3d_amd
     import bench
     import test_model_gpu as TM
@@ -317,10 +319,11 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
     from gaot_3d_amd.model import init_model
     batch, tokens = sample                         # make_synthetic_sample(N_PTS, LATENT, k=KNN, seed=0)
     torch.manual_seed(0)
-    model = init_model(6, 1, "gaot_3d", bench.model_config(LATENT, 10, KNN, 0.0)).to(DEV).train()
+    model = init_model(6, 1, "gaot_3d", bench.model_config(LATENT, 10, KNN, 0.1)).to(DEV).train()
     gaot_3d_amd.set_precision("bf16")
     try:
         gaot_3d_amd.clear_graph_cache(batch)
+        GF.set_dropout_seed(20261006, DEV)
         loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens), batch.x)
         loss.backward()
         torch.cuda.synchronize()
@@ -328,10 +331,10 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
         gaot_3d_amd.set_precision("fp32")
     got = TM._run_shard_workers(tmp_path, 2, 29591, GAOT_TEST_PREC="bf16", GAOT_TEST_CFG="bench", GAOT_TEST_PARALLEL="seq",
                                 GAOT_TEST_POINTS=N_PTS, GAOT_TEST_LATENT=",".join(str(v) for v in LATENT), GAOT_TEST_K=KNN,
-                                GAOT_TEST_LAYERS=10, GAOT_TEST_SEED=0)
+                                GAOT_TEST_LAYERS=10, GAOT_TEST_SEED=0, GAOT_TEST_DROPOUT=0.1, GAOT_TEST_DROPSEED=20261006)
     print(f"[parity] configs2_2rank/loss: {got['loss']:.8f} vs {float(loss.detach()):.8f}")
     assert abs(got["loss"] - float(loss.detach())) <= 2e-3 * abs(float(loss.detach()))
-    worst, n = 0.0, 0
+    worst, worst_head, n = 0.0, 0.0, 0
     for k, p in model.named_parameters():
         if p.grad is None:
             continue
@@ -339,11 +342,13 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
         assert k in got["norms"], k
         rel = abs(got["norms"][k] - float(ref.norm())) / (float(ref.norm()) + 1e-30)
         worst = max(worst, rel)
-        assert rel <= 3e-2, (k, got["norms"][k], float(ref.norm()))
+        assert rel <= 2e-2, (k, got["norms"][k], float(ref.norm()))         # achieved 6.4e-3 without dropout (profiles/r3_c)
         head = torch.tensor(got["grads"][k], dtype=torch.float64)
-        assert float((head - ref.flatten()[:64]).abs().max()) <= 5e-2 * float(ref.abs().max()) + 1e-9, k
+        hd = float((head - ref.flatten()[:64]).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        worst_head = max(worst_head, hd)
+        assert hd <= 3e-2, (k, hd)
         n += 1
-    print(f"[parity] configs2_2rank: {n} gradient tensors, worst norm deviation {worst:.2e}")
+    print(f"[parity] configs2_2rank (dropout 0.1): {n} gradient tensors, worst norm deviation {worst:.2e}, worst leading value {worst_head:.2e} of peak")
     assert n > 100
 
 

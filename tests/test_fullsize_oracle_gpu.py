@@ -12,7 +12,8 @@
   their edges) and ALL weight / bias gradients against the oracle's kernel MLP evaluated in fp64 over all 4 M edges.
 
 Tolerances: fp32 kernels rtol 1e-4 / atol 1e-5-of-peak on outputs, rtol 1e-3 on gradients; bf16 kernels
-max-abs <= 2e-2 of the reference's peak on outputs, cosine >= 0.999 and max-abs <= 5e-2 of peak on gradients."""
+max-abs <= 1e-2 of the reference's peak on outputs, cosine >= 0.999 and max-abs <= 1e-2 / 2e-2 of peak on gradients (<= 3 x the
+achieved errors of profiles/r4_ad_parity.txt: a 5 x regression fails)."""
 import math
 import os
 import sys
@@ -265,7 +266,7 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
     if precision == "fp32":
         PAR.close(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 1e-4, 1e-5 * float(ref.abs().max()))
     else:
-        PAR.close_peak(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 2e-2, rel_l2=1e-2)
+        PAR.close_peak(f"{tag}/out[{qs.numel()} rows, {int(sel.sum())} edges]", out[qs.to(DEV)], ref, 1e-2, rel_l2=1e-2)   # achieved 2.9e-3
 
     # ---- backward, grad f_y: every edge of >= 1 000 sampled source rows; mean reduction = sum / degree of the query -------
     ss = _sample_rows(deg_src, 1000, gen)
@@ -282,7 +283,7 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
         PAR.close(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-3, 1e-5 * float(fsub.grad.abs().max()))
     else:
         PAR.cosine(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 0.999)
-        PAR.close_peak(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 5e-2)
+        PAR.close_peak(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-2)     # achieved 2.8e-3 (r4_ad_parity)
 
     # ---- backward, weight / bias gradients: all E edges through the oracle's kernel MLP in fp64, chunked -------------------
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
@@ -298,7 +299,100 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
                 PAR.close(f"{tag}/grad_{nm}{i}", got, r, 1e-3, 2e-5 * float(r.abs().max()))
             else:
                 PAR.cosine(f"{tag}/grad_{nm}{i}", got, r, 0.999)
-                PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 5e-2)
+                PAR.close_peak(f"{tag}/grad_{nm}{i}", got, r, 2e-2)     # achieved <= 6.3e-3 (bias), 5.3e-3 (weights)
+
+
+@pytest.fixture(scope="module")
+def sample8m():
+    """BASELINE configs[4]-sized geometry: 8 000 000 points, 64 M edges per direction (knn k = 8 and its flip)"""
+    from gaot_3d_amd.data import make_synthetic_sample
+    batch, tokens = make_synthetic_sample(8_000_000, LATENT, k=KNN, seed=1, device=DEV, out_channels=4)
+    yield batch, tokens.to(DEV)
+    del batch
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("side,nh", [("encoder", 3), ("decoder", 2)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
+    """the fused GNO forward / backward on the 64 M-edge graphs of an 8 M-point sample (BASELINE configs[4]; VERDICT r4: that
+    size was exercised only through properties and sharded == unsharded) against the oracle on SAMPLED rows: forward on the
+    sub-graph of >= 1 000 query rows; grad f_y on every edge of >= 1 000 source rows (full dout); weight / bias gradients
+    from a second backward whose dout is zero outside >= 4 000 sampled query rows -- the kernels still walk all 64 M edges
+    (row pointers and gathers beyond 2^31 bytes), the oracle needs the sampled rows' edges only (fp64)."""
+    from gaot_3d_amd import ops
+    batch, tokens = sample8m
+    n, m = batch.pos.shape[0], tokens.shape[0]
+    if side == "encoder":
+        ei, y_pos, x_pos, n_src, n_dst = batch.encoder_edge_index_s0, batch.pos, tokens, n, m
+    else:
+        ei, y_pos, x_pos, n_src, n_dst = batch.decoder_edge_index_s0, tokens, batch.pos, m, n
+    gen = torch.Generator().manual_seed(78)
+    sd = _mlp_sd(nh, 15 + nh)
+    ws = [sd[f"channel_mlp.fcs.{i}.weight"].to(DEV) for i in range(nh + 1)]
+    bs = [sd[f"channel_mlp.fcs.{i}.bias"].to(DEV) for i in range(nh + 1)]
+    f_y = torch.randn(n_src, 32, generator=gen)
+    dout = torch.randn(n_dst, 32, generator=gen)
+    graph = ops.build_graph(ei, n_src, n_dst)
+    prec = 0 if precision == "fp32" else 1
+    f_d = f_y.to(DEV)
+    out = ops.gno_forward(ws, bs, y_pos, x_pos, f_d, graph, precision=prec)
+    gf, _, _ = ops.gno_backward(ws, bs, y_pos, x_pos, f_d, dout.to(DEV), graph, precision=prec)
+    ei_c = ei.cpu().long()
+    src, dst = ei_c[0], ei_c[1]
+    deg_dst = torch.bincount(dst, minlength=n_dst)
+    deg_src = torch.bincount(src, minlength=n_src)
+    qw = _sample_rows(deg_dst, 4000, gen)                   # query rows that carry the masked dout
+    dmask = torch.zeros_like(dout)
+    dmask[qw] = dout[qw]
+    _, gw, gb = ops.gno_backward(ws, bs, y_pos, x_pos, f_d, dmask.to(DEV), graph, precision=prec)
+    torch.cuda.synchronize()
+    y_c, x_c = y_pos.cpu(), x_pos.cpu()
+    tag = f"gno_8m_{side}_nh{nh}_{precision}"
+    print(f"[parity] {tag}: E={ei.shape[1]} max query degree {int(deg_dst.max())}, empty query rows {int((deg_dst == 0).sum())}, "
+          f"max source degree {int(deg_src.max())}")
+    assert ei.shape[1] == 64_000_000
+
+    qs = _sample_rows(deg_dst, 1000, gen)
+    local = torch.full((n_dst,), -1, dtype=torch.long)
+    local[qs] = torch.arange(qs.numel())
+    sel = local[dst] >= 0
+    ref = orc.integral_transform(sd, "", y_c, x_c[qs], torch.stack([src[sel], local[dst[sel]]]), f_y)
+    if precision == "fp32":
+        PAR.close(f"{tag}/out[{qs.numel()} rows]", out[qs.to(DEV)], ref, 1e-4, 1e-5 * float(ref.abs().max()))
+    else:
+        PAR.close_peak(f"{tag}/out[{qs.numel()} rows]", out[qs.to(DEV)], ref, 1e-2, rel_l2=1e-2)
+
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ss = _sample_rows(deg_src, 1000, gen)
+    local = torch.full((n_src,), -1, dtype=torch.long)
+    local[ss] = torch.arange(ss.numel())
+    sel = local[src] >= 0
+    es, ed = src[sel], dst[sel]
+    fsub = f_y[ss].double().requires_grad_(True)
+    kern = orc.channel_mlp(sd64, "channel_mlp.", torch.cat([y_c[es], x_c[ed]], dim=1).double())
+    (kern * fsub[local[es]] * (dout[ed].double() / deg_dst[ed].clamp(min=1)[:, None])).sum().backward()
+    if precision == "fp32":
+        PAR.close(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-3, 1e-5 * float(fsub.grad.abs().max()))
+    else:
+        PAR.cosine(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 0.999)
+        PAR.close_peak(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-2)
+
+    local = torch.full((n_dst,), -1, dtype=torch.long)
+    local[qw] = torch.arange(qw.numel())
+    sel = local[dst] >= 0
+    es, ed = src[sel], dst[sel]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
+    kern = orc.channel_mlp(leaves, "channel_mlp.", torch.cat([y_c[es], x_c[ed]], dim=1).double())
+    (kern * f_y[es].double() * (dout[ed].double() / deg_dst[ed].clamp(min=1).double()[:, None])).sum().backward()
+    for i in range(nh + 1):
+        for nm, got in (("weight", gw[i]), ("bias", gb[i])):
+            r = leaves[f"channel_mlp.fcs.{i}.{nm}"].grad
+            if precision == "fp32":
+                PAR.close(f"{tag}/grad_{nm}{i}[{qw.numel()} query rows]", got, r, 1e-3, 2e-5 * float(r.abs().max()))
+            else:
+                PAR.cosine(f"{tag}/grad_{nm}{i}[{qw.numel()} query rows]", got, r, 0.999)
+                PAR.close_peak(f"{tag}/grad_{nm}{i}[{qw.numel()} query rows]", got, r, 2e-2)
 
 
 @pytest.mark.parametrize("side", ["encoder_knn", "decoder_knn", "encoder_bidirectional"])
@@ -414,9 +508,10 @@ def test_model_full_size_vs_oracle():
             PAR.close("fullsize_vs_oracle_fp32/loss", loss, loss_r, 1e-5, 0.0)
             PAR.grads_cosine("fullsize_vs_oracle_fp32/grads", grads, grads_r, 0.99999, per_tensor=0.9999)
         else:
-            PAR.close_peak("fullsize_vs_oracle_bf16/pred", pred, pred_r, 3e-2, rel_l2=2e-2)
-            PAR.close("fullsize_vs_oracle_bf16/loss", loss, loss_r, 1e-2, 0.0)
-            PAR.grads_cosine("fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.999, per_tensor=0.99)
+            # achieved (profiles/r4_ad_parity.txt): pred 3.2e-3 of peak, rel_l2 1.4e-3, loss 2.3e-3, gradient cosine 0.999991
+            PAR.close_peak("fullsize_vs_oracle_bf16/pred", pred, pred_r, 1e-2, rel_l2=5e-3)
+            PAR.close("fullsize_vs_oracle_bf16/loss", loss, loss_r, 7e-3, 0.0)
+            PAR.grads_cosine("fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.9999, per_tensor=0.99)
         del m, pred, loss, grads
         torch.cuda.empty_cache()
 
@@ -472,8 +567,9 @@ def test_configs3_full_size_vs_oracle():
             PAR.close("configs3_fullsize_vs_oracle_fp32/loss", loss, loss_r, 1e-5, 0.0)
             PAR.grads_cosine("configs3_fullsize_vs_oracle_fp32/grads", grads, grads_r, 0.99999, per_tensor=0.9999)
         else:
-            PAR.close_peak("configs3_fullsize_vs_oracle_bf16/pred", pred, pred_r, 3e-2, rel_l2=2e-2)
-            PAR.close("configs3_fullsize_vs_oracle_bf16/loss", loss, loss_r, 1e-2, 0.0)
-            PAR.grads_cosine("configs3_fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.999, per_tensor=0.99)
+            # achieved: pred 3.5e-3 of peak, rel_l2 7.2e-4, loss 3.7e-4, gradient cosine 0.999999
+            PAR.close_peak("configs3_fullsize_vs_oracle_bf16/pred", pred, pred_r, 1e-2, rel_l2=3e-3)
+            PAR.close("configs3_fullsize_vs_oracle_bf16/loss", loss, loss_r, 2e-3, 0.0)
+            PAR.grads_cosine("configs3_fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.9999, per_tensor=0.99)
         del m, pred, loss, grads
         torch.cuda.empty_cache()

@@ -206,7 +206,7 @@ gaot_3d_amd.set_precision(E("GAOT_TEST_PREC", "fp32"))
 npts, latent, k = int(E("GAOT_TEST_POINTS", "3001")), tuple(int(v) for v in E("GAOT_TEST_LATENT", "8,8,4").split(",")), int(E("GAOT_TEST_K", "4"))
 if E("GAOT_TEST_CFG") == "bench":    # the benchmark's model section (pressure.yaml), dropout off
     import bench
-    cfg = bench.model_config(latent, int(E("GAOT_TEST_LAYERS", "10")), k, 0.0, E("GAOT_TEST_WORKLOAD", "cfg1"))
+    cfg = bench.model_config(latent, int(E("GAOT_TEST_LAYERS", "10")), k, float(E("GAOT_TEST_DROPOUT", "0")), E("GAOT_TEST_WORKLOAD", "cfg1"))
 else:
     cfg = T.small_config(hidden=int(E("GAOT_TEST_HIDDEN", "0")) or None, layers=int(E("GAOT_TEST_LAYERS", "2")), latent=latent, k=k)
 nout = int(E("GAOT_TEST_OUT", "1"))
@@ -221,6 +221,8 @@ def one():
     gaot_3d_amd.clear_graph_cache(local)
     model.zero_grad(set_to_none=True)
     return step.forward_backward(local, tokens)
+if E("GAOT_TEST_DROPSEED"):     # attention dropout on: every rank starts the common seed stream where the unsharded step started it
+    GF.set_dropout_seed(int(E("GAOT_TEST_DROPSEED")), dev)
 loss = one()
 torch.cuda.synchronize()
 extra = {}
@@ -255,7 +257,9 @@ dist.destroy_process_group()
 """
 
 
-def small_config(dec_geo=None, heads=None, hidden=None, layers=2, latent=(8, 8, 4), k=4, head_dim=None, embed=None):
+def small_config(dec_geo=None, heads=None, hidden=None, layers=2, latent=(8, 8, 4), k=4, head_dim=None, embed=None, dropout=None):
+    if dropout is None:
+        dropout = float(os.environ.get("GAOT_TEST_DROPOUT", "0"))
     if dec_geo is None:
         dec_geo = os.environ.get("GAOT_TEST_DEC_GEO", "0") == "1"
     if heads is None:
@@ -275,16 +279,21 @@ def small_config(dec_geo=None, heads=None, hidden=None, layers=2, latent=(8, 8, 
         transformer=TransformerConfig(patch_size=2, hidden_size=head_dim * heads, use_attn_norm=True, use_ffn_norm=True, norm_eps=1e-6,
                                       num_layers=layers, positional_embedding="rope", use_long_range_skip=True,
                                       attn_config=AttentionConfig(hidden_size=head_dim * heads, num_heads=heads, num_kv_heads=heads,
-                                                                  atten_dropout=0.0),
+                                                                  atten_dropout=float(dropout)),
                                       ffn_config=FFNConfig(hidden_size=128)),
         latent_tokens=tuple(latent))
 
 
-@pytest.mark.parametrize("dec_geo,parallel,world", [(False, "seq", 2), (True, "seq", 2), (False, "head", 2), (True, "replicated", 2),
-                                                    # four ranks, one head each: an exchange that orders its chunks wrongly is
-                                                    # invisible with two ranks (every permutation of two is a swap)
-                                                    (False, "seq", 4), (False, "head", 4)])
-def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world):
+@pytest.mark.parametrize("dec_geo,parallel,world,dropout", [
+    (False, "seq", 2, 0.0), (True, "seq", 2, 0.0), (False, "head", 2, 0.0), (True, "replicated", 2, 0.0),
+    # four ranks, one head each: an exchange that orders its chunks wrongly is invisible with two ranks (every permutation
+    # of two is a swap)
+    (False, "seq", 4, 0.0), (False, "head", 4, 0.0),
+    # training-mode attention dropout (reference default 0.1, attn.py:22, 122-126): the mask is keyed by the GLOBAL head
+    # index and all ranks read one seed word, so a head draws the same mask wherever it runs -- the sharded step must equal
+    # the unsharded one exactly as without dropout
+    (False, "seq", 2, 0.1), (False, "head", 2, 0.1), (False, "seq", 4, 0.1), (False, "head", 4, 0.1), (True, "replicated", 2, 0.1)])
+def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world, dropout):
     """The N>1 path end to end on the real kernels: two processes (both on cuda:0, gloo) each take half of the points
     of one sample; loss and every parameter gradient must equal the unsharded step on the same model and sample.
     parallel = "seq": the latent Transformer runs on half of the token rows per rank with one of the two heads per rank
@@ -299,8 +308,9 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world):
     gaot_3d_amd.set_precision("fp32")
     torch.manual_seed(0)
     heads = 2 if world == 2 else 4
-    model = init_model(6, 1, "gaot_3d", small_config(dec_geo, heads)).to(DEV).train()
+    model = init_model(6, 1, "gaot_3d", small_config(dec_geo, heads, dropout=dropout)).to(DEV).train()
     batch, tokens = make_synthetic_sample(3001, (8, 8, 4), k=4, seed=1, device=str(DEV))
+    GF.set_dropout_seed(20261004, DEV)
     pred = model(batch=batch, tokens_pos=tokens.to(DEV))
     loss = GF.mse_loss(pred, batch.x)
     loss.backward()
@@ -309,14 +319,15 @@ def test_point_shard_two_ranks_one_gpu(tmp_path, dec_geo, parallel, world):
     script.write_text(_WORKER)
     out = tmp_path / "out.json"
     env = dict(os.environ, GAOT_ROOT=ROOT, GAOT_OUT=str(out), MASTER_ADDR="127.0.0.1", GAOT_TEST_DEC_GEO="1" if dec_geo else "0",
-               GAOT_TEST_PARALLEL=parallel, GAOT_TEST_HEADS=str(heads))
-    port = 29533 + ["seq", "head", "replicated"].index(parallel) * 2 + int(dec_geo) + 10 * (world - 2)
+               GAOT_TEST_PARALLEL=parallel, GAOT_TEST_HEADS=str(heads), GAOT_TEST_DROPOUT=str(dropout),
+               GAOT_TEST_DROPSEED="20261004" if dropout > 0 else "")
+    port = 29533 + ["seq", "head", "replicated"].index(parallel) * 2 + int(dec_geo) + 10 * (world - 2) + (40 if dropout > 0 else 0)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.load(open(out))
     loss = loss.detach()
-    print(f"[parity] shard2/loss: {got['loss']:.8f} vs {float(loss):.8f}")
+    print(f"[parity] shard{world}_{parallel}_drop{dropout}/loss: {got['loss']:.8f} vs {float(loss):.8f}")
     assert abs(got["loss"] - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-8
     n = 0
     for k, p in model.named_parameters():
@@ -383,14 +394,15 @@ def test_point_shard_other_variants_one_gpu(tmp_path, parallel, head_dim, embed,
     assert n > 20
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,dropout", [(2, 0.0), (4, 0.0), (8, 0.0), (2, 0.1), (4, 0.1), (8, 0.1)])
+def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world, dropout):
     """bf16 mode, d_model 256 (8 heads): the sequence-parallel attention node (sharding.SeqAttnFn) -- projection written as
     the all-to-all's bf16 send buffer by the GEMM epilogue, every exchanged tensor bf16, bucketed gradient all-reduce from
     hooks on a second process group -- against the UNSHARDED bf16 step on the same model and sample.  The roundings are those
     the consuming MFMA kernels apply anyway (delta is formed from the rounded dO: the one numerical difference).
     world = 8 is the benchmark's largest degree: ONE head per rank (a 16 x 8 x 8 latent grid there, so that a rank still owns
-    16 token rows)."""
+    16 token rows).  dropout 0.1: the configuration the N > 1 bench line runs -- same masks as the unsharded step (global head
+    index, one seed word), same bounds."""
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd.data import make_synthetic_sample
@@ -399,16 +411,18 @@ def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world):
     try:
         torch.manual_seed(0)
         latent = (16, 8, 8) if world == 8 else (8, 8, 4)
-        model = init_model(6, 1, "gaot_3d", small_config(False, hidden=256, latent=latent)).to(DEV).train()
+        model = init_model(6, 1, "gaot_3d", small_config(False, hidden=256, latent=latent, dropout=dropout)).to(DEV).train()
         batch, tokens = make_synthetic_sample(3001, latent, k=4, seed=1, device=str(DEV))
+        GF.set_dropout_seed(20261005, DEV)
         loss = GF.mse_loss(model(batch=batch, tokens_pos=tokens.to(DEV)), batch.x)
         loss.backward()
         torch.cuda.synchronize()
     finally:
         gaot_3d_amd.set_precision("fp32")
-    got = _run_shard_workers(tmp_path, world, 29561 + world, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq",
-                             GAOT_TEST_LATENT=",".join(str(v) for v in latent))
-    print(f"[parity] seq_bf16_w{world}/loss: {got['loss']:.8f} vs {float(loss):.8f}")
+    got = _run_shard_workers(tmp_path, world, 29561 + world + (20 if dropout > 0 else 0), GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256,
+                             GAOT_TEST_PARALLEL="seq", GAOT_TEST_LATENT=",".join(str(v) for v in latent), GAOT_TEST_DROPOUT=dropout,
+                             GAOT_TEST_DROPSEED="20261005" if dropout > 0 else "")
+    print(f"[parity] seq_bf16_w{world}_drop{dropout}/loss: {got['loss']:.8f} vs {float(loss):.8f}")
     assert abs(got["loss"] - float(loss)) <= 2e-3 * abs(float(loss))
     n = 0
     for k, p in model.named_parameters():

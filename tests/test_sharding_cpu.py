@@ -272,10 +272,15 @@ def _bucket_worker(rank, world, port, ret):
         ps = [torch.nn.Parameter(torch.randn(n, 7, generator=g)) for n in (3, 50, 11, 200, 5)]
         unused = torch.nn.Parameter(torch.randn(4, 4, generator=g))            # never receives a gradient on ANY rank
         lonely = torch.nn.Parameter(torch.randn(6, 7, generator=g))            # a gradient on rank 1 only (rank 0's shard is empty)
-        gb = GradBuckets(ps + [unused, lonely], dist.new_group(backend="gloo"), bucket_bytes=1000)
-        assert len(gb.buckets) >= 3
+        # backward finishes parameters in reverse order: buckets [p4, p3] | [p2, lonely, p1] | [p0, unused].  Rank 1 completes
+        # bucket 1 from its hooks, rank 0 is one gradient short there and launches it (and bucket 2) in finish(): the order of
+        # the collectives on the group must be the same on both ranks all the same
+        allp = [unused, ps[0], ps[1], lonely, ps[2], ps[3], ps[4]]
+        gb = GradBuckets(allp, dist.new_group(backend="gloo"), bucket_bytes=1000)
+        assert [len(b["params"]) for b in gb.buckets] == [2, 3, 2] and any(q is lonely for q in gb.buckets[1]["params"])
         x = torch.randn(7, generator=torch.Generator().manual_seed(100 + rank))
-        for it in range(2):                                                     # second pass: counters were re-armed
+        launched = []
+        for it in range(3):                                                     # later passes: counters were re-armed
             for p in ps + [unused, lonely]:
                 p.grad = None
             n0 = comm.COUNTS["collectives"]
@@ -284,6 +289,7 @@ def _bucket_worker(rank, world, port, ret):
                 loss = loss + (lonely @ x).sum()
             loss.backward()
             launched_in_backward = comm.COUNTS["collectives"] - n0
+            launched.append(launched_in_backward)
             gb.finish()
         grads_out = [p.grad.clone() for p in ps]
         lonely_out = None if lonely.grad is None else lonely.grad.clone()
@@ -299,7 +305,7 @@ def _bucket_worker(rank, world, port, ret):
         except RuntimeError as e:
             refused = "already launched" in str(e)
         gb.reset()
-        ret[rank] = (grads_out, unused_none, launched_in_backward, lonely_out, refused)
+        ret[rank] = (grads_out, unused_none, launched, lonely_out, refused)
     finally:
         dist.destroy_process_group()
 
@@ -312,7 +318,10 @@ def test_grad_buckets_allreduce_from_hooks():
     xs = [torch.randn(7, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     for r in range(world):
         grads, unused_none, in_bwd, lonely, refused = ret[r]
-        assert unused_none and in_bwd >= 2          # complete buckets were launched while backward was still running
+        # complete buckets were launched while backward was still running, in index order: rank 1 has every gradient of
+        # buckets 0 and 1, rank 0 only of bucket 0; once `unused` is known to be unused everywhere (after the first step) it
+        # no longer holds the last bucket back on rank 1
+        assert unused_none and in_bwd == ([1, 1, 1] if r == 0 else [2, 3, 3]), in_bwd
         # the rank whose shard produced no gradient for `lonely` holds the other rank's gradient afterwards
         assert lonely is not None and torch.allclose(lonely, xs[1][None, :].expand(6, 7), rtol=1e-6, atol=1e-6)
         assert refused
