@@ -66,6 +66,10 @@ def parse_args(argv=None):
                          "(default at N>1: eager launches are timed first, then the SEGMENTED replay -- hipGraph segments "
                          "between eagerly issued collectives, gaot_3d_amd/comm.py -- which captures no collective)")
     ap.add_argument("--no-segmented", action="store_true", help="N>1: eager launches only")
+    ap.add_argument("--no-overlap-dw", action="store_true",
+                    help="N>1: skip the A/B of the weight-gradient side stream (ShardedStep(overlap_dw=True))")
+    ap.add_argument("--overlap-dw-timeout", type=float, default=240.0,
+                    help="N>1: seconds the overlap_dw A/B may take before the already measured line is printed and the ranks leave")
     ap.add_argument("--graph-attempt-timeout", type=float, default=150.0,
                     help="N>1 with --graph: seconds the guarded whole-step capture + replay may take; on a timeout the "
                          "already measured result is printed and the process exits with status 3")
@@ -518,7 +522,7 @@ def main(argv=None):
                 loss = step_ctx.forward_backward(batch, tokens)
             opt.step()
             return loss
-        return model, step, edges
+        return model, step, edges, step_ctx
 
     # The step is a few hundred short kernels; launched eagerly from Python the host can become the bottleneck.  Capture
     # ONE whole step (CSR build, forward, loss, backward, gradient exchange, AdamW) into a hipGraph after the warm-up and
@@ -651,15 +655,20 @@ def main(argv=None):
         torch.cuda.set_stream(torch.cuda.Stream())
     # second process group over the same ranks: the bucketed weight-gradient all-reduce runs on its own RCCL stream
     grad_group = dist.new_group(backend="gloo" if one_device else "nccl") if world > 1 else None
-    model, step, edge_counts = build(n_total, args.atten_dropout, args.parallel)
+    model, step, edge_counts, step_ctx = build(n_total, args.atten_dropout, args.parallel)
     elapsed, graph, loss, t_host_main = measure(step, args.steps, args.warmup, use_graph)
     main_step_ms = list(last_step_ms)
     eager_rec = seg_rec = None
     exchange_profile = {}
-    if world > 1 and not args.no_graph and not args.no_segmented:
-        eager_rec = dict(ms_per_step=elapsed / args.steps * 1e3, value=n_total / (elapsed / args.steps),
-                         host_ms_per_step=round(t_host_main / args.steps * 1e3, 3))
+
+    def sharded_modes(e_eager, loss_eager, th_eager, ms_eager):
+        """N > 1: given the timed EAGER step, add its exchange profile, then record + time + profile the SEGMENTED replay
+        -> (eager record, segmented record, profiles, best = (elapsed, loss, host s, graph or None, per-step ms))"""
         from gaot_3d_amd import comm
+        prof_out = {}
+        e_rec = dict(ms_per_step=e_eager / args.steps * 1e3, value=n_total / (e_eager / args.steps),
+                     host_ms_per_step=round(th_eager / args.steps * 1e3, 3))
+        best = (e_eager, loss_eager, th_eager, None, list(ms_eager))
         # per-rank split of the EAGER step's device time first (no capture involved): exchange steps vs kernels
         try:
             k_prof = max(1, min(args.steps, 3))
@@ -667,9 +676,9 @@ def main(argv=None):
                 for _ in range(k_prof):
                     step()
             torch.cuda.synchronize()
-            exchange_profile["eager"] = prof.summary(k_prof)
+            prof_out["eager"] = prof.summary(k_prof)
         except Exception as ex:
-            exchange_profile["eager"] = dict(error=f"{type(ex).__name__}: {ex}")
+            prof_out["eager"] = dict(error=f"{type(ex).__name__}: {ex}")
         sg = None
         seg_err = None
         try:
@@ -686,20 +695,25 @@ def main(argv=None):
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)
         if okf.item() >= 1.0:
             e_s, loss_s, th_s, tx_s = time_segmented(sg, args.steps, args.warmup)
-            seg_rec = dict(ms_per_step=e_s / args.steps * 1e3, value=n_total / (e_s / args.steps),
-                           host_ms_per_step=round(th_s / args.steps * 1e3, 3),
-                           host_ms_per_step_outside_exchange=round((th_s - tx_s) / args.steps * 1e3, 3),
-                           graph_segments=sg.num_segments, exchanges=sg.num_exchanges,
-                           host_launches_plus_collectives=sg.num_segments + sg.num_exchanges)
+            s_rec = dict(ms_per_step=e_s / args.steps * 1e3, value=n_total / (e_s / args.steps),
+                         host_ms_per_step=round(th_s / args.steps * 1e3, 3),
+                         host_ms_per_step_outside_exchange=round((th_s - tx_s) / args.steps * 1e3, 3),
+                         graph_segments=sg.num_segments, exchanges=sg.num_exchanges,
+                         host_launches_plus_collectives=sg.num_segments + sg.num_exchanges,
+                         side_stream_closures=sum(len(v) for v in sg.side))
             try:
-                exchange_profile["segmented"] = sg.replay_profiled(max(1, min(args.steps, 3)))
+                prof_out["segmented"] = sg.replay_profiled(max(1, min(args.steps, 3)))
             except Exception as ex:
-                exchange_profile["segmented"] = dict(error=f"{type(ex).__name__}: {ex}")
-            if e_s < elapsed:
-                elapsed, loss, t_host_main, graph = e_s, loss_s, th_s, sg
-                main_step_ms = list(last_step_ms)
+                prof_out["segmented"] = dict(error=f"{type(ex).__name__}: {ex}")
+            if e_s < e_eager:
+                best = (e_s, loss_s, th_s, sg, list(last_step_ms))
         else:
-            seg_rec = dict(error=seg_err or "the recording failed on another rank: every rank reports its eager launches")
+            s_rec = dict(error=seg_err or "the recording failed on another rank: every rank reports its eager launches")
+        return e_rec, s_rec, prof_out, best
+
+    if world > 1 and not args.no_graph and not args.no_segmented:
+        eager_rec, seg_rec, exchange_profile, best = sharded_modes(elapsed, loss, t_host_main, main_step_ms)
+        elapsed, loss, t_host_main, graph, main_step_ms = best
 
     secondary = None
     fp32_mode = None
@@ -767,7 +781,7 @@ def main(argv=None):
         other = "weak" if args.scaling == "strong" else "strong"
         try:
             n2 = args.points * world if other == "weak" else args.points
-            model2, step2, _ = build(n2, args.atten_dropout, args.parallel)
+            model2, step2, _, _ = build(n2, args.atten_dropout, args.parallel)
             k2 = max(2, min(args.steps, 5))
             e2, _, _, _ = measure(step2, k2, 1, False)
             weak = dict(scaling=other, points=n2, ms_per_step=e2 / k2 * 1e3, value=n2 / (e2 / k2), steps=k2, launch="eager")
@@ -944,6 +958,55 @@ def main(argv=None):
                 grad_group="second communicator (bucketed weight-gradient all-reduce, asynchronous)")
     if rank == 0 and world > 1:
         out["eager"], out["segmented"] = eager_rec, seg_rec
+    # ---- N > 1: the same step with the weight-gradient GEMMs, bucket copies and bucket all-reduces on a SIDE stream
+    # (ShardedStep(overlap_dw=True): gaot_3d_amd/comm.py side_run), both launch modes again, under a watchdog: a mode that
+    # wedges reports the already measured line and leaves instead of hanging the job
+    if world > 1 and not args.no_graph and not args.no_segmented and not args.no_overlap_dw and step_ctx is not None:
+        import threading
+        ab_done = threading.Event()
+
+        def ab_timeout():
+            if ab_done.is_set():
+                return
+            try:
+                if rank == 0:
+                    out["overlap_dw"] = dict(error=f"no result after {args.overlap_dw_timeout:.0f} s: the default mode is reported")
+                    print(json.dumps(out))
+                    sys.stdout.flush()
+            finally:
+                os._exit(0)
+        timer = threading.Timer(args.overlap_dw_timeout + (0.0 if rank == 0 else 15.0), ab_timeout)
+        timer.daemon = True
+        timer.start()
+        ab = {}
+        try:
+            step_ctx.set_overlap_dw(True)
+            e_o, _, loss_o, th_o = measure(step, args.steps, args.warmup, False)
+            e_rec, s_rec, prof_o, best_o = sharded_modes(e_o, loss_o, th_o, list(last_step_ms))
+            ab = dict(eager=e_rec, segmented=s_rec)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, prof_o)
+            if rank == 0:
+                ab["exchange_profile"] = summarize_exchange_profiles(gathered)
+            if best_o[0] < elapsed:
+                elapsed, loss, t_host_main, graph, main_step_ms = best_o
+                ab["reported_as_value"] = True
+        except Exception as ex:
+            ab["error"] = f"{type(ex).__name__}: {ex}"
+            print(f"[bench] rank {rank}: overlap_dw A/B failed ({ab['error']})", file=sys.stderr)
+        finally:
+            ab_done.set()
+            timer.cancel()
+            step_ctx.set_overlap_dw(False)
+        # all ranks agree on which mode is reported (MAX-reduced times are equal on all ranks, so the choice already is)
+        if rank == 0:
+            if ab.get("reported_as_value"):
+                keep = {kk: out[kk] for kk in ("eager", "segmented", "exchange_profile") if kk in out}
+                launch_txt = ("overlap_dw: " + (f"segmented hipGraph replay: {graph.num_segments} graph launches + {graph.num_exchanges} "
+                                                f"exchange steps + side-stream closures" if graph is not None else "eager"))
+                out = make_out(elapsed, launch_txt, t_host_main, main_step_ms)
+                out.update(keep)
+            out["overlap_dw"] = ab
     attempted = False
     if world > 1 and args.graph and not args.no_graph and not one_device:
         def on_timeout():

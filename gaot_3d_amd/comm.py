@@ -52,6 +52,52 @@ def run(fn: Callable[[], None], keep: Tuple = (), kind: str = "collective") -> N
         rec.boundary(fn, keep, kind)
 
 
+_SIDE: Optional[torch.cuda.Stream] = None      # weight gradients beside the backward chain (ShardedStep(overlap_dw=True))
+
+
+def set_side_stream(stream: Optional[torch.cuda.Stream]) -> None:
+    global _SIDE
+    _SIDE = stream
+
+
+def side_stream() -> Optional[torch.cuda.Stream]:
+    return _SIDE
+
+
+def side_run(fn: Callable[[], None], keep: Tuple = ()) -> None:
+    """run ``fn`` (kernel launches on tensors that already exist: ``keep``) on the side stream, ordered behind everything the
+    step's stream has been given so far; nothing on the step's stream waits for it until ``side_join``.  With no side stream
+    set: a plain call.  Under ``SegmentedGraph.capture`` the closure is NOTED and replayed eagerly on the side stream right
+    after the graph segment it was noted in has been launched -- i.e. BEFORE the exchange step that follows the segment is
+    issued, so the work runs beside that exchange (a kernel captured into the segment itself would sit in front of the
+    exchange in stream order).  ``keep`` stays alive with the recording: a block of the graph pool freed during the capture
+    could be handed to a later allocation of the same capture, which the side work would then overwrite / read."""
+    side = _SIDE
+    if side is None:
+        fn()
+        return
+    rec = _ACTIVE
+    if rec is not None:
+        rec.note_side(fn, keep)
+        return
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    for t in keep:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(side)
+
+
+def side_join() -> None:
+    """the step's stream waits for the side stream (before the optimizer reads the weight gradients).  An exchange-like step
+    of its own under a recording: a captured graph cannot wait for an event of a stream that is not captured."""
+    side = _SIDE
+    if side is None:
+        return
+    run(lambda: torch.cuda.current_stream().wait_stream(side), (), "side_join")
+
+
 class ExchangeProfile:
     """Device time of a step split into "inside exchange steps" and "inside everything else" (graph segments / eager
     kernels), per collective kind, from HIP events recorded on the step's stream around every ``comm.run`` closure.  A
@@ -130,6 +176,10 @@ class SegmentedGraph:
 
     def __init__(self):
         self.segments: List[Tuple[torch.cuda.CUDAGraph, Optional[Callable[[], None]], Tuple]] = []
+        self.side: List[List[Callable[[], None]]] = []     # per segment: closures to run on the side stream behind it
+        self._side_cur: List[Callable[[], None]] = []
+        self._side_keep: List = []                          # operands / results of the side work: alive as long as the recording
+        self.side_stream: Optional[torch.cuda.Stream] = None
         self.kinds: List[Tuple[str, int]] = []          # (kind, bytes) of the exchange that follows segment i
         self.pool = None
         self.stream: Optional[torch.cuda.Stream] = None
@@ -147,7 +197,21 @@ class SegmentedGraph:
         self._cur.capture_end()
         self.segments.append((self._cur, fn, tuple(keep)))
         self.kinds.append((kind, _nbytes(tuple(keep))))
+        self.side.append(self._side_cur)
+        self._side_cur = []
         self._cur = None
+
+    def note_side(self, fn, keep):
+        self.side_stream = _SIDE
+        self._side_cur.append(fn)
+        self._side_keep.extend(t for t in keep if isinstance(t, torch.Tensor))
+
+    def _run_side(self, fns):
+        side = self.side_stream
+        side.wait_stream(self.stream)
+        with torch.cuda.stream(side):
+            for f in fns:
+                f()
 
     def boundary(self, fn, keep, kind="collective"):
         # The closure is only RECORDED here, not run: the recording pass executes no kernel, so no value it would move is
@@ -195,6 +259,7 @@ class SegmentedGraph:
                 self._cur = None
                 self.segments = []
                 self.kinds = []
+                self.side, self._side_cur, self._side_keep = [], [], []
                 self.pool = None
                 self.result = None
                 raise
@@ -211,14 +276,18 @@ class SegmentedGraph:
         whose collectives block the host (gloo on device tensors) that part is device waiting time, not launch cost"""
         with torch.cuda.stream(self.stream):
             if not timed:
-                for g, fn, _ in self.segments:
+                for (g, fn, _), sfn in zip(self.segments, self.side):
                     g.replay()
+                    if sfn:
+                        self._run_side(sfn)
                     if fn is not None:
                         fn()
                 return
             import time
-            for g, fn, _ in self.segments:
+            for (g, fn, _), sfn in zip(self.segments, self.side):
                 g.replay()
+                if sfn:
+                    self._run_side(sfn)
                 if fn is not None:
                     t0 = time.perf_counter()
                     fn()
@@ -231,8 +300,10 @@ class SegmentedGraph:
         with torch.cuda.stream(self.stream):
             prof.begin()
             for _ in range(steps):
-                for (g, fn, _), (kind, nbytes) in zip(self.segments, self.kinds):
+                for (g, fn, _), (kind, nbytes), sfn in zip(self.segments, self.kinds, self.side):
                     g.replay()
+                    if sfn:
+                        self._run_side(sfn)
                     if fn is not None:
                         prof.around(fn, kind, nbytes)
             prof.end()

@@ -79,6 +79,18 @@ def _wb(w: Tensor, precision: Optional[int]) -> Tensor:
     return w
 
 
+def _dw_gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, precision) -> Tensor:
+    """a weight-gradient product dW[m, n] = a^T b over the rows.  Nothing in the backward chain reads it, so with a side stream
+    set (``ShardedStep(overlap_dw=True)`` -> ``comm.set_side_stream``) it is issued there, beside the chain's kernels and the
+    exchange steps, and joined once before the optimizer (``comm.side_join``); otherwise a plain call."""
+    from . import comm
+    if comm.side_stream() is None:
+        return ops.gemm(a, b, m, n, k, lda, ldb, True, False, precision=precision)
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    comm.side_run(lambda: ops.gemm(a, b, m, n, k, lda, ldb, True, False, out=out, ldc=n, precision=precision), (a, b, out))
+    return out
+
+
 class LinearFn(Function):
     """y = act(x W^T + b) [+ residual].  Stands in for nn.Linear (+ F.gelu / ReLU, + the residual add that follows
     it in the Transformer block) and its autograd."""
@@ -130,9 +142,9 @@ class LinearFn(Function):
             dx = ops.gemm(dz, w, m, k, n, n, k, False, False, precision=ctx.precision).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             if n == 1:   # dW[0][:] = sum_m dz[m] x[m][:] -- put the wide dimension on the tile rows instead
-                dw = ops.gemm(x2, dz, k, 1, m, k, 1, True, False, precision=ctx.precision).view(ctx.wshape)
+                dw = _dw_gemm(x2, dz, k, 1, m, k, 1, ctx.precision).view(ctx.wshape)
             else:
-                dw = ops.gemm(dz, x2, n, k, m, n, k, True, False, precision=ctx.precision).view(ctx.wshape)
+                dw = _dw_gemm(dz, x2, n, k, m, n, k, ctx.precision).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dz, m, n, n)
         if ctx.res_shape is not None and ctx.needs_input_grad[5]:
@@ -538,10 +550,10 @@ class FFNFn(Function):
             dyb = ops.cast_bf16(dy2)
             du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,
                           out_dtype=torch.bfloat16)
-            dw2 = ops.gemm(dyb, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
+            dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1).view(w2shape)
         else:
             du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
-            dw2 = ops.gemm(dy2, u, d, f, m, d, f, True, False, precision=1).view(w2shape)
+            dw2 = _dw_gemm(dy2, u, d, f, m, d, f, 1).view(w2shape)
         dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -553,7 +565,7 @@ class FFNFn(Function):
             else:
                 dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,
                               precision=1).view(xshape)
-        dwcat = ops.gemm(dag, x2, 2 * f, d, m, 2 * f, d, True, False, precision=1)
+        dwcat = _dw_gemm(dag, x2, 2 * f, d, m, 2 * f, d, 1)
         dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
         return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None
 
@@ -741,7 +753,7 @@ class MultiLinearFn(Function):
             (wcat,) = ws
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(d, wcat, m, k, ntot, ntot, k, False, False, precision=ctx.precision)
-            dwcat = ops.gemm(d, x2, ntot, k, m, ntot, k, True, False, precision=ctx.precision)
+            dwcat = _dw_gemm(d, x2, ntot, k, m, ntot, k, ctx.precision)
             for shp in ctx.wshapes:
                 n = shp[0]
                 dws.append(dwcat[col:col + n].view(shp))
@@ -752,7 +764,7 @@ class MultiLinearFn(Function):
             blk = d[:, col:]
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(blk, w, m, k, n, ntot, k, False, False, residual=dx, ldr=k, precision=ctx.precision)
-            dws.append(ops.gemm(blk, x2, n, k, m, ntot, k, True, False, precision=ctx.precision).view(ctx.wshapes[i])
+            dws.append(_dw_gemm(blk, x2, n, k, m, ntot, k, ctx.precision).view(ctx.wshapes[i])
                        if ctx.needs_input_grad[3 + i] else None)
             col += n
         return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)

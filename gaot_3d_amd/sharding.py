@@ -434,6 +434,7 @@ class SeqAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
+        from . import functional as GF
         from . import ops
         xb, wcat, img, o, lse, freqs, seed = ctx.saved_tensors
         group, world, rank, h, hkv, r, k, scale, dropout_p, xshape, wshapes = ctx.meta
@@ -458,7 +459,7 @@ class SeqAttnFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dproj, wcat, r, k, ntot, ntot, k, False, False, precision=1).view(xshape)
-        dwcat = ops.gemm(dproj, xb, ntot, k, r, ntot, k, True, False, precision=1)
+        dwcat = GF._dw_gemm(dproj, xb, ntot, k, r, ntot, k, 1)
         dws, col = [], 0
         for shp in wshapes:
             dws.append(dwcat[col:col + shp[0]].view(shp))
@@ -590,12 +591,20 @@ class GradBuckets:
                 copy_dst.append(v)
                 copy_src.append(g)
             p.grad = v
+        # with weight gradients on a side stream (overlap_dw) the copies into the flat buffer and the all-reduce's dependency
+        # follow them there: the bucket leaves when ITS gradients are done, and the step's stream never waits for it
         if copy_dst:
-            torch._foreach_copy_(copy_dst, copy_src)
+            comm.side_run(lambda: torch._foreach_copy_(copy_dst, copy_src), tuple(copy_dst) + tuple(copy_src))
         flat, group = b["flat"], self.group
+        side = comm.side_stream()          # bound now: a replayed closure runs when the module-level setting is long reset
 
         def issue():
-            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            if side is None:
+                b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            else:
+                side.wait_stream(torch.cuda.current_stream())      # gradients the chain itself produced (biases, norms)
+                with torch.cuda.stream(side):
+                    b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         comm.run(issue, (flat,), "grad_bucket_issue")
         b["launched"] = True
         self._next += 1
@@ -662,13 +671,17 @@ class ShardedStep:
     """forward + MSE + backward of the drop-in model on a rank-local shard (see module docstring)."""
 
     def __init__(self, model, group, n_total: int, head_parallel: bool = True, parallel: Optional[str] = None,
-                 grad_group=None, overlap_grads: bool = True):
+                 grad_group=None, overlap_grads: bool = True, overlap_dw: bool = False):
         """``parallel``: how the latent Transformer is divided -- "seq" (token rows per rank, heads per rank inside
         attention), "head" (replicated except the attention heads), "replicated"; default "seq" when heads and token rows
         divide over the ranks, else "head" (``head_parallel=False`` -> "replicated").
         ``grad_group``: a second process group over the same ranks for the bucketed weight-gradient all-reduce (its own RCCL
         stream, so the buckets overlap the exchange steps of the remaining backward); default: ``group``.
-        ``overlap_grads=False``: one flat all-reduce after backward instead of buckets launched from gradient hooks."""
+        ``overlap_grads=False``: one flat all-reduce after backward instead of buckets launched from gradient hooks.
+        ``overlap_dw=True``: the weight-gradient GEMMs (and the bucket copies / all-reduces that follow them) run on a side
+        stream beside the backward chain and its exchange steps, joined once before the step returns (``comm.side_run``);
+        measured SLOWER on one GPU (no idle CUs beside the chain: profiles/r4_u), meant for N > 1 where the chain waits in
+        exchange steps -- ``bench.py --gpus N`` times both settings."""
         self.model = model
         self.group = group
         self.n_total = n_total
@@ -685,6 +698,8 @@ class ShardedStep:
         self.parallel = parallel
         self.partial = partial_grad_parameters(model, parallel)
         self.buckets = GradBuckets(self.partial, grad_group if grad_group is not None else group) if overlap_grads else None
+        self.overlap_dw = bool(overlap_dw)
+        self._side = torch.cuda.Stream() if (self.overlap_dw and torch.cuda.is_available()) else None
         model.encoder._shard_group = group
         model.decoder._shard_group = group
         model._shard_group = group
@@ -694,6 +709,13 @@ class ShardedStep:
             # the outputs / gradients are all-gathered; "seq": all-to-all around the kernels (SeqAttnFn / AttentionFn)
             mod._head_group = group if parallel == "head" else None
             mod._seq_group = group if parallel == "seq" else None
+
+    def set_overlap_dw(self, on: bool) -> None:
+        """switch the weight-gradient side stream between steps (a recorded SegmentedGraph keeps the setting it was
+        recorded with)"""
+        self.overlap_dw = bool(on)
+        if self.overlap_dw and self._side is None:
+            self._side = torch.cuda.Stream()
 
     def release(self):
         """undo the hooks on the model (tests)"""
@@ -714,10 +736,15 @@ class ShardedStep:
         n_local = pred.shape[0]
         # global MSE = sum over ranks of (local sum of squares) / (N_total * out)
         loss = GF.mse_loss(pred, batch.x) * (float(n_local) / float(self.n_total))
-        loss.backward()
-        if self.buckets is not None:
-            self.buckets.finish()
-        else:
+        comm.set_side_stream(self._side if self.overlap_dw else None)
+        try:
+            loss.backward()
+            if self.buckets is not None:
+                self.buckets.finish()
+            comm.side_join()               # every weight gradient is complete on the step's stream from here on
+        finally:
+            comm.set_side_stream(None)
+        if self.buckets is None:
             allreduce_partial_grads(self.partial, self.group)
         total = loss.detach().clone()
         group = self.group

@@ -215,7 +215,8 @@ batch, tokens = make_synthetic_sample(npts, latent, k=k, seed=int(E("GAOT_TEST_S
 tokens = tokens.to(dev)
 local = sharding.shard_batch(batch, rank, world, num_latent=tokens.shape[0])
 del batch
-step = sharding.ShardedStep(model, dist.group.WORLD, npts, parallel=E("GAOT_TEST_PARALLEL") or None, grad_group=grad_group)
+step = sharding.ShardedStep(model, dist.group.WORLD, npts, parallel=E("GAOT_TEST_PARALLEL") or None, grad_group=grad_group,
+                            overlap_dw=E("GAOT_TEST_OVERLAP_DW") == "1")
 assert step.parallel == (E("GAOT_TEST_PARALLEL") or "seq")
 def one():
     gaot_3d_amd.clear_graph_cache(local)
@@ -437,34 +438,41 @@ def test_seq_parallel_bf16_exchange_one_gpu(tmp_path, world, dropout):
     assert n > 20
 
 
-@pytest.mark.parametrize("prec,parallel", [("fp32", "seq"), ("bf16", "seq"), ("fp32", "head")])
-def test_segmented_graph_replay_equals_eager_one_gpu(tmp_path, prec, parallel):
+@pytest.mark.parametrize("prec,parallel,overlap_dw,world", [("fp32", "seq", 0, 2), ("bf16", "seq", 0, 2), ("fp32", "head", 0, 2),
+                                                            # weight gradients + bucket copies / all-reduces on the side stream
+                                                            # (ShardedStep(overlap_dw=True)): eager closures beside the segments
+                                                            ("bf16", "seq", 1, 2), ("fp32", "head", 1, 2), ("bf16", "seq", 1, 4)])
+def test_segmented_graph_replay_equals_eager_one_gpu(tmp_path, prec, parallel, overlap_dw, world):
     """comm.SegmentedGraph: the sharded step recorded as hipGraph segments between eagerly issued exchange steps (boundaries
     inside loss.backward() included: they are crossed on the autograd thread) and replayed twice gives bit-identical
     gradients and loss to the eager step, with a bounded number of host-side launches"""
-    got = _run_shard_workers(tmp_path, 2, 29571 + (prec == "bf16") + 2 * (parallel == "head"), GAOT_TEST_PREC=prec,
-                             GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL=parallel, GAOT_TEST_SEGMENTED=1)
-    print(f"[parity] segmented_{prec}_{parallel}: segments {got['segments']} exchanges {got['exchanges']} "
+    got = _run_shard_workers(tmp_path, world, 29571 + (prec == "bf16") + 2 * (parallel == "head") + 4 * overlap_dw + world,
+                             GAOT_TEST_PREC=prec, GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL=parallel, GAOT_TEST_SEGMENTED=1,
+                             GAOT_TEST_OVERLAP_DW=overlap_dw)
+    print(f"[parity] segmented_{prec}_{parallel}_dw{overlap_dw}_w{world}: segments {got['segments']} exchanges {got['exchanges']} "
           f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
     assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
-    assert got["segments"] == got["exchanges"] + 1 and got["segments"] + got["exchanges"] <= 60    # L = 2
+    assert got["segments"] == got["exchanges"] + 1 and got["segments"] + got["exchanges"] <= 62    # L = 2 (+ the side join)
     # the device-time split bench.py --gpus N reports (comm.ExchangeProfile): every exchange is accounted for under its kind,
     # with its payload, and the two parts add up to the step
     pr, kinds = got["profile"], got["profile_kinds"]
     assert sum(int(round(c)) for c, _ in kinds.values()) == got["exchanges"]
     assert abs(pr["exchange_device_ms"] + pr["compute_device_ms"] - pr["step_device_ms"]) <= 1e-2 and pr["compute_device_ms"] > 0
     want = {"all_reduce", "grad_bucket_issue", "grad_bucket_wait"} | ({"all_to_all"} if parallel == "seq" else {"all_gather"})
+    if overlap_dw:
+        want |= {"side_join"}
     assert want <= set(kinds) and want <= set(got["eager_profile_kinds"]), (sorted(kinds), got["eager_profile_kinds"])
     assert all(b > 0 for k_, (c, b) in kinds.items() if k_ not in ("grad_bucket_wait",))
 
 
-def test_segmented_graph_replay_over_rccl_one_rank(tmp_path):
+@pytest.mark.parametrize("overlap_dw", [0, 1])
+def test_segmented_graph_replay_over_rccl_one_rank(tmp_path, overlap_dw):
     """the same over RCCL ("nccl" backend) on a one-rank group: all_to_all_single / reduce_scatter_tensor / all_gather_into_tensor
     and the asynchronous bucket all-reduces on a second communicator are issued between graph launches on pool-allocated
     buffers; replay equals eager bit for bit (multi-rank RCCL needs a multi-GPU node: the driver's scaling run)"""
-    got = _run_shard_workers(tmp_path, 1, 29579, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq",
-                             GAOT_TEST_SEGMENTED=1, GAOT_TEST_BACKEND="nccl")
-    print(f"[parity] segmented_rccl1: segments {got['segments']} exchanges {got['exchanges']} "
+    got = _run_shard_workers(tmp_path, 1, 29585 + overlap_dw, GAOT_TEST_PREC="bf16", GAOT_TEST_HIDDEN=256, GAOT_TEST_PARALLEL="seq",
+                             GAOT_TEST_SEGMENTED=1, GAOT_TEST_BACKEND="nccl", GAOT_TEST_OVERLAP_DW=overlap_dw)
+    print(f"[parity] segmented_rccl1_dw{overlap_dw}: segments {got['segments']} exchanges {got['exchanges']} "
           f"max|replay - eager| {got['replay_vs_eager_max_abs']:.3e}")
     assert got["replay_vs_eager_max_abs"] == 0.0 and got["replay_loss_minus_eager"] == 0.0
 
