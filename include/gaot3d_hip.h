@@ -277,7 +277,8 @@ int gaot_axpy(const float* a, const float* b, float alpha, float* out, int64_t n
 int gaot_stream_copy(const void* src, void* dst, int64_t bytes, gaot_stream_t stream);
 /* the same copy in a chosen form (measurement only): 0 = grid-stride plain; 1..3 = a contiguous 64-KiB chunk per workgroup,
  * 8 loads in flight per thread, non-temporal loads + stores / plain loads + non-temporal stores / plain; 4..6 = the same with
- * 256-KiB chunks and 4 loads in flight.  gaot_stream_copy runs the fastest form measured on MI355X. */
+ * 256-KiB chunks and 4 loads in flight; 7..9 = non-temporal with 16 / 8 / 4 loads in flight and 128-KiB / 1-MiB / 16-KiB chunks.
+ * gaot_stream_copy runs the fastest form measured on MI355X. */
 int gaot_stream_copy_ex(const void* src, void* dst, int64_t bytes, int variant, gaot_stream_t stream);
 int gaot_patchify(const float* src, float* dst, int B, int D, int H, int W, int P, int C, int to_tokens,
                   gaot_stream_t stream);

@@ -346,7 +346,7 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
         head = torch.tensor(got["grads"][k], dtype=torch.float64)
         hd = float((head - ref.flatten()[:64]).abs().max()) / (float(ref.abs().max()) + 1e-30)
         worst_head = max(worst_head, hd)
-        assert hd <= 3e-2, (k, hd)
+        assert hd <= 1e-2, (k, hd)                                           # achieved 2.4e-3 (profiles/r5_a_parity.txt)
         n += 1
     print(f"[parity] configs2_2rank (dropout 0.1): {n} gradient tensors, worst norm deviation {worst:.2e}, worst leading value {worst_head:.2e} of peak")
     assert n > 100
