@@ -1506,6 +1506,255 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_attn_bwd_asm: the same fused pass with ONE wave per SIMD and a hand-scheduled tile loop.  Workgroup = 4 waves x
+// 4 key blocks = 512 keys (same slabs, same dQ slab partials and reduction, same bit-reproducibility), stages of 128 queries.
+// The stage code (global loads, LDS staging, slot reduction, barriers, epilogue) is the C++ below; the tile loop of a stage -- 16
+// (query tile, key block) units = 160 MFMAs, 1 724 vector instructions -- is ONE generated asm statement
+// (gen_attn_bwd_asm.py -> attn_bwd_asm.inc) that owns v48-v255, s64-s95 and the AGPRs: a0-a127 dK^T / dV^T accumulators,
+// a128-a191 K / V row fragments, a192-a223 K^T fragments.  The AGPRs live ACROSS the asm statements: nothing else in this kernel
+// touches them (no MFMA intrinsic, no spill -- tests/test_host_cpu.py checks the code object for v_accvgpr outside the asm's own).
+// ------------------------------------------------------------------------------------------------
+#include "attn_bwd_asm.inc"
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// four consecutive AGPRs a[BASE .. BASE+3] <- the 16 bytes of v (the register numbers are part of the instruction text)
+template <int BASE>
+__device__ __forceinline__ void agpr_write4(uint4 v) {
+    asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%4+1], %1\n\t"
+                 "v_accvgpr_write_b32 a[%4+2], %2\n\tv_accvgpr_write_b32 a[%4+3], %3"
+                 :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"(BASE) : "memory");
+}
+template <int REG>
+__device__ __forceinline__ float agpr_read() {
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(REG) : "memory");
+    return r;
+}
+struct AsmLds {
+    static constexpr int NT = GAOT_ATTN_BWD_ASM_NT, W = 4, KB = 4, QS = 32 * NT;
+    static constexpr int STAGE = 0;                                  // Q tiles, then dO tiles
+    static constexpr int LSE = STAGE + 2 * NT * TILE_BYTES;          // float[QS]
+    static constexpr int DEL = LSE + QS * 4;                         // float[QS]
+    static constexpr int AW = DEL + QS * 4;                          // uint32[QS + 8] packed row words (two parity copies)
+    static constexpr int DS = (AW + (QS + 8) * 4 + 2047) / 2048 * 2048;   // per wave KB dS tiles (2 KB aligned: xor addressing)
+    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32; the waves' K tiles alias it at start
+    static constexpr int TOTAL = SLOT + NT * W * 4096;
+    static constexpr int KEYS = W * KB * 32;
+};
+static_assert(AsmLds::TOTAL <= 160 * 1024 && AsmLds::SLOT % 128 == 0 && AsmLds::NT * AsmLds::W * 4096 >= AsmLds::W * AsmLds::KB * TILE_BYTES, "LDS layout");
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
+    using L = AsmLds;
+    constexpr int NT = L::NT, KB = L::KB, QS = L::QS, NTHR = 256, WV = L::W;
+    const BwdArgs& a = fa.a;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const float dscale = DROP ? a.drop.keep : 1.f;
+    unsigned long long seed = 0;
+    if constexpr (DROP) seed = *a.drop.seed;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int hkv = blockIdx.x % a.HKV, b = blockIdx.z, slab = blockIdx.x / a.HKV;
+    const int rep = a.H / a.HKV;
+    const int64_t key0 = (int64_t)slab * L::KEYS + wave * (32 * KB);
+    const int64_t rowbase = (int64_t)b * a.S;
+    char* dstile = lds + L::DS + wave * KB * TILE_BYTES;
+    // ---- the wave's K / V rows -> AGPR fragments; K rows once through a wave-private tile for the transposed (K^T) fragments ----
+    asm volatile(GAOT_ATTN_BWD_ASM_ZERO_ACC ::: GAOT_ATTN_BWD_ASM_ACC_CLOBBERS);
+    {
+        char* ktile = lds + L::SLOT + wave * KB * TILE_BYTES;
+        static_for<0, KB>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            const int64_t ki = key0 + 32 * kb + l31;
+            const bf16_t* kp = a.qkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+            const bf16_t* vp = a.qkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+            static_for<0, 2>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                uint4 kq = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+                if (ki < a.S) {
+                    kq = *reinterpret_cast<const uint4*>(kp + 16 * s + 8 * hf);
+                    vq = *reinterpret_cast<const uint4*>(vp + 16 * s + 8 * hf);
+                }
+                *reinterpret_cast<uint4*>(ktile + kb * TILE_BYTES + tile_off(l31, 2 * s + hf)) = kq;
+                agpr_write4<128 + 8 * kb + 4 * s>(kq);
+                agpr_write4<160 + 8 * kb + 4 * s>(vq);
+            });
+        });
+        static_for<0, KB>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            static_for<0, 2>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                agpr_write4<192 + 8 * kb + 4 * s>(__builtin_bit_cast(uint4, frag_cols(ktile + kb * TILE_BYTES, lane, s)));
+            });
+        });
+    }
+    // ---- per-lane LDS addresses of the tile loop (32-bit LDS byte addresses) -------------------------------------------------------
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const int sw = (l31 >> 2) & 3;
+    const unsigned a_const = lbase + L::LSE + 16 * hf;
+    const unsigned a_r0 = lbase + L::STAGE + tile_off(l31, hf), a_r1 = lbase + L::STAGE + tile_off(l31, 2 + hf);
+    unsigned a_c0, a_c1;
+    {
+        const int i = lane & 15, grp = (lane >> 4) & 1, col = 16 * grp + 4 * (i & 3), r0 = 4 * hf + (i >> 2), r1 = r0 + 8;
+        a_c0 = tile_off(r0, col >> 3) + ((col & 7) << 1);
+        a_c1 = tile_off(r1, col >> 3) + ((col & 7) << 1);
+    }
+    const unsigned a_dc0 = lbase + L::DS + wave * KB * TILE_BYTES + a_c0, a_dc1 = lbase + L::DS + wave * KB * TILE_BYTES + a_c1;
+    a_c0 += lbase + L::STAGE;
+    a_c1 += lbase + L::STAGE;
+    const unsigned a_w = lbase + L::AW + ((l31 & 1) * (QS / 2 + 4) + hf * 8) * 4;
+    const unsigned a_ds = lbase + L::DS + wave * KB * TILE_BYTES + l31 * 64 + (sw << 4) + 8 * hf;
+    const unsigned a_slot = lbase + L::SLOT + wave * 4096 + l31 * 128 + ((hf ^ (l31 & 7)) << 4);
+
+    constexpr int NST = 2 * NT * 128 / NTHR;      // staged 16-byte chunks per thread
+    constexpr int NRS = NT * 256 / NTHR;          // slot-reduction items per thread
+    for (int hr = 0; hr < rep; ++hr) {
+        const int head = hkv * rep + hr;
+        const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
+        const bf16_t* dop = a.dob + rowbase * (a.H * D) + head * D;
+        const float* lsep = a.lse + ((int64_t)b * a.H + head) * a.S;
+        const float* delp = a.delta + ((int64_t)b * a.H + head) * a.S;
+        bf16_t* part = fa.dqpart + (((int64_t)b * a.H + head) * fa.nslab + slab) * (int64_t)a.S * D;
+        const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((int64_t)a.S * a.ld * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t do_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dop, 0, (int)((int64_t)a.S * a.H * D * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc((void*)lsep, 0, a.S * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t del_rs = __builtin_amdgcn_make_buffer_rsrc((void*)delp, 0, a.S * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (int)((int64_t)a.S * D * 2), 0x00020000);
+        const int st_tw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
+        int st_voff[NST];
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+            const int row = 32 * (st_t % NT) + st_r;
+            st_voff[it] = (st_t < NT) ? row * (int)a.ld * 2 + 16 * st_c : row * (a.H * D * 2) + 16 * st_c;
+        }
+        auto stage_load = [&](uint4 (&rg)[NST], int64_t q0) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int st_t = st_tw + ((it * NTHR) >> 7);          // wave-uniform
+                if (st_t < NT) rg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, st_voff[it], (int)q0 * (int)a.ld * 2, 0));
+                else rg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(do_rs, st_voff[it], (int)q0 * (a.H * D * 2), 0));
+            }
+        };
+        auto stage_store = [&](const uint4 (&rg)[NST]) {
+#pragma unroll
+            for (int it = 0; it < NST; ++it) {
+                const int idx = threadIdx.x + it * NTHR, st_t = idx >> 7, st_r = (idx & 127) >> 2, st_c = idx & 3;
+                *reinterpret_cast<uint4*>(lds + L::STAGE + st_t * TILE_BYTES + tile_off(st_r, st_c)) = rg[it];
+            }
+        };
+        auto reduce_slots = [&](int64_t q0) {    // sum the 4 waves' dQ^T partials of the stage that started at q0, wave order
+#pragma unroll
+            for (int it = 0; it < NRS; ++it) {
+                const int idx = threadIdx.x + it * NTHR;
+                const int rt = idx >> 8, rq = (idx >> 3) & 31, rc = idx & 7;
+                const char* sp = lds + L::SLOT + rt * WV * 4096 + rq * 128 + ((rc ^ (rq & 7)) << 4);
+                float4 acc = *reinterpret_cast<const float4*>(sp);
+#pragma unroll
+                for (int w = 1; w < WV; ++w) {
+                    const float4 v = *reinterpret_cast<const float4*>(sp + w * 4096);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(u32x2_t, make_uint2((unsigned)f2bf(acc.x) | ((unsigned)f2bf(acc.y) << 16), (unsigned)f2bf(acc.z) | ((unsigned)f2bf(acc.w) << 16))),
+                    part_rs, (32 * rt + rq) * (D * 2) + 8 * rc, (int)q0 * (D * 2), 0);
+            }
+        };
+        uint4 regs[NST];
+        stage_load(regs, 0);
+        float lt = 0.f, et = 0.f;
+        auto load_consts = [&](int64_t qbase) {
+            if (threadIdx.x < QS) {
+                lt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lse_rs, threadIdx.x * 4, (int)qbase * 4, 0));
+                et = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(del_rs, threadIdx.x * 4, (int)qbase * 4, 0));
+            }
+        };
+        load_consts(0);
+        uint32_t rk = 0, bsel[KB] = {0, 0, 0, 0};
+        if constexpr (DROP) {
+            const int bh = a.drop.bh(b, head);
+            rk = gdrop::row_key(seed, bh);
+            const uint32_t ck = gdrop::col_key(seed, bh);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int64_t ki = key0 + 32 * kb + l31;
+                const uint32_t bw = gdrop::col_word(ck, (uint32_t)(ki >> 1));
+                bsel[kb] = (ki & 1) ? (bw >> 16) : (bw & 0xffffu);
+                bsel[kb] |= bsel[kb] << 16;
+            }
+        }
+        const uint32_t thr_v = a.drop.thr;
+        float* lse_w = reinterpret_cast<float*>(lds + L::LSE);
+        float* del_w = reinterpret_cast<float*>(lds + L::DEL);
+        uint32_t* aw_w = reinterpret_cast<uint32_t*>(lds + L::AW);
+        for (int64_t q0 = 0; q0 < a.S; q0 += QS) {
+            __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
+            stage_store(regs);
+            if (threadIdx.x < QS) {
+                const bool in = q0 + threadIdx.x < a.S;
+                lse_w[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;
+                del_w[threadIdx.x] = in ? -et * dscale : 0.f;
+            }
+            if constexpr (DROP) {
+                if (threadIdx.x < QS / 2) {   // packed row words: see k_attn_bwd_fused (PK)
+                    const int u = threadIdx.x, st = u >> 4, sh = (u >> 3) & 1, sg = (u >> 1) & 3, sj = u & 1;
+                    const uint32_t qe = (uint32_t)q0 + 32 * st + 8 * sg + 4 * sh + 2 * sj;
+                    const uint32_t w0 = gdrop::row_word(rk, qe), w1 = gdrop::row_word(rk, qe + 1);
+                    aw_w[u] = (w0 & 0xffffu) | (w1 << 16);
+                    aw_w[QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
+                }
+            }
+            if (q0 > 0) reduce_slots(q0 - QS);
+            __syncthreads();     // B
+            if (q0 + QS < a.S) {
+                stage_load(regs, q0 + QS);
+                load_consts(q0 + QS);
+            }
+            if constexpr (DROP)
+                asm volatile(GAOT_ATTN_BWD_STAGE_ASM_DROP
+                             :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1), [a_w] "v"(a_w),
+                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1), [a_slot] "v"(a_slot), [bsel0] "v"(bsel[0]),
+                                [bsel1] "v"(bsel[1]), [bsel2] "v"(bsel[2]), [bsel3] "v"(bsel[3]), [thr] "s"(thr_v)
+                             : GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS);
+            else
+                asm volatile(GAOT_ATTN_BWD_STAGE_ASM_NODROP
+                             :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1),
+                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1), [a_slot] "v"(a_slot)
+                             : GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS);
+        }
+        __syncthreads();
+        reduce_slots(((a.S - 1) / QS) * (int64_t)QS);
+    }
+    const float vsc = DROP ? a.drop.inv_keep : 1.f;
+    const float ksc = vsc / LOG2E;
+    static_for<0, KB>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        const int64_t ki = key0 + 32 * kb + l31;
+        float dk[16], dv[16];
+        static_for<0, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            dk[r] = agpr_read<16 * kb + r>();
+            dv[r] = agpr_read<64 + 16 * kb + r>();
+        });
+        if (ki < a.S) {
+            float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+            float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t = make_float4(dk[4 * g] * ksc, dk[4 * g + 1] * ksc, dk[4 * g + 2] * ksc, dk[4 * g + 3] * ksc);
+                *reinterpret_cast<float4*>(dkp + 8 * g + 4 * hf) = unrope4(t, a.freqs, (int)ki, g, hf);
+                float4 u = make_float4(dv[4 * g] * vsc, dv[4 * g + 1] * vsc, dv[4 * g + 2] * vsc, dv[4 * g + 3] * vsc);
+                *reinterpret_cast<float4*>(dvp + 8 * g + 4 * hf) = u;
+            }
+        }
+    });
+}
+
 // dq[b, q, head, :] = scale / (1-p) * sum over the key slabs (slab order) of the fused kernel's partials, rotated back
 __global__ void k_attn_dq_reduce(const bf16_t* __restrict__ part, int nslab, int B, int S, int H, int ld, float qsc,
                                  const float* __restrict__ freqs, float* __restrict__ dqkv) {
@@ -1773,7 +2022,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // GAOT_ATTN_BWD_STAMPS=1: the diagnostic instantiation with in-kernel cycle stamps (results unchanged, slower)
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
-            if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
+            if (variant == 2 && nyf == 1)   // one wave per SIMD, hand-scheduled tile loop (k_attn_bwd_asm)
+                rc = drop ? go(k_attn_bwd_asm<true>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds::TOTAL, 256);
+            else if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
             // (128-query stages with bf16 slots -- FB_NT = 4 -- measured 1.07 / 0.81 ms against 0.90 / 0.76: spills in the
             // dropout variant, profiles/r4_g_attn_lab.txt; removed)
