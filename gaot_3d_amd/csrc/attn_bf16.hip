@@ -1549,7 +1549,9 @@ struct AsmLds {
 };
 static_assert(AsmLds::TOTAL <= 160 * 1024 && AsmLds::SLOT % 128 == 0 && AsmLds::NT * AsmLds::W * 4096 >= AsmLds::W * AsmLds::KB * TILE_BYTES, "LDS layout");
 
-template <bool DROP>
+// LAB (measurement only, results invalid): 1 = the stage code without the tile loop, 2 = the tile loop without slot reduction /
+// row-word hashing (barriers and tile staging kept), 3 = no barriers either
+template <bool DROP, int LAB = 0>
 __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
     using L = AsmLds;
     constexpr int NT = L::NT, KB = L::KB, QS = L::QS, NTHR = 256, WV = L::W;
@@ -1693,14 +1695,14 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
         float* del_w = reinterpret_cast<float*>(lds + L::DEL);
         uint32_t* aw_w = reinterpret_cast<uint32_t*>(lds + L::AW);
         for (int64_t q0 = 0; q0 < a.S; q0 += QS) {
-            __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
+            if constexpr (LAB != 3) __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
             stage_store(regs);
             if (threadIdx.x < QS) {
                 const bool in = q0 + threadIdx.x < a.S;
                 lse_w[threadIdx.x] = in ? -lt * LOG2E : -INFINITY;
                 del_w[threadIdx.x] = in ? -et * dscale : 0.f;
             }
-            if constexpr (DROP) {
+            if constexpr (DROP && LAB < 2) {
                 if (threadIdx.x < QS / 2) {   // packed row words: see k_attn_bwd_fused (PK)
                     const int u = threadIdx.x, st = u >> 4, sh = (u >> 3) & 1, sg = (u >> 1) & 3, sj = u & 1;
                     const uint32_t qe = (uint32_t)q0 + 32 * st + 8 * sg + 4 * sh + 2 * sj;
@@ -1709,12 +1711,13 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
                     aw_w[QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
                 }
             }
-            if (q0 > 0) reduce_slots(q0 - QS);
-            __syncthreads();     // B
+            if (q0 > 0 && LAB < 2) reduce_slots(q0 - QS);
+            if constexpr (LAB != 3) __syncthreads();     // B
             if (q0 + QS < a.S) {
                 stage_load(regs, q0 + QS);
                 load_consts(q0 + QS);
             }
+            if constexpr (LAB == 1) continue;
             if constexpr (DROP)
                 asm volatile(GAOT_ATTN_BWD_STAGE_ASM_DROP
                              :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1), [a_w] "v"(a_w),
@@ -2022,8 +2025,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // GAOT_ATTN_BWD_STAMPS=1: the diagnostic instantiation with in-kernel cycle stamps (results unchanged, slower)
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
-            if (variant == 2 && nyf == 1)   // one wave per SIMD, hand-scheduled tile loop (k_attn_bwd_asm)
-                rc = drop ? go(k_attn_bwd_asm<true>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds::TOTAL, 256);
+            if (variant == 2 && nyf == 1) {   // one wave per SIMD, hand-scheduled tile loop (k_attn_bwd_asm)
+                if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds::TOTAL, 256);
+                else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds::TOTAL, 256);
+                else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds::TOTAL, 256);
+                else rc = drop ? go(k_attn_bwd_asm<true>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds::TOTAL, 256);
+            }
             else if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
             // (128-query stages with bf16 slots -- FB_NT = 4 -- measured 1.07 / 0.81 ms against 0.90 / 0.76: spills in the
