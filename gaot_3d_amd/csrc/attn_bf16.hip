@@ -2025,7 +2025,12 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // GAOT_ATTN_BWD_STAMPS=1: the diagnostic instantiation with in-kernel cycle stamps (results unchanged, slower)
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
-            if (variant == 2 && nyf == 1) {   // one wave per SIMD, hand-scheduled tile loop (k_attn_bwd_asm)
+            // k_attn_bwd_asm (one wave per SIMD, hand-scheduled tile loop): measured on MI355X at S = 16 384, H = 8 (profiles/
+            // r5_b / r5_c / r5_d): without dropout 0.684 against 0.725 ms (-6 %) -> the default there; with dropout 0.838-0.856
+            // against 0.843-0.852 ms (a wash: a lone wave issues one vector instruction per 4 cycles, and the dropout unit's ~108
+            // vector + 15 LDS + 10 MFMA instructions are ~700 issue cycles -- the measured 758 per unit ARE that stream) -> the
+            // two-waves-per-SIMD kernel stays.  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
+            if ((variant == 2 || (variant == 0 && !drop && lab == 0 && !want_stamps)) && nyf == 1) {
                 if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds::TOTAL, 256);
                 else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds::TOTAL, 256);
                 else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds::TOTAL, 256);

@@ -21,7 +21,8 @@ Usage: python3 gen_attn_bwd_asm.py > attn_bwd_asm.inc   (the Makefile checks tha
 """
 import sys
 
-NT = 4            # query tiles per stage (128 queries)
+import os
+NT = int(os.environ.get("GEN_NT", "4"))            # query tiles per stage
 W = 4             # waves per workgroup
 KB = 4            # key blocks per wave
 QS = 32 * NT
@@ -183,13 +184,17 @@ def gen_stage(drop: bool):
             st.lds(f"ds_write_b64 {adr}, {vr(DSPK + 2 * c, 2)} offset:{TILE * kb}")
 
     def store_slot(t):
+        off, base = t * W * 4096, "%[a_slot]"
+        if off >= 65536:            # beyond the 16-bit offset field: one add (XR is free outside the compare phase)
+            st.ins(f"v_add_u32 {vr(XR[0])}, 0x10000, %[a_slot]")
+            off, base = off - 65536, vr(XR[0])
         for g in range(4):
             if g == 0:
-                adr = "%[a_slot]"
+                adr = base
             else:
-                st.ins(f"v_xor_b32 {vr(ADR[g & 1])}, {32 * g}, %[a_slot]")
+                st.ins(f"v_xor_b32 {vr(ADR[g & 1])}, {32 * g}, {base}")
                 adr = vr(ADR[g & 1])
-            st.lds(f"ds_write_b128 {adr}, {vr(DQ + 4 * g, 4)} offset:{t * W * 4096}")
+            st.lds(f"ds_write_b128 {adr}, {vr(DQ + 4 * g, 4)} offset:{off}")
 
     # ---- the vector stream of a unit: a list of closures, one per instruction --------------------------------------------------
     def valu_unit(u):

@@ -30,6 +30,39 @@ def test_library_exports_every_declared_symbol():
 
 
 
+def test_attn_bwd_asm_include_is_current_and_owns_its_agprs(tmp_path):
+    """k_attn_bwd_asm keeps dK^T / dV^T accumulators and the K / V fragments in a0-a223 ACROSS its asm statements: the
+    generated include must be what the generator writes, and the compiler-generated part of the kernel must not touch those
+    registers (checked on the device assembly: everything outside the ;;#ASMSTART / ;;#ASMEND blocks)."""
+    import re, subprocess
+    csrc = os.path.join(ROOT, "gaot_3d_amd", "csrc")
+    gen = subprocess.run([sys.executable, os.path.join(csrc, "gen_attn_bwd_asm.py")], capture_output=True, text=True, check=True,
+                         env={k: v for k, v in os.environ.items() if k != "GEN_NT"}).stdout
+    assert gen == open(os.path.join(csrc, "attn_bwd_asm.inc")).read(), "attn_bwd_asm.inc is stale: python3 gen_attn_bwd_asm.py > attn_bwd_asm.inc"
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    asm = tmp_path / "attn.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-ffp-contract=fast", "-S",
+                    "--cuda-device-only", os.path.join(csrc, "attn_bf16.hip"), "-o", str(asm)], check=True, capture_output=True)
+    txt = asm.read_text()
+    kernels = re.findall(r"^(_ZN\S*k_attn_bwd_asm\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", txt, re.S | re.M)
+    assert len(kernels) >= 2, "k_attn_bwd_asm<true> / <false> not found in the device assembly"
+    for name, body in kernels:
+        inside, bad = False, []
+        for ln in body.split("\n"):
+            if "#ASMSTART" in ln:
+                inside = True
+            elif "#ASMEND" in ln:
+                inside = False
+            elif not inside and not ln.strip().startswith(";"):
+                for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", ln):
+                    if int(m.group(1)) < 224:
+                        bad.append(ln.strip())
+        assert not bad, f"{name}: compiler-generated code touches the asm's AGPRs: {bad[:5]}"
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body) or "LAB" in name, f"{name} needs scratch"
+
+
 def test_hot_path_kernels_need_no_scratch(tmp_path):
     """No kernel of the shipped path may need scratch memory (spilled registers / private arrays): the code objects' metadata is
     read from the built library.  Known exceptions are variants off the default path (lab / fallback instantiations)."""
