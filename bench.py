@@ -43,6 +43,9 @@ def parse_args(argv=None):
                          "cfg4: configs[4] shape -- 8M points, 4 output fields, knn k=8.  Graphs are built once, outside the "
                          "timed step (precompute_edges=True as in the reference); their CSR forms inside it")
     ap.add_argument("--points", type=int, default=None, help="default 500000 (cfg4: 8000000)")
+    ap.add_argument("--point-order", choices=["random", "morton"], default="random",
+                    help="storage order of the synthetic points: the draw's (no locality, the worst case for the GNO gathers; "
+                         "default) or along the Z-order curve (data.morton_order: what io.enrich_sample(reorder='morton') stores)")
     ap.add_argument("--latent", type=str, default="64,64,32")
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--knn", type=int, default=8)
@@ -152,14 +155,14 @@ def model_config(latent, layers, k, atten_dropout=0.1, workload="cfg1"):
         latent_tokens=tuple(latent))
 
 
-def make_workload_sample(workload, n_points, latent, k, seed, device):
+def make_workload_sample(workload, n_points, latent, k, seed, device, order="random"):
     """(batch, tokens) of a single-GPU workload: the synthetic surface sample with the workload's graphs as PRECOMPUTED edge
     lists (the reference's precompute_edges=True contract, stat.py:163-214), built once on the device by
     get_neighbor_strategy (csrc/graph.hip)"""
     import torch
     from gaot_3d_amd.data import make_synthetic_sample
     enc_s, dec_s, kk, _, cin, cout, _ = WORKLOADS[workload]
-    batch, tokens = make_synthetic_sample(n_points, latent, k=k, seed=seed, device=device, out_channels=cout)
+    batch, tokens = make_synthetic_sample(n_points, latent, k=k, seed=seed, device=device, out_channels=cout, order=order)
     tokens = tokens.to(device)
     if cin == 5:     # NASA CRM: pos + [Mach, AOA] broadcast per point (metadata.py:60-76)
         batch.c = torch.tensor([[0.85, 2.5]], device=device).expand(n_points, 2).contiguous()
@@ -496,10 +499,10 @@ def main(argv=None):
             from gaot_3d_amd import sharding
             # every rank generates only ITS point range on the device (host RNG draws are the whole sample's: 7 floats/point)
             batch, tokens = make_synthetic_shard(n_total, latent, rank, world, k=args.knn, seed=args.seed, device=str(dev),
-                                                 out_channels=wl_out)
+                                                 out_channels=wl_out, order=args.point_order)
             step_ctx = sharding.ShardedStep(model, dist.group.WORLD, n_total, parallel=parallel, grad_group=grad_group)
         else:
-            batch, tokens = make_workload_sample(args.workload, n_total, latent, args.knn, args.seed, str(dev))
+            batch, tokens = make_workload_sample(args.workload, n_total, latent, args.knn, args.seed, str(dev), args.point_order)
             step_ctx = None
         tokens = tokens.to(dev)
         # edges of THIS rank's graphs (variable for the radius / bidirectional workloads)
@@ -916,6 +919,7 @@ def main(argv=None):
                        "points": n_total, "latent_tokens": list(latent), "edges": e_enc if world == 1 else n_total * args.knn,
                        "edges_decoder": e_dec if world == 1 else n_total * args.knn, "layers": args.layers,
                        "precision": args.precision, "points_per_gpu": n_total // world, "atten_dropout": args.atten_dropout,
+                       "point_order": args.point_order,
                        "sharding": shard_txt},
             "loss": float(loss.detach()),
             "launch": launch_txt,

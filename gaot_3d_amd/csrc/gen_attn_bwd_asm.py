@@ -82,6 +82,7 @@ class Stream:
         self.rec.append(("lds", text, tag, tuple(needs)))
 
     def render(self):
+        lab = os.environ.get("GEN_LAB", "")      # measurement builds (results invalid): nowait = no s_waitcnt, nolds = no LDS at all
         out = []
         issued = 0            # LDS operations issued so far
         pos = {}              # tag -> index (1-based count) of the LDS operation that produces it
@@ -95,13 +96,15 @@ class Stream:
                 need_idx = max(need_idx, pos[t])
             if need_idx > waited:
                 n = issued - need_idx
-                if n < 15:     # with 15 or more younger operations outstanding the counter cannot express it: it has returned
+                if n < 15 and not lab:     # with 15 or more younger operations outstanding the counter cannot express it: it has returned
                     out.append(f"s_waitcnt lgkmcnt({n})")
                 waited = need_idx
             if r[0] == "lds":
                 issued += 1
                 if r[2] is not None:
                     pos[r[2]] = issued
+                if lab == "nolds":
+                    continue
             out.append(r[1])
         return out
 

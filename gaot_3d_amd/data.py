@@ -178,7 +178,22 @@ def rescale(x: Tensor, lims=(-1.0, 1.0)) -> Tensor:
     return (x - x.min()) / (x.max() - x.min()) * (lims[1] - lims[0]) + lims[0]
 
 
-def _synthetic_fields(n_points: int, out_channels: int, seed: int, surface: bool):
+def morton_order(pos: Tensor, bits: int = 10) -> Tensor:
+    """permutation that sorts points along the Z-order (Morton) curve of their bounding box, `bits` bits per axis (stable:
+    points of one cell keep their order).  A per-sample constant like the neighbour lists: points that are close in space end
+    up close in memory, so the coordinate / feature rows the GNO kernels gather for one token share cache lines (no reference
+    counterpart: the reference gathers through torch indexing in whatever order the mesh file has)."""
+    p = pos.detach().to(torch.float64)
+    lo, hi = p.min(dim=0).values, p.max(dim=0).values
+    q = ((p - lo) / (hi - lo).clamp(min=1e-30) * ((1 << bits) - 1)).round().clamp(0, (1 << bits) - 1).to(torch.int64)
+    code = torch.zeros(p.shape[0], dtype=torch.int64, device=pos.device)
+    for b in range(bits):
+        for a in range(p.shape[1]):
+            code |= ((q[:, a] >> b) & 1) << (b * p.shape[1] + a)
+    return torch.sort(code, stable=True).indices
+
+
+def _synthetic_fields(n_points: int, out_channels: int, seed: int, surface: bool, order: str = "random"):
     g = torch.Generator().manual_seed(seed)
     if surface:
         pos, nrm = superellipsoid_surface(n_points, generator=g)
@@ -188,17 +203,22 @@ def _synthetic_fields(n_points: int, out_channels: int, seed: int, surface: bool
         nrm = torch.randn(n_points, 3, generator=g)
         nrm = nrm / nrm.norm(dim=1, keepdim=True)
     x = torch.randn(n_points, out_channels, generator=g)
+    if order == "morton":      # the same point set, stored along the Z-order curve (what a mesh file's locality looks like)
+        perm = morton_order(pos)
+        pos, nrm, x = pos[perm].contiguous(), nrm[perm].contiguous(), x[perm].contiguous()
+    elif order != "random":
+        raise ValueError(f"order must be 'random' or 'morton', got {order}")
     return pos, nrm, x
 
 
 def make_synthetic_shard(n_points: int, latent_tokens: Sequence[int], rank: int, world: int, k: int = 8,
                          in_normals: bool = True, out_channels: int = 1, seed: int = 0, surface: bool = True,
-                         device: str = "cpu") -> Tuple[MeshBatch, Tensor]:
+                         device: str = "cpu", order: str = "random") -> Tuple[MeshBatch, Tensor]:
     """Rank ``rank``'s share of ``make_synthetic_sample(n_points, ...)`` -- identical values to
     ``sharding.shard_batch`` of the whole sample -- without ever holding the whole sample on the device: the host
     draws the per-point fields (7 floats a point; the global rescale needs all of them), the rank's contiguous point
     range goes to the device and only ITS edges are built there."""
-    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface)
+    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface, order)
     lo, hi = (n_points * rank) // world, (n_points * (rank + 1)) // world
     pos_d = pos[lo:hi].contiguous().to(device)
     enc = knn_edges_grid(pos_d, latent_tokens, (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), k)
@@ -214,11 +234,12 @@ def make_synthetic_shard(n_points: int, latent_tokens: Sequence[int], rank: int,
 
 def make_synthetic_sample(n_points: int, latent_tokens: Sequence[int], k: int = 8, in_normals: bool = True,
                           out_channels: int = 1, seed: int = 0, surface: bool = True,
-                          device: str = "cpu") -> Tuple[MeshBatch, Tensor]:
+                          device: str = "cpu", order: str = "random") -> Tuple[MeshBatch, Tensor]:
     """Seeded synthetic sample of the BASELINE shapes: points on a car-like surface
     (or uniform in the cube), rescaled to [-1,1]; ``c`` = unit normals; knn(k) encoder edges
-    (phys-major) and the flipped list as decoder edges; N(0,1) target.  Returns (batch, tokens_pos)."""
-    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface)
+    (phys-major) and the flipped list as decoder edges; N(0,1) target.  Returns (batch, tokens_pos).
+    ``order``: "random" (the draw's order: no locality at all, the worst case for the gathers) or "morton"."""
+    pos, nrm, x = _synthetic_fields(n_points, out_channels, seed, surface, order)
     pos_d = pos.to(device)
     enc = knn_edges_grid(pos_d, latent_tokens, (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), k)
     b = MeshBatch(pos=pos_d, x=x.to(device), batch=torch.zeros(n_points, dtype=torch.long, device=device),

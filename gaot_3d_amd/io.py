@@ -132,14 +132,28 @@ def save_sample(sample: MeshBatch, path: str) -> None:
 
 
 def enrich_sample(sample: MeshBatch, latent_tokens_pos: Tensor, gno_config, latent_dims=None, device=None,
-                  rescale_pos: bool = True) -> MeshBatch:
+                  rescale_pos: bool = True, reorder: Optional[str] = None) -> MeshBatch:
     """the trainer's pre-computation pass (stat.py:163-214): rescale the coordinates to [-1, 1], build the encoder /
     decoder edge lists of every scale with ``get_neighbor_strategy`` -- on ``device`` through the graph kernels when the
     tokens are a regular grid (``latent_dims``) -- and store them as int32 together with the per-query counts and
-    ``num_latent_nodes``.  Returns a new sample on the CPU (what the reference writes back to the .pt file)."""
+    ``num_latent_nodes``.  Returns a new sample on the CPU (what the reference writes back to the .pt file).
+    ``reorder="morton"`` (extension): the points -- ``pos`` and every per-point attribute -- are stored along the Z-order curve
+    before the edges are built (``data.morton_order``); ``point_perm`` keeps the permutation (row i of the enriched sample is row
+    ``point_perm[i]`` of the file), so predictions can be put back in file order with ``pred[torch.argsort(point_perm)]``."""
+    from .data import morton_order
     from .model.layers.magno import get_neighbor_strategy, parse_neighbor_strategy
     dev = torch.device(device) if device is not None else sample.pos.device
     out = MeshBatch(**{k: v for k, v in sample.__dict__.items() if not k.startswith("_")})
+    if reorder == "morton":
+        perm = morton_order(sample.pos).cpu()
+        n0 = sample.pos.shape[0]
+        for k, v in list(out.__dict__.items()):
+            if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n0 and not k.startswith(("encoder_", "decoder_")):
+                setattr(out, k, v[perm.to(v.device)].contiguous())
+        out.point_perm = perm
+        sample = out
+    elif reorder is not None:
+        raise ValueError(f"reorder must be None or 'morton', got {reorder}")
     pos = sample.pos.to(torch.float32)
     pos = rescale(pos, (-1, 1)) if rescale_pos else pos
     lat = latent_tokens_pos.to(dev, torch.float32)

@@ -62,6 +62,45 @@ def test_enrich_sample_variable_degree_matches_host(strategy):
             assert torch.equal(cnt, torch.bincount(want[1], minlength=nq).to(torch.int32))
 
 
+def test_enrich_sample_morton_reorder_is_a_pure_permutation():
+    """io.enrich_sample(reorder="morton") stores the points along the Z-order curve (gather locality for the GNO kernels): every
+    per-point attribute moves with its point, the edge set is the same up to the renumbering, and the model's prediction put
+    back in file order equals the prediction on the file-order sample (fp32 mode: only summation orders inside the segments
+    change)"""
+    import gaot_3d_amd
+    import test_model_gpu as TM
+    from gaot_3d_amd import io
+    from gaot_3d_amd.data import MeshBatch, latent_grid, superellipsoid_surface
+    from gaot_3d_amd.model import init_model
+    n, dims = 20_000, (8, 8, 4)
+    g = torch.Generator().manual_seed(9)
+    pos, nrm = superellipsoid_surface(n, generator=g)
+    raw = MeshBatch(pos=pos, x=torch.randn(n, 1, generator=g), c=nrm)
+    cfg = TM.small_config(False, 2, latent=dims, k=4)
+    lat = latent_grid(dims)
+    a = io.enrich_sample(raw, lat, cfg.magno, latent_dims=dims, device=DEV)
+    b = io.enrich_sample(raw, lat, cfg.magno, latent_dims=dims, device=DEV, reorder="morton")
+    perm = b.point_perm
+    assert sorted(perm.tolist()) == list(range(n))
+    assert torch.equal(b.x, raw.x[perm]) and torch.equal(b.c, raw.c[perm]) and torch.equal(b.pos, a.pos[perm])
+    inv = torch.argsort(perm)
+    ea, eb = a.encoder_edge_index_s0.long(), b.encoder_edge_index_s0.long()
+    assert _pairs(torch.stack([perm[eb[0]], eb[1]])) == _pairs(ea)              # same graph, points renumbered
+    d = ((b.pos[1:] - b.pos[:-1]).norm(dim=1).mean() / (a.pos[1:] - a.pos[:-1]).norm(dim=1).mean()).item()
+    assert d < 0.2, d                                                            # consecutive points are neighbours in space now
+    gaot_3d_amd.set_precision("fp32")
+    torch.manual_seed(0)
+    model = init_model(6, 1, "gaot_3d", cfg).to(DEV).eval()
+    preds = []
+    for smp in (a, b):
+        batch = MeshBatch.from_data_list([smp], num_latent_nodes=lat.shape[0]).to(DEV)
+        with torch.no_grad():
+            preds.append(model(batch=batch, tokens_pos=lat.to(DEV)).cpu())
+    err = float((preds[1][inv] - preds[0]).abs().max()) / float(preds[0].abs().max())
+    print(f"[parity] morton reorder: max|pred(reordered)[inv] - pred| = {err:.2e} of peak")
+    assert err <= 1e-5
+
+
 def test_loader_stages_through_pinned_memory_and_keeps_batches_on_the_device(tmp_path):
     import gaot_3d_amd
     from gaot_3d_amd import dataset as D
