@@ -172,6 +172,67 @@ __global__ __launch_bounds__(256) void k_knn_brute(const float* __restrict__ pos
             if (j < kout) out[i * kout + j] = bi[j];      // K = capacity >= kout (see k_knn_grid)
 }
 
+// k > 64 (torch_cluster takes any k, magno.py:183-189): selection in passes of 64.  Pass `start` picks the 64 nearest tokens whose
+// key (distance, index) lies strictly BEHIND the key of entry start-1 -- the last one the previous pass wrote -- so the passes
+// together produce the same (distance, index)-ordered list one big register list would.  The distance is formed without
+// contraction (__fmul_rn / __fadd_rn), so the floor's key recomputed here equals the key it was selected with, whatever the
+// compiler does around it.
+__device__ __forceinline__ float dist2_rn(const float* __restrict__ tok, int64_t lin, float px, float py, float pz) {
+    const float dx = __fsub_rn(tok[3 * lin], px), dy = __fsub_rn(tok[3 * lin + 1], py), dz = __fsub_rn(tok[3 * lin + 2], pz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+__global__ __launch_bounds__(256) void k_knn_brute_pass(const float* __restrict__ pos, int64_t N, const float* __restrict__ tok,
+                                                        int64_t M, int* __restrict__ out, int kout, int start) {
+    constexpr int K = 64;
+    __shared__ float ts[BRUTE_TILE * 3];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    const float px = live ? pos[3 * i] : 0.f, py = live ? pos[3 * i + 1] : 0.f, pz = live ? pos[3 * i + 2] : 0.f;
+    float fd = -1.f;          // floor key: nothing selected yet
+    int fi = -1;
+    if (live && start > 0) {
+        fi = out[i * kout + start - 1];
+        fd = dist2_rn(tok, fi, px, py, pz);
+    }
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bd[j] = FLT_MAX; bi[j] = 0x7fffffff; }
+    for (int64_t t0 = 0; t0 < M; t0 += BRUTE_TILE) {
+        const int nt = (int)min((int64_t)BRUTE_TILE, M - t0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nt * 3; j += 256) ts[j] = tok[t0 * 3 + j];
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const float d = dist2_rn(ts, j, px, py, pz);
+            const int lin = (int)(t0 + j);
+            const bool behind = d > fd || (d == fd && lin > fi);
+            if (behind && (d < bd[K - 1] || (d == bd[K - 1] && lin < bi[K - 1]))) {
+                bd[K - 1] = d;
+                bi[K - 1] = lin;
+#pragma unroll
+                for (int q = K - 1; q > 0; --q) {
+                    const bool lt = bd[q] < bd[q - 1] || (bd[q] == bd[q - 1] && bi[q] < bi[q - 1]);
+                    if (lt) {
+                        const float td = bd[q]; bd[q] = bd[q - 1]; bd[q - 1] = td;
+                        const int ti = bi[q]; bi[q] = bi[q - 1]; bi[q - 1] = ti;
+                    }
+                }
+            }
+        }
+    }
+    if (live)
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (start + j < kout) out[i * kout + start + j] = bi[j];
+}
+static void knn_many(const float* pos, int64_t num_points, const float* token_pos, int64_t num_tokens, int k, int32_t* out_idx,
+                     hipStream_t st) {
+    const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
+    for (int start = 0; start < k; start += 64)
+        GAOT_KLAUNCH(k_knn_brute_pass, grd, blk, 0, st, pos, num_points, token_pos, num_tokens, out_idx, k, start);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_radius_brute(const float* __restrict__ pos, int64_t N, const float* __restrict__ tok,
                                                       int64_t M, float radius, int cap, int* __restrict__ counts,
@@ -289,10 +350,15 @@ extern "C" int gaot_knn_grid(const float* pos, int64_t num_points, const gaot_gr
     GAOT_CHECK_ARG(make_grid(grid, g) == 0, "bad grid descriptor");
     GAOT_CHECK_ARG(num_points >= 0, "negative size");
     const int64_t m = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
-    GAOT_CHECK_ARG(k >= 1 && k <= 64 && k <= m, "k must be in [1, min(64, number of tokens)]");
+    GAOT_CHECK_ARG(k >= 1 && k <= m, "k must be in [1, number of tokens]");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (k > 64) {     // beyond the register list: passes of 64 over all tokens (k_knn_brute_pass)
+        knn_many(pos, num_points, token_pos, m, k, out_idx, st);
+        GAOT_LAUNCH_CHECK();
+        return GAOT_OK;
+    }
     const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
 #define GAOT_KNN(KK) GAOT_KLAUNCH((k_knn_grid<KK>), grd, blk, 0, st, pos, num_points, g, token_pos, out_idx, k)
     switch (k <= 8 ? k : k <= 12 ? 12 : k <= 16 ? 16 : k <= 24 ? 24 : k <= 32 ? 32 : k <= 48 ? 48 : 64) {
@@ -320,10 +386,15 @@ extern "C" int gaot_knn_brute(const float* pos, int64_t num_points, const float*
                               int32_t* out_idx, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(num_points >= 0 && num_tokens >= 1, "bad size");
-    GAOT_CHECK_ARG(k >= 1 && k <= 64 && k <= num_tokens, "k must be in [1, min(64, number of tokens)]");
+    GAOT_CHECK_ARG(k >= 1 && k <= num_tokens, "k must be in [1, number of tokens]");
     if (num_points == 0) return GAOT_OK;
     GAOT_CHECK_ARG(pos && token_pos && out_idx, "null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (k > 64) {
+        knn_many(pos, num_points, token_pos, num_tokens, k, out_idx, st);
+        GAOT_LAUNCH_CHECK();
+        return GAOT_OK;
+    }
     const dim3 grd((unsigned)ceil_div(num_points, 256)), blk(256);
 #define GAOT_KNNB(KK) GAOT_KLAUNCH((k_knn_brute<KK>), grd, blk, 0, st, pos, num_points, token_pos, num_tokens, out_idx, k)
     switch (k <= 8 ? k : k <= 12 ? 12 : k <= 16 ? 16 : k <= 24 ? 24 : k <= 32 ? 32 : k <= 48 ? 48 : 64) {

@@ -99,7 +99,11 @@ class IntegralTransform(nn.Module):
         dims = [(fc.weight.shape[0], fc.weight.shape[1]) for fc in fcs]
         cd = y_pos.shape[1]
         c = dims[-1][0]
-        ok = (cd in (1, 2, 3) and dims[0] == (64, 2 * cd) and dims[-1][1] == 64 and all(d == (64, 64) for d in dims[1:-1])
+        # hidden widths: the kernels are written for 64; any width <= 64 (the lists in_/out_gno_channel_mlp_hidden_layers are free,
+        # magno.py:32,36) is zero-padded to it -- gelu(0) = 0 and the padded rows / columns of the neighbouring weights are 0,
+        # so every added product is exactly 0 (a width of 32 then costs what 64 costs; wider layers take the general path)
+        chain = all(dims[i][1] == dims[i - 1][0] for i in range(1, len(dims)))
+        ok = (cd in (1, 2, 3) and dims[0][1] == 2 * cd and chain and all(1 <= d[0] <= 64 for d in dims[:-1])
               and 1 <= c <= 256 and f_y.shape[1] == c and all(fc.bias is not None for fc in fcs))
         return (cd, c) if ok else None
 
@@ -111,7 +115,8 @@ class IntegralTransform(nn.Module):
 
     def _forward_fused(self, fcs, y_pos, x_pos, f_y, graph, cd: int, c: int):
         w2 = lambda fc: fc.weight[:, :, 0] if fc.weight.dim() == 3 else fc.weight    # Conv1d(k=1) storage of mlp_type='channel'
-        if cd == 3 and c == 32:                                                       # the shipped shape: straight through
+        pad_hidden = any(fc.weight.shape[0] != 64 for fc in fcs[:-1])
+        if cd == 3 and c == 32 and not pad_hidden:                                    # the shipped shape: straight through
             params = []
             for fc in fcs:
                 params += [fc.weight, fc.bias]
@@ -122,12 +127,17 @@ class IntegralTransform(nn.Module):
             x3 = torch.nn.functional.pad(x_pos, (0, 3 - cd))
             # [src coords | 0.. | query coords | 0..] by concatenation: no index tensor built on the host (a pageable
             # host-to-device copy per forward is a synchronisation and is illegal inside a hipGraph capture)
-            z = w0.new_zeros(64, 3 - cd)
+            z = w0.new_zeros(w0.shape[0], 3 - cd)
             w0 = torch.cat([w0[:, :cd], z, w0[:, cd:2 * cd], z], dim=1)
+        pad2 = lambda w, rows, cols: w if (w.shape[0] == rows and w.shape[1] == cols) else torch.nn.functional.pad(
+            w, (0, cols - w.shape[1], 0, rows - w.shape[0]))
+        pad1 = lambda v, n: v if v.shape[0] == n else torch.nn.functional.pad(v, (0, n - v.shape[0]))
+        w0, b0 = pad2(w0, 64, 6), pad1(fcs[0].bias, 64)
         mid = []
         for fc in fcs[1:-1]:
-            mid += [w2(fc), fc.bias]
+            mid += [pad2(w2(fc), 64, 64), pad1(fc.bias, 64)]
         wl, bl = w2(fcs[-1]), fcs[-1].bias
+        wl = pad2(wl, wl.shape[0], 64)
         outs = []
         for c0 in range(0, c, 32):
             n = min(32, c - c0)
@@ -136,7 +146,7 @@ class IntegralTransform(nn.Module):
                 wb = torch.nn.functional.pad(wb, (0, 0, 0, 32 - n))
                 bb = torch.nn.functional.pad(bb, (0, 32 - n))
                 fb = torch.nn.functional.pad(fb, (0, 32 - n))
-            o = GF.GnoFn.apply(fb.contiguous(), y3, x3, graph, w0, fcs[0].bias, *mid, wb.contiguous(), bb.contiguous())
+            o = GF.GnoFn.apply(fb.contiguous(), y3, x3, graph, w0, b0, *mid, wb.contiguous(), bb.contiguous())
             outs.append(o[:, :n] if n < 32 else o)
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 

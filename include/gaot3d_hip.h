@@ -318,7 +318,8 @@ int gaot_adamw_step(const gaot_adamw_tensor_t* tensors, int num_tensors, const f
  * D x H x W grid (gaot_3d.py:35-46, stat.py:238-252): gaot_grid_t bounds the search window,
  * token_pos [D*H*W, 3] supplies the coordinates the distances are measured to.
  *   gaot_knn_grid          pyg_knn(x=latent, y=phys, k): out_idx[i*k + j] = j-th nearest token of
- *                          point i, ordered by (distance, token index); k in {1..8, 12, 16, 32}
+ *                          point i, ordered by (distance, token index); any 1 <= k <= number of tokens (torch_cluster
+ *                          takes any k, magno.py:183-189): register lists up to 64, passes of 64 over all tokens beyond
  *   gaot_radius_grid_*     pyg_radius(x=latent, y=phys, r, max_num_neighbors=cap): tokens with d <= r
  *                          of every point, ascending token index, at most cap; count pass, exclusive
  *                          scan (gaot_exclusive_scan_i32 -> offsets[n+1]), fill pass

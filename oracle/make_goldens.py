@@ -389,6 +389,43 @@ def gno_shapes_case():
     save("gno_shapes", dict(name="gno_shapes", variants=variants), arrays)
 
 
+def gno_hidden_case():
+    """IntegralTransform with kernel-MLP hidden widths other than 64: `in_gno_channel_mlp_hidden_layers` /
+    `out_gno_channel_mlp_hidden_layers` are free lists (magno.py:32,36).  Widths <= 64 run the fused kernels through exact zero
+    padding, 128 the general per-edge path; same graph family as gno_shapes"""
+    from src.model.layers.integral_transform import IntegralTransform
+
+    gen = torch.Generator().manual_seed(31)
+    torch.manual_seed(31)
+    lat3 = latent_grid((4, 4, 3))
+    pos3 = torch.rand(220, 3, generator=gen) * 2 - 1
+    pos3, enc = variable_degree_graph(pos3, lat3, 0.45, heavy_token=9, n_heavy=39, gen=gen)
+    arrays = {"in/pos3": pos3, "in/lat3": lat3, "in/edge_index": enc.to(torch.int32)}
+    variants = []
+    for tag, cd, layers in (("h32_cd3", 3, [6, 32, 32, 32]), ("h48_64_16_cd2", 2, [4, 48, 64, 16, 16]),
+                            ("h8_cd3_c40", 3, [6, 8, 40]), ("h128_cd3", 3, [6, 128, 32])):
+        it = IntegralTransform(channel_mlp_layers=layers, transform_type="linear", coord_dim=cd)
+        with torch.no_grad():
+            for p in it.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        y, x = pos3[:, :cd].contiguous(), lat3[:, :cd].contiguous()
+        f = torch.randn(pos3.shape[0], layers[-1], generator=gen).requires_grad_(True)
+        out = it(y_pos=y, x_pos=x, edge_index=enc, f_y=f)
+        w = torch.randn(out.shape, generator=gen)
+        (out * w).sum().backward()
+        arrays[f"in/{tag}/f_y"] = f.detach()
+        arrays[f"in/{tag}/w"] = w
+        arrays[f"out/{tag}/out"] = out
+        arrays[f"grad/{tag}/f_y"] = f.grad
+        for k, v in it.state_dict().items():
+            arrays[f"sd/{tag}/{k}"] = v
+        for k, g in grads_of(it).items():
+            arrays[f"grad/{tag}/{k}"] = g
+        variants.append(dict(tag=tag, coord_dim=cd, layers=layers))
+    save("gno_hidden", dict(name="gno_hidden", variants=variants), arrays)
+
+
 def gno_variants_case():
     """IntegralTransform variants the reference's config surface reaches beyond the shipped yaml: segment-softmax attention
     weights on coordinates of dimension 2 / 1 (`gno_coord_dim: 2` is the reference's default, magno.py:28; scores slice
@@ -458,6 +495,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lr_mix":
         lr_schedule_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "gno_hidden":
+        gno_hidden_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gno_shapes":
         gno_shapes_case()
         return
@@ -466,6 +506,7 @@ def main():
         return
     ops_case()
     gno_shapes_case()
+    gno_hidden_case()
     gno_variants_case()
     attn_dropout_case()
     lr_schedule_case()

@@ -364,6 +364,50 @@ def test_integral_transform_other_shapes_golden(precision):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_integral_transform_hidden_widths_golden(precision):
+    """kernel-MLP hidden widths other than 64 (`in_/out_gno_channel_mlp_hidden_layers` are free lists, magno.py:32,36) against
+    goldens captured from the reference's IntegralTransform (tests/golden/gno_hidden.npz): widths <= 64 -- 32 / 32, 48 / 64 / 16,
+    a single layer of 8 -- run the FUSED kernels through exact zero padding to 64 (gelu(0) = 0, zero rows / columns in the
+    neighbouring weights), 128 takes the general per-edge path"""
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers.integral_transform import IntegralTransform
+    meta, g = gio.load("gno_hidden")
+    ei = g["in"]["edge_index"].to(DEV)
+    gaot_3d_amd.set_precision(precision)
+    try:
+        for v in meta["variants"]:
+            tag, cd, layers = v["tag"], v["coord_dim"], v["layers"]
+            it = IntegralTransform(channel_mlp_layers=layers, transform_type="linear", coord_dim=cd)
+            it.load_state_dict(gio.sub(g["sd"], tag), strict=True)
+            it = it.to(DEV).train()
+            y, x = g["in"]["pos3"][:, :cd].contiguous().to(DEV), g["in"]["lat3"][:, :cd].contiguous().to(DEV)
+            f = g["in"][f"{tag}/f_y"].to(DEV).requires_grad_(True)
+            plan = it._fused_plan(list(it.channel_mlp.fcs), f, y)
+            assert (plan is None) == (max(layers[1:-1]) > 64), (tag, plan)
+            out = it(y_pos=y, x_pos=x, edge_index=ei, f_y=f)
+            (out * g["in"][f"{tag}/w"].to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            ref = g["out"][f"{tag}/out"]
+            if precision == "fp32":
+                close(f"gno_hidden/{tag}/out", out, ref, 1e-4, 1e-5)
+                close(f"gno_hidden/{tag}/grad_f", f.grad, g["grad"][f"{tag}/f_y"], 1e-3, 1e-5)
+                for k, p in it.named_parameters():
+                    close(f"gno_hidden/{tag}/grad_{k}", p.grad, g["grad"][f"{tag}/{k}"], 1e-3, 2e-5)
+            else:
+                peak = float(ref.abs().max())
+                assert report(f"gno_hidden_bf16/{tag}/out", out.detach().cpu(), ref) <= 3e-2 * peak
+                a = torch.cat([p.grad.flatten().cpu().double() for _, p in it.named_parameters()] + [f.grad.flatten().cpu().double()])
+                r = torch.cat([g["grad"][f"{tag}/{k}"].flatten().double() for k, _ in it.named_parameters()] +
+                              [g["grad"][f"{tag}/f_y"].flatten().double()])
+                cos = float(a @ r / (a.norm() * r.norm()))
+                print(f"[parity] gno_hidden_bf16/{tag}/grads cosine={cos:.6f}")
+                assert cos >= 0.999
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_integral_transform_variants_golden(precision):
     """Variant holes of round 3: `use_attn` with coord_dim 2 / 1 (the reference's default is
     gno_coord_dim 2, magno.py:28; scores on `[:, :coord_dim]`, integral_transform.py:126-142) and kernel MLPs with the other

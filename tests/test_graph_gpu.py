@@ -29,7 +29,8 @@ def _grid(dims, lo=(-1.0, -1.0, -1.0), hi=(1.0, 1.0, 1.0)):
 
 @pytest.mark.parametrize("dims,lo,hi", [((8, 8, 8), (-1, -1, -1), (1, 1, 1)), ((16, 16, 8), (-1, -1, -1), (1, 1, 1)),
                                          ((5, 9, 3), (-0.5, -1.0, 0.0), (0.7, 1.0, 0.4)), ((6, 1, 7), (-1, 0, -1), (1, 0, 1))])
-@pytest.mark.parametrize("k", [1, 4, 8, 11, 16, 27, 40, 64])     # torch_cluster takes any k (magno.py:183-189): any k <= 64 here
+# torch_cluster takes any k (magno.py:183-189): register lists up to 64, passes of 64 beyond (100, 130: two and three passes)
+@pytest.mark.parametrize("k", [1, 4, 8, 11, 16, 27, 40, 64, 100, 130])
 def test_knn_to_grid_matches_bruteforce(dims, lo, hi, k):
     from gaot_3d_amd import graph
     lat = _grid(dims, lo, hi)
@@ -304,7 +305,7 @@ def test_arbitrary_token_sets_on_the_device(strategy, is_decoder):
     b = fn(strategy, p, graph.TokenSet(grid), 0.45, 3)
     assert torch.equal(a, b)
     if strategy == "knn" and not is_decoder:      # k outside the instantiated register lists, non-grid token set
-        for kk in (9, 21, 50):
+        for kk in (9, 21, 50, 70, 120):     # 70, 120 (= all tokens): beyond the register lists, passes of 64
             ref_k = strategy_fn("knn", pos, bp, lat, bl, 0.3, kk, False)
             got_k = strategy_fn("knn", pos.to(DEV), bp.to(DEV), lat.to(DEV), bl.to(DEV), 0.3, kk, False).cpu().long()
             assert got_k.shape == ref_k.shape and _as_set(got_k) == _as_set(ref_k), kk

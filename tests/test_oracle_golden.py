@@ -68,10 +68,11 @@ def test_integral_transform_variants():
     close(out, g["out"]["it_empty"])
 
 
-def test_integral_transform_other_shapes():
+@pytest.mark.parametrize("name", ["gno_shapes", "gno_hidden"])
+def test_integral_transform_other_shapes(name):
     """the reference's default shapes (lifting_channels 16, gno_coord_dim 2: magno.py:25,28), 64 channels, four hidden
-    layers, coord dim 1"""
-    meta, g = gio.load("gno_shapes")
+    layers, coord dim 1 (gno_shapes); kernel-MLP hidden widths 8 / 32 / 48-64-16 / 128 (gno_hidden: free lists, magno.py:32,36)"""
+    meta, g = gio.load(name)
     ei = g["in"]["edge_index"]
     for v in meta["variants"]:
         tag, cd = v["tag"], v["coord_dim"]
