@@ -381,7 +381,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gaot_3d_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -483,6 +483,12 @@ def main(argv=None):
     if world > 1 and args.workload not in ("cfg1", "cfg4"):
         raise SystemExit("--workload cfg3 / yaml are single-GPU lines (their graphs are built from the whole point set)")
     wl_in, wl_out = WORKLOADS[args.workload][4], WORKLOADS[args.workload][5]
+    # tag of the measured-traffic file of this workload variant (tools/gpu_workloads.sh writes profiles/pmc_traffic_<tag>.json)
+    wl_tag = args.workload
+    if args.points != WORKLOADS[args.workload][6]:
+        wl_tag += f"_{args.points // 1000000}m" if args.points % 1000000 == 0 else f"_{args.points}"
+    if args.point_order != "random":
+        wl_tag += f"_{args.point_order}"
     latent = tuple(int(v) for v in args.latent.split(","))
     m_lat = latent[0] * latent[1] * latent[2]
     s_tok = m_lat // 8
@@ -797,10 +803,17 @@ def main(argv=None):
         measured FETCH_SIZE / WRITE_SIZE bytes per launch when profiles/pmc_traffic*.json is from these sources + workload"""
         pj = {}
         try:
-            name = "pmc_traffic.json" if args.workload == "cfg1" else f"pmc_traffic_{args.workload}.json"
+            name = "pmc_traffic.json" if wl_tag == "cfg1" else f"pmc_traffic_{wl_tag}.json"
             cand = json.load(open(os.path.join(ROOT, "profiles", name)))
             if cand.get("_source", {}).get("csrc_sha16") == csrc_sha16() and world == 1:
                 pj = cand
+        except Exception:
+            pass
+        sq_file = {}
+        try:
+            cand = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+            if cand.get("_source", {}).get("csrc_sha16") == csrc_sha16() and world == 1 and args.workload == "cfg1":
+                sq_file = cand
         except Exception:
             pass
         out = {}
@@ -813,6 +826,12 @@ def main(argv=None):
             mb = out[kname]["measured_bytes_per_launch"]
             if mb:
                 out[kname]["measured_gbps"] = round(mb / (ent["avg_ms"] * 1e-3) / 1e9, 1)
+            dd = sq_file.get(kname, {}).get("derived") if kname != "_source" else None
+            if dd:      # the roof the kernel actually sits under (SQ counters): these kernels are instruction-issue bound, not HBM bound
+                out[kname]["issue_busy"] = dd.get("issue_busy")
+                out[kname]["mfma_busy_counted"] = dd.get("mfma_busy_counted")
+                out[kname]["bound_actual"] = ("instruction issue" if dd.get("issue_busy", 0.0) >= 0.6 and out[kname]["frac_of_8tbps"] < 0.4
+                                              else "hbm")
         tot = sum(v["avg_ms"] for v in out.values())
         return dict(kernels=out, total_ms_per_step=round(tot, 4)) if out else None
 
@@ -851,7 +870,7 @@ def main(argv=None):
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pass.sh); they are reported only
             # when the committed file was measured on exactly these kernel sources, otherwise null
             # (one file per workload: the GNO kernels' bytes depend on the graph)
-            pmc_name = "pmc_traffic.json" if args.workload == "cfg1" else f"pmc_traffic_{args.workload}.json"
+            pmc_name = "pmc_traffic.json" if wl_tag == "cfg1" else f"pmc_traffic_{wl_tag}.json"
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             try:
                 pj = json.load(open(pmc))
@@ -863,6 +882,25 @@ def main(argv=None):
                     roof["traffic_source"] = f"profiles/{pmc_name} is from other kernel sources or another N: not reported"
             except Exception:
                 pass
+        # SQ counters of these kernel sources (tools/gpu_pass.sh -> tools/pmc_sq.py -> profiles/pmc_sq.json): what the kernel is
+        # REALLY bound by.  mfma_busy_counted = matrix-pipe time, recomputed products included (the algorithmic `frac` counts the
+        # useful flops only); issue_busy = share of the SIMDs' time spent issuing instructions -- vector and LDS instructions of
+        # the waves of a SIMD issue one at a time, so a kernel near 0.9 sits on its instruction stream, not on MFMA or HBM
+        sq = {}
+        try:
+            cand = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+            if cand.get("_source", {}).get("csrc_sha16") == csrc_sha16() and world == 1 and args.workload == "cfg1":
+                sq = cand
+        except Exception:
+            pass
+        if roof is not None and sq.get(dom):
+            dd = sq[dom]["derived"]
+            roof["counters"] = dict(dd, source=f"profiles/pmc_sq.json (tag {sq['_source'].get('tag')})")
+            if dd.get("issue_busy", 0.0) >= 0.75:
+                roof["bound_actual"] = ("instruction issue: the SIMDs spend %.0f %% of the kernel issuing vector (%.0f %%) and LDS (%.0f %%) "
+                                        "instructions, which share one issue port per SIMD; matrix pipe busy %.0f %%"
+                                        % (100 * dd["issue_busy"], 100 * dd.get("valu_issue", 0), 100 * dd.get("lds_issue", 0),
+                                           100 * dd.get("mfma_busy_counted", 0)))
         troof = step_roofline_ms(n_total // world, m_lat, e_enc, e_dec, s_tok, args.layers, args.precision, out=wl_out)
         if world > 1 and args.parallel == "seq":   # per-rank work of a perfectly divided step (token rows / heads / points)
             troof["transformer_ms"] /= world
@@ -932,7 +970,8 @@ def main(argv=None):
             "without_attention_dropout": secondary,
             "geometry_cached": geom_cached,
             "hbm_copy_peak_measured": (dict(gbps=copy_peak, frac_of_8tbps=round(copy_peak / 8000.0, 4),
-                                            how="float4 grid-stride copy of 1 GiB, read + written bytes, HIP events, same run")
+                                            how="float4 copy of 1 GiB (non-temporal loads and stores, 16-KiB chunk per workgroup, 4 loads in flight per "
+                                                "thread), read + written bytes, HIP events, same run")
                                        if copy_peak else None),
             "fp32_mode": fp32_mode,
             "other_scaling": weak,

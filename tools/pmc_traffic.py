@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 NAMES = [("k_attn_fwd_bf16", "attn_fwd"), ("k_attn_bwd_dkv_kb", "attn_bwd_dkv"), ("k_attn_bwd_dkv_bf16", "attn_bwd_dkv"), ("k_attn_bwd_dq_kb", "attn_bwd_dq"), ("k_attn_bwd_dq_bf16", "attn_bwd_dq"),
          ("k_attn_fwd_f32", "attn_fwd"), ("k_attn_bwd_dkv_f32", "attn_bwd_dkv"), ("k_attn_bwd_dq_f32", "attn_bwd_dq"),
          ("k_gno_fwd_bf16<3", "gno_fwd_nh3"), ("k_gno_fwd_bf16<2", "gno_fwd_nh2"), ("k_gno_bwd3_bf16<3", "gno_bwd_nh3"),
-         ("k_gno_bwd3_bf16<2", "gno_bwd_nh2"), ("k_attn_bwd_fused", "attn_bwd"),
+         ("k_gno_bwd3_bf16<2", "gno_bwd_nh2"), ("k_attn_bwd_fused", "attn_bwd"), ("k_attn_bwd_asm", "attn_bwd"),
          ("k_gno_fwd<3", "gno_fwd_nh3"), ("k_gno_fwd<2", "gno_fwd_nh2"), ("k_gno_bwd<3", "gno_bwd_nh3"),
          ("k_gno_bwd<2", "gno_bwd_nh2")]
 
@@ -26,17 +26,18 @@ def collect(d, counter):
     return {k: tot[k] / max(len(cnt[k]), 1) for k in tot}
 
 
-fetch = collect(sys.argv[1], "FETCH_SIZE")
-write = collect(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    f_raw, w_raw = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
-    out[k] = dict(bytes_per_launch=2 * f_raw + w_raw, fetch_raw_bytes=f_raw, fetch_corrected_bytes=2 * f_raw,
-                  write_bytes=w_raw, note="FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes")
-# provenance: bench.py reports these bytes only while the kernel sources still hash to this value
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-out["_source"] = dict(tag=sys.argv[4] if len(sys.argv) > 4 else None, csrc_sha16=bench.csrc_sha16())
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1))
+if __name__ == "__main__":
+    fetch = collect(sys.argv[1], "FETCH_SIZE")
+    write = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f_raw, w_raw = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
+        out[k] = dict(bytes_per_launch=2 * f_raw + w_raw, fetch_raw_bytes=f_raw, fetch_corrected_bytes=2 * f_raw,
+                      write_bytes=w_raw, note="FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes")
+    # provenance: bench.py reports these bytes only while the kernel sources still hash to this value
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_source"] = dict(tag=sys.argv[4] if len(sys.argv) > 4 else None, csrc_sha16=bench.csrc_sha16())
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
