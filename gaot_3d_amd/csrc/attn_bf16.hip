@@ -1770,7 +1770,20 @@ __global__ void k_attn_dq_reduce(const bf16_t* __restrict__ part, int nslab, int
     const int64_t b = bh / H;
     const bf16_t* p = part + (bh * nslab * (int64_t)S + q) * D + 4 * c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nslab; ++s) {
+    // the partials are read exactly once: non-temporal loads, eight slabs requested before the first is added (same slab order)
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+        u32x2v v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(p + (int64_t)(s + j) * S * D));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc.x += __uint_as_float(v[j].x << 16); acc.y += __uint_as_float(v[j].x & 0xffff0000u);
+            acc.z += __uint_as_float(v[j].y << 16); acc.w += __uint_as_float(v[j].y & 0xffff0000u);
+        }
+    }
+    for (; s < nslab; ++s) {
         const uint2 v = *reinterpret_cast<const uint2*>(p + (int64_t)s * S * D);
         acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
         acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);

@@ -102,6 +102,55 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
         dw_part[(int64_t)blockIdx.x * d + i] = sm[i] + sm[d + i] + sm[2 * d + i] + sm[3 * d + i];
 }
 
+// d == 256 (the Transformer's width): a lane owns ONE float4 of a row, so the eight rows of a wave are loaded TOGETHER (x, dy and
+// the residual's gradient: 24 independent 16-byte loads in flight per lane) before the eight row reductions -- the generic kernel
+// above walks its rows one after the other, each a dependent load -> reduce -> store chain (17.3 us at [16 384, 256]: latency
+// bound at 3.9 TB/s).  Same arithmetic, same summation order, same partial layout.
+__global__ __launch_bounds__(256) void k_rmsnorm_bwd_d256(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, const float* __restrict__ rstd,
+                                                          const float* __restrict__ dx_add, float* __restrict__ dx,
+                                                          float* __restrict__ dw_part, int64_t rows) {
+    constexpr int d = 256, R = RN_ROWS_PER_WAVE;
+    __shared__ float sm[4 * d];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4 ww = reinterpret_cast<const float4*>(w)[lane];
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    float4 v[R], g[R], e[R];
+    float r[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int64_t row = row0 + rr < rows ? row0 + rr : rows - 1;      // clamped: the tail rows are computed and not stored
+        v[rr] = reinterpret_cast<const float4*>(x + row * d)[lane];
+        g[rr] = reinterpret_cast<const float4*>(dy + row * d)[lane];
+        e[rr] = dx_add ? reinterpret_cast<const float4*>(dx_add + row * d)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[rr] = rstd[row];
+    }
+    float dot[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+        dot[rr] = v[rr].x * g[rr].x * ww.x + v[rr].y * g[rr].y * ww.y + v[rr].z * g[rr].z * ww.z + v[rr].w * g[rr].w * ww.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) dot[rr] += __shfl_xor(dot[rr], o, 64);
+    float4 dwacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        if (row0 + rr >= rows) break;
+        const float rs = r[rr], c = dot[rr] * rs * rs * rs / (float)d;
+        reinterpret_cast<float4*>(dx + (row0 + rr) * d)[lane] =
+            make_float4(rs * ww.x * g[rr].x - v[rr].x * c + e[rr].x, rs * ww.y * g[rr].y - v[rr].y * c + e[rr].y,
+                        rs * ww.z * g[rr].z - v[rr].z * c + e[rr].z, rs * ww.w * g[rr].w - v[rr].w * c + e[rr].w);
+        dwacc.x += g[rr].x * v[rr].x * rs;
+        dwacc.y += g[rr].y * v[rr].y * rs;
+        dwacc.z += g[rr].z * v[rr].z * rs;
+        dwacc.w += g[rr].w * v[rr].w * rs;
+    }
+    reinterpret_cast<float4*>(sm + wave * d)[lane] = dwacc;
+    __syncthreads();
+    dw_part[(int64_t)blockIdx.x * d + threadIdx.x] = sm[threadIdx.x] + sm[d + threadIdx.x] + sm[2 * d + threadIdx.x] + sm[3 * d + threadIdx.x];
+}
+
 // out[n] = sum_{p<parts} part[p][n]; 8 columns x 32 part-lanes per block (the partial tables are a few hundred rows of a
 // few hundred columns: many short blocks instead of 8 long serial ones -- 13 -> 4 us), fixed summation order
 constexpr int RP_COLS = 8, RP_LANES = 32;
@@ -488,8 +537,11 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     GAOT_CHECK_ARG(x && weight && dy && rstd && dx && dweight && workspace, "null pointer");
     const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
     float* part = (float*)workspace;
-    GAOT_KLAUNCH(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
-                       dx_add, dx, part, rows, dim);
+    if (dim == 256 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)weight) & 15) == 0)
+        GAOT_KLAUNCH(k_rmsnorm_bwd_d256, dim3((unsigned)nblk), dim3(256), 0, st, x, weight, dy, rstd, dx_add, dx, part, rows);
+    else
+        GAOT_KLAUNCH(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
+                           dx_add, dx, part, rows, dim);
     GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
