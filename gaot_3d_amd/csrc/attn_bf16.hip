@@ -1543,7 +1543,8 @@ struct AsmLds {
     static constexpr int DEL = LSE + QS * 4;                         // float[QS]
     static constexpr int AW = DEL + QS * 4;                          // uint32[QS + 8] packed row words (two parity copies)
     static constexpr int DS = (AW + (QS + 8) * 4 + 2047) / 2048 * 2048;   // per wave KB dS tiles (2 KB aligned: xor addressing)
-    static constexpr int SLOT = DS + W * KB * TILE_BYTES;            // [NT][wave][32 q][32 d] fp32; the waves' K tiles alias it at start
+    // (GAOT_ATTN_BWD_ASM_MFMA_T: the dS tile is transposed on the matrix pipe, the region does not exist)
+    static constexpr int SLOT = DS + (GAOT_ATTN_BWD_ASM_MFMA_T ? 0 : W * KB * TILE_BYTES);   // [NT][wave][32 q][32 d] fp32; the waves' K tiles alias it at start
     static constexpr int TOTAL = SLOT + NT * W * 4096;
     static constexpr int KEYS = W * KB * 32;
 };
@@ -1565,7 +1566,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
     const int rep = a.H / a.HKV;
     const int64_t key0 = (int64_t)slab * L::KEYS + wave * (32 * KB);
     const int64_t rowbase = (int64_t)b * a.S;
-    char* dstile = lds + L::DS + wave * KB * TILE_BYTES;
     // ---- the wave's K / V rows -> AGPR fragments; K rows once through a wave-private tile for the transposed (K^T) fragments ----
     asm volatile(GAOT_ATTN_BWD_ASM_ZERO_ACC ::: GAOT_ATTN_BWD_ASM_ACC_CLOBBERS);
     {
@@ -1595,6 +1595,21 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             });
         });
     }
+#if GAOT_ATTN_BWD_ASM_MFMA_T
+    // permutation ("identity") fragments of the dS transpose (gen_attn_bwd_asm.py: TR = "mfma"): B operand [k = query][n = query'],
+    // lane (n = l31, hf), k-step s, element j stands for query 16 s + 8 (j >> 2) + 4 hf + (j & 3) -- the k order of an accumulator
+    // used as an operand -- and is 1.0 where that query is the lane's own
+    static_for<0, 2>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        unsigned wds[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int q0 = 16 * s + 8 * ((2 * jj) >> 2) + 4 * hf + ((2 * jj) & 3), q1 = 16 * s + 8 * ((2 * jj + 1) >> 2) + 4 * hf + ((2 * jj + 1) & 3);
+            wds[jj] = (q0 == l31 ? 0x3F80u : 0u) | (q1 == l31 ? 0x3F800000u : 0u);
+        }
+        agpr_write4<224 + 4 * s>(make_uint4(wds[0], wds[1], wds[2], wds[3]));
+    });
+#endif
     // ---- per-lane LDS addresses of the tile loop (32-bit LDS byte addresses) -------------------------------------------------------
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const int sw = (l31 >> 2) & 3;
@@ -1606,11 +1621,13 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
         a_c0 = tile_off(r0, col >> 3) + ((col & 7) << 1);
         a_c1 = tile_off(r1, col >> 3) + ((col & 7) << 1);
     }
+#if !GAOT_ATTN_BWD_ASM_MFMA_T
     const unsigned a_dc0 = lbase + L::DS + wave * KB * TILE_BYTES + a_c0, a_dc1 = lbase + L::DS + wave * KB * TILE_BYTES + a_c1;
+    const unsigned a_ds = lbase + L::DS + wave * KB * TILE_BYTES + l31 * 64 + (sw << 4) + 8 * hf;
+#endif
     a_c0 += lbase + L::STAGE;
     a_c1 += lbase + L::STAGE;
     const unsigned a_w = lbase + L::AW + ((l31 & 1) * (QS / 2 + 4) + hf * 8) * 4;
-    const unsigned a_ds = lbase + L::DS + wave * KB * TILE_BYTES + l31 * 64 + (sw << 4) + 8 * hf;
     const unsigned a_slot = lbase + L::SLOT + wave * 4096 + l31 * 128 + ((hf ^ (l31 & 7)) << 4);
 
     constexpr int NST = 2 * NT * 128 / NTHR;      // staged 16-byte chunks per thread
@@ -1721,13 +1738,19 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             if constexpr (DROP)
                 asm volatile(GAOT_ATTN_BWD_STAGE_ASM_DROP
                              :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1), [a_w] "v"(a_w),
-                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1), [a_slot] "v"(a_slot), [bsel0] "v"(bsel[0]),
+#if !GAOT_ATTN_BWD_ASM_MFMA_T
+                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1),
+#endif
+                                [a_slot] "v"(a_slot), [bsel0] "v"(bsel[0]),
                                 [bsel1] "v"(bsel[1]), [bsel2] "v"(bsel[2]), [bsel3] "v"(bsel[3]), [thr] "s"(thr_v)
                              : GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS);
             else
                 asm volatile(GAOT_ATTN_BWD_STAGE_ASM_NODROP
                              :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1),
-                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1), [a_slot] "v"(a_slot)
+#if !GAOT_ATTN_BWD_ASM_MFMA_T
+                                [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1),
+#endif
+                                [a_slot] "v"(a_slot)
                              : GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS);
         }
         __syncthreads();

@@ -27,6 +27,12 @@ W = 4             # waves per workgroup
 KB = 4            # key blocks per wave
 QS = 32 * NT
 TILE = 2048
+# how the unit's dS tile gets from "key on the lane" (the accumulator layout it is born in: B operand of dK^T) to "query on the lane"
+# (B operand of dQ^T): "mfma" = TWO MORE MFMAs against a permutation ("identity") fragment -- the accumulator as the A operand
+# [key][query] times I[query][query'] comes out with the query on the lane, exactly (products with 1.0 / 0.0), then 8 cvt_pk;
+# "lds" = through a wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit).  LDS instructions cost ~13 issue
+# cycles each on the port the vector stream needs (profiles/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
+TR = os.environ.get("GEN_TR", "mfma")
 
 # ---- register map -----------------------------------------------------------------------------------------------------------
 V0 = 48           # first VGPR the asm owns (the compiler keeps v0 .. V0-1 for what lives across the block)
@@ -51,11 +57,13 @@ PPK, DSPK = 200, 208          # packed bf16 P_drop and dS of the unit (8 regs ea
 DQ = 216                      # dQ^T accumulator of the tile (16 regs)
 DSF = 232                     # transposed dS fragments (B operand of dQ^T): 2 x 4 regs
 XR = [240, 241]               # xor results
-TMP = [[242, 243, 244, 245, 246, 247], [248, 249, 250, 251, 252, 253]]   # p0 p1 pm0 pm1 t0 t1, two sets
+TMP = [[242, 243, 244, 245, 246, 247], [242, 243, 244, 245, 246, 247]]   # p0 p1 pm0 pm1 t0 t1 (in-order issue: one set serves every pair)
+FREE_V = list(range(248, 254))  # left to the compiler
 ADR = [254, 255]              # xor-ed LDS addresses
 SM0 = 64                      # s[64:95]: the 16 lane masks of a unit (pair j: s[64+4j:65+4j], s[66+4j:67+4j])
 
-A_DKT, A_DVT, A_KF, A_VF, A_KTF = 0, 64, 128, 160, 192
+A_DKT, A_DVT, A_KF, A_VF, A_KTF, A_ID = 0, 64, 128, 160, 192, 224
+A_END = A_ID + 8 if TR == "mfma" else A_ID
 
 
 def dkt(kb): return ar(A_DKT + 16 * kb, 16)
@@ -173,7 +181,17 @@ def gen_stage(drop: bool):
         """dQ^T of the tile += K^T(kb) dS^T(u), k-step s"""
         kb = u % KB
         c = "0" if (kb == 0 and s == 0) else vr(DQ, 16)
-        st.ins(f"{MFMA} {vr(DQ, 16)}, {ktf(kb, s)}, {vr(DSF + 4 * s, 4)}, {c}", (f"dsf{u}",))
+        st.ins(f"{MFMA} {vr(DQ, 16)}, {ktf(kb, s)}, {vr(DSF + 4 * s, 4)}, {c}", (f"dsf{u}",) if TR == "lds" else ())
+
+    def mfma_T(u, s):
+        """dS^T(u) with the query on the lane = dS-as-A-operand x permutation fragment, k-step s, into unit u's (dead) S buffer"""
+        b = u & 1
+        c = "0" if s == 0 else vr(SB[b], 16)
+        st.ins(f"{MFMA} {vr(SB[b], 16)}, {vr(DSPK + 4 * s, 4)}, {ar(A_ID + 4 * s, 4)}, {c}")
+
+    def cvt_T(u, j):
+        b = u & 1
+        st.ins(f"v_cvt_pk_bf16_f32 {vr(DSF + j)}, {vr(SB[b] + 2 * j)}, {vr(SB[b] + 2 * j + 1)}")
 
     def store_ds(u, half):
         """the unit's packed dS, k-step `half`: two 8-byte stores into the wave's dS tile [key][query]"""
@@ -238,13 +256,30 @@ def gen_stage(drop: bool):
     ph1 = 24 if drop else 0                      # xor / compare instructions in front of the pair arithmetic
     per_pair = (nv - ph1) // 8
     half_done = ph1 + 4 * per_pair               # pairs 0-3 packed
-    # positions (index of the vector instruction an item is issued in front of); one MFMA per ~nv/10 instructions
-    step = nv / 10.0
-    slot = [int(round(i * step)) for i in range(10)]
-    # slots 0,1: B'(u-1) k-step 1; 2,3: C(u-1); 4-7: A(u+1); 8,9: B(u) k-step 0 (needs pairs 0-3: >= half_done + 2)
-    slot[8] = max(slot[8], half_done + 3)
-    slot[9] = max(slot[9], slot[8] + max(4, int(step) - 2))
-    assert slot[9] < nv
+    first_ds = ph1 + per_pair - 1                # the instruction that overwrites DSPK[0] (the previous unit's, read by T' k-step 0)
+    nm = 12 if TR == "mfma" else 10              # MFMAs of a unit
+    step = nv / float(nm)
+    # positions (index of the vector instruction an item is issued in front of), in issue order:
+    #   mfma: T'(u-1) k-steps 0, 1 | B'(u-1) k-step 1 (dV, dK) | C(u-1) k-steps 0, 1 | A(u+1) x 4 | B(u) k-step 0 (dV, dK)
+    #   lds:                         B'(u-1)                    | C(u-1)              | A(u+1)     | B(u)
+    names = (["T0", "T1"] if TR == "mfma" else []) + ["Bp2", "Bp3", "C0", "C1", "A0", "A1", "A2", "A3", "B0", "B1"]
+    pos, p, cvt_at = [], 0, None
+    for i, nme in enumerate(names):
+        if nme == "C0" and TR == "mfma":
+            # the 8 packs of the transposed tile ride as extra instructions in front of vector instructions cvt_at .. cvt_at + 7:
+            # >= 12 instructions behind T1 (MFMA result -> VALU read), C0 two more behind the last of them (VALU write -> MFMA read)
+            cvt_at = pos[1] + 12
+            p = max(p, cvt_at + 10)
+        if nme == "B0":
+            p = max(p, half_done + 3)
+        p = min(p, nv - 1 - 2 * (len(names) - 1 - i))      # leave two instructions per MFMA that still has to follow
+        pos.append(p)
+        p += max(2, (nv - 6 - p) // max(1, len(names) - 1 - i))     # (the last MFMA a few instructions before the unit's end)
+    P = dict(zip(names, pos))
+    assert all(pos[i] < pos[i + 1] for i in range(len(pos) - 1)) and pos[-1] < nv, P
+    if TR == "mfma":
+        assert P["T0"] < first_ds and P["T1"] < first_ds + 4 * per_pair and P["C0"] >= cvt_at + 10 and P["A0"] > P["C1"], (P, first_ds, cvt_at)
+    assert P["Bp3"] < first_ds + 4 * per_pair and P["B0"] >= half_done + 3, P
 
     # ---- prologue --------------------------------------------------------------------------------------------------------------
     load_rows(0)
@@ -262,39 +297,58 @@ def gen_stage(drop: bool):
         seq = valu_unit(u)
         extra = {}                                # position -> list of closures issued in front of that instruction
 
-        def at(pos, fn):
-            extra.setdefault(min(pos, nv - 1), []).append(fn)
+        def at(pos_, fn):
+            extra.setdefault(min(pos_, nv - 1), []).append(fn)
         if u > 0:
-            at(0, lambda u=u: load_dsf(u - 1))                      # behind the last dS store of unit u-1 (program order)
-            at(slot[0], lambda u=u: mfma_B(u - 1, 2))
-            at(slot[1], lambda u=u: mfma_B(u - 1, 3))
-            at(slot[2], lambda u=u: mfma_C(u - 1, 0))
-            at(slot[3], lambda u=u: mfma_C(u - 1, 1))
+            if TR == "mfma":
+                at(P["T0"], lambda u=u: mfma_T(u - 1, 0))
+                at(P["T1"], lambda u=u: mfma_T(u - 1, 1))
+                for j in range(8):
+                    at(cvt_at + j, lambda u=u, j=j: cvt_T(u - 1, j))
+            else:
+                at(0, lambda u=u: load_dsf(u - 1))                  # behind the last dS store of unit u-1 (program order)
+            at(P["Bp2"], lambda u=u: mfma_B(u - 1, 2))
+            at(P["Bp3"], lambda u=u: mfma_B(u - 1, 3))
+            at(P["C0"], lambda u=u: mfma_C(u - 1, 0))
+            at(P["C1"], lambda u=u: mfma_C(u - 1, 1))
             if kb == 0:                                             # the previous tile's dQ^T is complete: to its slot
-                at(slot[7] + 4, lambda t=t: store_slot(t - 1))
+                at(P["C1"] + 14, lambda t=t: store_slot(t - 1))
         if kb == 0 and u > 0:
-            at(slot[1] + 2, lambda t=t: load_cols(t))               # behind B'(t-1, 3): the last reader of the old columns
+            at(P["Bp3"] + 2, lambda t=t: load_cols(t))              # behind B'(t-1, 3): the last reader of the old columns
         if u + 1 < NU:
             for i in range(4):
-                at(slot[4 + i], lambda u=u, i=i: mfma_A(u + 1, i))
+                at(P[f"A{i}"], lambda u=u, i=i: mfma_A(u + 1, i))
         if kb == KB - 2 and t + 1 < NT:                             # behind A(t, 3): rows / row constants of the next tile
-            at(slot[7] + 6, lambda t=t: load_rows(t + 1))
-            at(slot[7] + 8, lambda t=t: load_consts(t + 1))
+            at(P["A3"] + 3, lambda t=t: load_rows(t + 1))
+            at(P["A3"] + 5, lambda t=t: load_consts(t + 1))
         if kb == KB - 1 and t + 1 < NT and drop:                    # behind the unit's last xor: the next tile's row words
             at(ph1 + 1, lambda t=t: load_w8(t + 1))
-        at(slot[8], lambda u=u: mfma_B(u, 0))
-        at(slot[8] + 1, lambda u=u: store_ds(u, 0))
-        at(slot[9], lambda u=u: mfma_B(u, 1))
+        at(P["B0"], lambda u=u: mfma_B(u, 0))
+        if TR == "lds":
+            at(P["B0"] + 1, lambda u=u: store_ds(u, 0))
+        at(P["B1"], lambda u=u: mfma_B(u, 1))
         for i, fn in enumerate(seq):
             for e in extra.get(i, ()):
                 e()
             fn()
-        store_ds(u, 1)
+        if TR == "lds":
+            store_ds(u, 1)
     # ---- epilogue: the last unit's second halves, its dQ^T, the last tile's slot -------------------------------------------------
     u = NU - 1
-    load_dsf(u)
-    mfma_B(u, 2)
-    mfma_B(u, 3)
+    if TR == "mfma":
+        mfma_T(u, 0)
+        mfma_T(u, 1)
+        mfma_B(u, 2)
+        mfma_B(u, 3)
+        st.ins("s_nop 7")
+        st.ins("s_nop 7")      # MFMA result -> VALU read: 8-pass XDL write needs >= 11 wait states
+        for j in range(8):
+            cvt_T(u, j)
+        st.ins("s_nop 1")
+    else:
+        load_dsf(u)
+        mfma_B(u, 2)
+        mfma_B(u, 3)
     mfma_C(u, 0)
     mfma_C(u, 1)
     st.ins("s_nop 7")
@@ -304,9 +358,9 @@ def gen_stage(drop: bool):
     return st.render()
 
 
-CLOBBER_V = [f"v{i}" for i in range(V0, 256)]
+CLOBBER_V = [f"v{i}" for i in range(V0, 256) if i not in FREE_V]
 CLOBBER_S = [f"s{i}" for i in range(SM0, SM0 + 32)]
-CLOBBER_A = [f"a{i}" for i in range(0, 224)]
+CLOBBER_A = [f"a{i}" for i in range(0, A_END)]
 
 
 def c_string(lines):
@@ -316,7 +370,7 @@ def c_string(lines):
 def main():
     out = []
     out.append("// GENERATED by gen_attn_bwd_asm.py -- do not edit (the Makefile rebuilds and compares it).")
-    out.append(f"// NT = {NT} query tiles per stage, {W} waves x {KB} key blocks; asm-owned registers v{V0}-v255, s{SM0}-s{SM0 + 31}, a0-a223.")
+    out.append(f"// NT = {NT} query tiles per stage, {W} waves x {KB} key blocks; asm-owned registers v{V0}-v255, s{SM0}-s{SM0 + 31}, a0-a{A_END - 1}; dS transpose: {TR}.")
     for name, drop in (("DROP", True), ("NODROP", False)):
         lines = gen_stage(drop)
         n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
@@ -335,6 +389,7 @@ def main():
     cl = ", ".join(f'"{r}"' for r in CLOBBER_V + CLOBBER_S + CLOBBER_A + ["vcc", "memory"])
     out.append(f"#define GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS {cl}")
     out.append(f"#define GAOT_ATTN_BWD_ASM_NT {NT}")
+    out.append(f"#define GAOT_ATTN_BWD_ASM_MFMA_T {1 if TR == 'mfma' else 0}")
     print("\n".join(out))
 
 
