@@ -1536,25 +1536,29 @@ __device__ __forceinline__ float agpr_read() {
     asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(REG) : "memory");
     return r;
 }
-struct AsmLds {
+template <bool MT>     // MT: the dS tile is transposed on the matrix pipe (no wave-private dS tiles in LDS)
+struct AsmLdsT {
     static constexpr int NT = GAOT_ATTN_BWD_ASM_NT, W = 4, KB = 4, QS = 32 * NT;
     static constexpr int STAGE = 0;                                  // Q tiles, then dO tiles
     static constexpr int LSE = STAGE + 2 * NT * TILE_BYTES;          // float[QS]
     static constexpr int DEL = LSE + QS * 4;                         // float[QS]
     static constexpr int AW = DEL + QS * 4;                          // uint32[QS + 8] packed row words (two parity copies)
     static constexpr int DS = (AW + (QS + 8) * 4 + 2047) / 2048 * 2048;   // per wave KB dS tiles (2 KB aligned: xor addressing)
-    // (GAOT_ATTN_BWD_ASM_MFMA_T: the dS tile is transposed on the matrix pipe, the region does not exist)
-    static constexpr int SLOT = DS + (GAOT_ATTN_BWD_ASM_MFMA_T ? 0 : W * KB * TILE_BYTES);   // [NT][wave][32 q][32 d] fp32; the waves' K tiles alias it at start
+    static constexpr int SLOT = DS + (MT ? 0 : W * KB * TILE_BYTES);   // [NT][wave][32 q][32 d] fp32; the waves' K tiles alias it at start
     static constexpr int TOTAL = SLOT + NT * W * 4096;
     static constexpr int KEYS = W * KB * 32;
 };
-static_assert(AsmLds::TOTAL <= 160 * 1024 && AsmLds::SLOT % 128 == 0 && AsmLds::NT * AsmLds::W * 4096 >= AsmLds::W * AsmLds::KB * TILE_BYTES, "LDS layout");
+template <bool DROP>
+using AsmLds = AsmLdsT<DROP ? (GAOT_ATTN_BWD_ASM_MFMA_T_DROP != 0) : (GAOT_ATTN_BWD_ASM_MFMA_T_NODROP != 0)>;
+static_assert(AsmLds<false>::TOTAL <= 160 * 1024 && AsmLds<true>::SLOT % 128 == 0 && AsmLds<false>::SLOT % 128 == 0 &&
+              AsmLds<true>::NT * 4 * 4096 >= 4 * 4 * TILE_BYTES, "LDS layout");
 
 // LAB (measurement only, results invalid): 1 = the stage code without the tile loop, 2 = the tile loop without slot reduction /
 // row-word hashing (barriers and tile staging kept), 3 = no barriers either
 template <bool DROP, int LAB = 0>
 __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
-    using L = AsmLds;
+    using L = AsmLds<DROP>;
+    constexpr bool MT = DROP ? (GAOT_ATTN_BWD_ASM_MFMA_T_DROP != 0) : (GAOT_ATTN_BWD_ASM_MFMA_T_NODROP != 0);
     constexpr int NT = L::NT, KB = L::KB, QS = L::QS, NTHR = 256, WV = L::W;
     const BwdArgs& a = fa.a;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -1595,7 +1599,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             });
         });
     }
-#if GAOT_ATTN_BWD_ASM_MFMA_T
+    if constexpr (MT) {
     // permutation ("identity") fragments of the dS transpose (gen_attn_bwd_asm.py: TR = "mfma"): B operand [k = query][n = query'],
     // lane (n = l31, hf), k-step s, element j stands for query 16 s + 8 (j >> 2) + 4 hf + (j & 3) -- the k order of an accumulator
     // used as an operand -- and is 1.0 where that query is the lane's own
@@ -1609,7 +1613,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
         }
         agpr_write4<224 + 4 * s>(make_uint4(wds[0], wds[1], wds[2], wds[3]));
     });
-#endif
+    }
     // ---- per-lane LDS addresses of the tile loop (32-bit LDS byte addresses) -------------------------------------------------------
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const int sw = (l31 >> 2) & 3;
@@ -1621,10 +1625,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
         a_c0 = tile_off(r0, col >> 3) + ((col & 7) << 1);
         a_c1 = tile_off(r1, col >> 3) + ((col & 7) << 1);
     }
-#if !GAOT_ATTN_BWD_ASM_MFMA_T
+    // (LDS transpose only; unused -- and removed by the compiler -- when the tile is transposed on the matrix pipe)
     const unsigned a_dc0 = lbase + L::DS + wave * KB * TILE_BYTES + a_c0, a_dc1 = lbase + L::DS + wave * KB * TILE_BYTES + a_c1;
     const unsigned a_ds = lbase + L::DS + wave * KB * TILE_BYTES + l31 * 64 + (sw << 4) + 8 * hf;
-#endif
     a_c0 += lbase + L::STAGE;
     a_c1 += lbase + L::STAGE;
     const unsigned a_w = lbase + L::AW + ((l31 & 1) * (QS / 2 + 4) + hf * 8) * 4;
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             if constexpr (DROP)
                 asm volatile(GAOT_ATTN_BWD_STAGE_ASM_DROP
                              :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1), [a_w] "v"(a_w),
-#if !GAOT_ATTN_BWD_ASM_MFMA_T
+#if !GAOT_ATTN_BWD_ASM_MFMA_T_DROP
                                 [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1),
 #endif
                                 [a_slot] "v"(a_slot), [bsel0] "v"(bsel[0]),
@@ -1747,7 +1750,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             else
                 asm volatile(GAOT_ATTN_BWD_STAGE_ASM_NODROP
                              :: [a_const] "v"(a_const), [a_r0] "v"(a_r0), [a_r1] "v"(a_r1), [a_c0] "v"(a_c0), [a_c1] "v"(a_c1),
-#if !GAOT_ATTN_BWD_ASM_MFMA_T
+#if !GAOT_ATTN_BWD_ASM_MFMA_T_NODROP
                                 [a_ds] "v"(a_ds), [a_dc0] "v"(a_dc0), [a_dc1] "v"(a_dc1),
 #endif
                                 [a_slot] "v"(a_slot)
@@ -2066,11 +2069,11 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // against 0.843-0.852 ms (a wash: a lone wave issues one vector instruction per 4 cycles, and the dropout unit's ~108
             // vector + 15 LDS + 10 MFMA instructions are ~700 issue cycles -- the measured 758 per unit ARE that stream) -> the
             // two-waves-per-SIMD kernel stays.  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
-            if ((variant == 2 || (variant == 0 && !drop && lab == 0 && !want_stamps)) && nyf == 1) {
-                if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds::TOTAL, 256);
-                else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds::TOTAL, 256);
-                else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds::TOTAL, 256);
-                else rc = drop ? go(k_attn_bwd_asm<true>, AsmLds::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds::TOTAL, 256);
+            if ((variant == 2 || (variant == 0 && lab == 0 && !want_stamps)) && nyf == 1) {
+                if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds<false>::TOTAL, 256);
+                else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds<false>::TOTAL, 256);
+                else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds<false>::TOTAL, 256);
+                else rc = drop ? go(k_attn_bwd_asm<true>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds<false>::TOTAL, 256);
             }
             else if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);

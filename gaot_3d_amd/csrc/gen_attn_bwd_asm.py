@@ -32,7 +32,8 @@ TILE = 2048
 # [key][query] times I[query][query'] comes out with the query on the lane, exactly (products with 1.0 / 0.0), then 8 cvt_pk;
 # "lds" = through a wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit).  LDS instructions cost ~13 issue
 # cycles each on the port the vector stream needs (profiles/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
-TR = os.environ.get("GEN_TR", "mfma")
+TR_DROP = os.environ.get("GEN_TR_DROP", "mfma")       # measured: 0.854 (mfma) against 0.896 ms for the compiled kernel on one box, lds 0.838 / 0.843
+TR_NODROP = os.environ.get("GEN_TR_NODROP", "lds")   # without dropout the unit is MFMA bound: 12 MFMAs cost more than the LDS round trip (0.726 against 0.684 ms)
 
 # ---- register map -----------------------------------------------------------------------------------------------------------
 V0 = 48           # first VGPR the asm owns (the compiler keeps v0 .. V0-1 for what lives across the block)
@@ -63,7 +64,7 @@ ADR = [254, 255]              # xor-ed LDS addresses
 SM0 = 64                      # s[64:95]: the 16 lane masks of a unit (pair j: s[64+4j:65+4j], s[66+4j:67+4j])
 
 A_DKT, A_DVT, A_KF, A_VF, A_KTF, A_ID = 0, 64, 128, 160, 192, 224
-A_END = A_ID + 8 if TR == "mfma" else A_ID
+A_END = A_ID + 8
 
 
 def dkt(kb): return ar(A_DKT + 16 * kb, 16)
@@ -118,6 +119,7 @@ class Stream:
 
 
 def gen_stage(drop: bool):
+    TR = TR_DROP if drop else TR_NODROP
     st = Stream()
     nv = 104 if drop else 48          # vector instructions of a unit
 
@@ -370,7 +372,7 @@ def c_string(lines):
 def main():
     out = []
     out.append("// GENERATED by gen_attn_bwd_asm.py -- do not edit (the Makefile rebuilds and compares it).")
-    out.append(f"// NT = {NT} query tiles per stage, {W} waves x {KB} key blocks; asm-owned registers v{V0}-v255, s{SM0}-s{SM0 + 31}, a0-a{A_END - 1}; dS transpose: {TR}.")
+    out.append(f"// NT = {NT} query tiles per stage, {W} waves x {KB} key blocks; asm-owned registers v{V0}-v255, s{SM0}-s{SM0 + 31}, a0-a{A_END - 1}; dS transpose: {TR_DROP} (dropout) / {TR_NODROP} (none).")
     for name, drop in (("DROP", True), ("NODROP", False)):
         lines = gen_stage(drop)
         n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
@@ -389,7 +391,8 @@ def main():
     cl = ", ".join(f'"{r}"' for r in CLOBBER_V + CLOBBER_S + CLOBBER_A + ["vcc", "memory"])
     out.append(f"#define GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS {cl}")
     out.append(f"#define GAOT_ATTN_BWD_ASM_NT {NT}")
-    out.append(f"#define GAOT_ATTN_BWD_ASM_MFMA_T {1 if TR == 'mfma' else 0}")
+    out.append(f"#define GAOT_ATTN_BWD_ASM_MFMA_T_DROP {1 if TR_DROP == 'mfma' else 0}")
+    out.append(f"#define GAOT_ATTN_BWD_ASM_MFMA_T_NODROP {1 if TR_NODROP == 'mfma' else 0}")
     print("\n".join(out))
 
 
