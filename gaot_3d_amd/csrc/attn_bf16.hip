@@ -1107,7 +1107,10 @@ struct FusedArgs {
 // mask-generation instructions per pair instead of 4, and half the row-word reads.
 // ORD (with PK): 0 = all of a tile's exp / mask work, then all of its dV / dK products; 1 = key block by key block (block 0's
 // dV / dK MFMAs are in flight under block 1's exp / mask stream)
-template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0, int SB = 0>
+// TT (round 5): the dS tile reaches the dQ product's "query on the lane" orientation on the MATRIX pipe -- the accumulator as the
+// A operand [key][query] times a permutation fragment I[query][query'] (two MFMAs, exact: products with 1.0 / 0.0), packed again --
+// instead of through the wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit on an issue port that is 89 % busy)
+template <bool DROP, int FB_WAVES, int FB_KB, int FB_NT, bool PK = false, int ORD = 0, int SB = 0, bool TT = false>
 __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 : 2)) void k_attn_bwd_fused(FusedArgs fa) {
     using L = FusedLds<FB_WAVES, FB_KB, FB_NT>;
     constexpr int FB_QS = L::QS, FB_OFF_STAGE = L::STAGE, FB_OFF_LSE = L::LSE, FB_OFF_DEL = L::DEL, FB_OFF_AW = L::AW, FB_OFF_K = L::K;
@@ -1179,6 +1182,13 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
     for (int kb = 0; kb < FB_KB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkt[kb][r] = 0.f; dvt[kb][r] = 0.f; }
+    // TT: permutation fragments, B operand [k = query][n = query'], element j of k-step s stands for query 16 s + 8 (j >> 2) +
+    // 4 hf + (j & 3) (the k order of an accumulator used as an operand): 1.0 where that query is the lane's own
+    bf16x8 idf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (TT && (16 * s + 8 * (j >> 2) + 4 * hf + (j & 3)) == l31) ? (short)0x3F80 : (short)0;
     // loop-invariant K^T fragments (the A operand of dQ^T = K^T dS^T): read back once from the wave's own tile when the
     // register file has room for them (one wave per SIMD), else re-read per tile (two waves per SIMD, 256 registers)
     bf16x8 ktf[KT_REGS ? FB_KB : 1][2];
@@ -1416,6 +1426,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                         wv = nxt;
                     }
                 }
+                bf16x8 tsf[FB_KB][2];     // TT: the unit's dS^T fragments (query on the lane)
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
                     if constexpr (DROP && PK && ORD == 1) {
@@ -1439,6 +1450,14 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     dkt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc0, d0, dkt[kb], 0, 0, 0);
                     dvt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dc1, p1, dvt[kb], 0, 0, 0);
                     dkt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qc1, d1, dkt[kb], 0, 0, 0);
+                    if constexpr (TT) {
+                        f32x16 tr;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tr[r] = 0.f;
+                        tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, idf[0], tr, 0, 0, 0);
+                        tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, idf[1], tr, 0, 0, 0);
+                        acc_to_frags(tr, tsf[kb][0], tsf[kb][1]);
+                    } else {
                     // dS tile [key = l31][query]: the lane's 4 runs of 4 consecutive queries (8 g + 4 hf + 0..3) = 8-byte stores
                     const uint4 lo = __builtin_bit_cast(uint4, d0), hi = __builtin_bit_cast(uint4, d1);
                     char* dst = dstile + kb * TILE_BYTES;
@@ -1446,6 +1465,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 1) + 8 * hf) = make_uint2(lo.z, lo.w);
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 2) + 8 * hf) = make_uint2(hi.x, hi.y);
                     *reinterpret_cast<uint2*>(dst + tile_off(l31, 3) + 8 * hf) = make_uint2(hi.z, hi.w);
+                    }
                 }
                 if constexpr ((SB & 4) != 0) __builtin_amdgcn_sched_barrier(0);
                 STAMP(7);        // conversions, dV / dK MFMAs issued, dS tile stored
@@ -1457,7 +1477,10 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
                 for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < FB_KB; ++kb) {
-                    if constexpr (KT_REGS) {
+                    if constexpr (TT) {
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KT_REGS ? ktf[kb][0] : frag_cols(ktile + kb * TILE_BYTES, lane, 0), tsf[kb][0], dq, 0, 0, 0);
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KT_REGS ? ktf[kb][1] : frag_cols(ktile + kb * TILE_BYTES, lane, 1), tsf[kb][1], dq, 0, 0, 0);
+                    } else if constexpr (KT_REGS) {
                         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kb][0], frag_cols(dstile + kb * TILE_BYTES, lane, 0), dq, 0, 0, 0);
                         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[kb][1], frag_cols(dstile + kb * TILE_BYTES, lane, 1), dq, 0, 0, 0);
                     } else {
@@ -2064,11 +2087,11 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // GAOT_ATTN_BWD_STAMPS=1: the diagnostic instantiation with in-kernel cycle stamps (results unchanged, slower)
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
-            // k_attn_bwd_asm (one wave per SIMD, hand-scheduled tile loop): measured on MI355X at S = 16 384, H = 8 (profiles/
-            // r5_b / r5_c / r5_d): without dropout 0.684 against 0.725 ms (-6 %) -> the default there; with dropout 0.838-0.856
-            // against 0.843-0.852 ms (a wash: a lone wave issues one vector instruction per 4 cycles, and the dropout unit's ~108
-            // vector + 15 LDS + 10 MFMA instructions are ~700 issue cycles -- the measured 758 per unit ARE that stream) -> the
-            // two-waves-per-SIMD kernel stays.  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
+            // k_attn_bwd_asm (one wave per SIMD, hand-scheduled tile loop, dS transposed on the matrix pipe with dropout / through LDS
+            // without) is the default for whole-sequence launches: same box, S = 16 384, H = 8 (profiles/r5_d_attn_bwd_asm_mfma_t2.txt):
+            // 0.798 against 0.836 ms with dropout (-4.5 %), 0.669 against 0.717 ms without (-6.7 %); dK / dV bit-identical to the compiled
+            // kernel, dQ within 5e-5 of peak (four slots of four key blocks instead of eight of two).  Few heads per launch (query-range
+            // parts) keep the compiled kernel.  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
             if ((variant == 2 || (variant == 0 && lab == 0 && !want_stamps)) && nyf == 1) {
                 if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds<false>::TOTAL, 256);
                 else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds<false>::TOTAL, 256);
@@ -2102,6 +2125,8 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                 }
             }
 
+            else if (lab == 200)      // TT: dS transposed on the matrix pipe
+                rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26, true>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26, true>, FusedLds<8, 2, 2>::TOTAL, 512);
             else if (lab == 100)      // no schedule pins (the round-3 / r4_d schedule)
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512);
             // (compile-time priority variants on the pinned schedule -- waves >= W/2 one level higher, static priority without
