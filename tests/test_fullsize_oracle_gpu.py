@@ -99,15 +99,17 @@ def test_attention_full_sequence_vs_fp64_oracle(precision, p):
             PAR.close_peak(f"{tag}/{nm}", qd.grad[:, lo:hi], gref[:, lo:hi], 2e-2)   # achieved ~8e-3 (2e-2 of peak)
 
 
+@pytest.mark.parametrize("h", [4, 8])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_attention_fused_backward_vs_fp64_oracle(p):
-    """The FUSED backward (k_attn_bwd_fused: dK, dV and dQ from one pass, bf16 slab partials, fixed-order reduction) at
-    S = 16 384 with 4 heads (the grid at which it is dispatched), against the oracle's SDPA in fp64 for ONE of the heads
-    (head 2: mask keyed by the head index, per-head slices of lse / delta / partials), and against the two-pass kernels."""
+def test_attention_fused_backward_vs_fp64_oracle(p, h):
+    """The FUSED backward (dK, dV and dQ from one pass, bf16 slab partials, fixed-order reduction) at S = 16 384, against the
+    oracle's SDPA in fp64 for ONE of the heads (head 2: mask keyed by the head index, per-head slices of lse / delta / partials),
+    and against the two-pass kernels.  4 heads: the compiled kernel k_attn_bwd_fused with the queries in two parts (128 slabs x
+    heads < 256 workgroups); 8 heads: a whole-sequence launch = the hand-scheduled k_attn_bwd_asm (round 5)."""
     import gaot_3d_amd
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd import ops
-    s, h, hd = S_FULL, 4, 2
+    s, hd = S_FULL, 2
     g = torch.Generator().manual_seed(4321)
     qkv = torch.randn(s, 3 * h * 32, generator=g)
     qkv[:, :2 * h * 32] *= 1.5
@@ -125,7 +127,7 @@ def test_attention_fused_backward_vs_fp64_oracle(p):
     g_two = ops.attn_bwd_bf16(img, o, wd, lse, 1, s, h, h, scale, p, st, freqs=fd, fused=False)
     torch.cuda.synchronize()
     assert torch.equal(g_fused, g_fused2)                       # fixed summation order: bit-reproducible
-    tag = f"attn_fused_S{s}_p{p}"
+    tag = f"attn_fused_S{s}_h{h}_p{p}"
     for nm, lo, hi in (("dq", 0, h * 32), ("dk", h * 32, 2 * h * 32), ("dv", 2 * h * 32, 3 * h * 32)):
         PAR.cosine(f"{tag}/{nm} fused vs two-pass", g_fused[:, lo:hi], g_two[:, lo:hi], 0.99999)
         PAR.close_peak(f"{tag}/{nm} fused vs two-pass", g_fused[:, lo:hi], g_two[:, lo:hi], 1e-2)
@@ -147,7 +149,10 @@ def test_attention_fused_backward_vs_fp64_oracle(p):
 
 
 @pytest.mark.parametrize("b,s,h,hkv,p", [(8, 2085, 8, 4, 0.1), (2, 4133, 8, 8, 0.0), (1, 16384 - 37, 8, 4, 0.1),
-                                         (1, 16384, 1, 1, 0.1), (1, 16384, 2, 1, 0.0), (1, 9000 + 13, 2, 2, 0.1), (1, 16384, 4, 4, 0.1)])
+                                         (1, 16384, 1, 1, 0.1), (1, 16384, 2, 1, 0.0), (1, 9000 + 13, 2, 2, 0.1), (1, 16384, 4, 4, 0.1),
+                                         # >= 256 workgroups: whole-sequence launches = the hand-scheduled k_attn_bwd_asm (round 5) --
+                                         # ragged last stage / slab, batches, grouped-query heads (two q heads per kv head), no dropout
+                                         (2, 8192 + 77, 8, 8, 0.1), (4, 8192, 8, 4, 0.1), (1, 16384 - 37, 8, 8, 0.0), (2, 16384 - 130, 8, 4, 0.1)])
 def test_attention_fused_backward_ragged_gqa_batches(b, s, h, hkv, p):
     """ragged sequence lengths (keys and queries past S inside the last slab / stage), grouped-query heads (a workgroup loops
     over the heads of its kv head), batches, and FEW heads per launch (the heads one rank of a sharded step owns: the queries
