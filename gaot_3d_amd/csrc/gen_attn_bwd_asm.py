@@ -5,19 +5,25 @@ attn_bf16.hip).  Reference operator: F.scaled_dot_product_attention's backward, 
 One workgroup = 4 waves = ONE wave per SIMD with the whole 512-register file; a wave owns 4 key blocks (128 keys) and walks the
 stage's NT query tiles.  Per (query tile, key block) UNIT the arithmetic is exactly k_attn_bwd_fused's: S^T / dP^T (4 MFMAs, the
 row constants -lse / -delta as the C operand), p = exp2(S'), the dropout mask on packed row words (xor + 2 SDWA compares per
-query pair), P_drop / dS (4 selects, 2 multiplies, 2 cvt_pk per pair), dV^T / dK^T (4 MFMAs), the dS tile through LDS
-(4 ds_write_b64, 4 transposed reads) and dQ^T (2 MFMAs).  What the compiler could not do with 512 registers (VERDICT r4 #1:
+query pair), P_drop / dS (4 selects, 2 multiplies, 2 cvt_pk per pair), dV^T / dK^T (4 MFMAs), the dS tile turned from "key on
+the lane" to "query on the lane" (TR below), dQ^T (2 MFMAs).  What the compiler could not do with 512 registers (VERDICT r4 #1:
 it moved every MFMA result through AGPR copies and spilled) is done by hand here:
   * AGPRs hold what only the matrix pipe touches: dK^T / dV^T accumulators (a0-a127), the K / V row fragments (B operands of
-    S / dP: a128-a191) and the K^T fragments (A operand of dQ^T: a192-a223) -- no v_accvgpr traffic in the loop;
+    S / dP: a128-a191), the K^T fragments (A operand of dQ^T: a192-a223), the permutation fragments of the transpose
+    (a224-a231) -- no v_accvgpr traffic in the loop;
   * the score tiles live in VGPRs (double buffered: the 4 MFMAs of unit u + 1 are issued inside unit u's vector stream);
-  * a unit's ~104 vector instructions carry its 10 MFMAs in their gaps (one per ~10 instructions = ~45 issue cycles >= the
-    MFMA's 32): B'(u-1) second halves, C(u-1) (dQ), A(u+1) (S, dP), B(u) first halves -- MI355X_MICROARCH.md "single-issue
-    instructions hidden per MFMA gap";
-  * every LDS read is issued a unit (or a tile) ahead of its use and waited for by COUNT (s_waitcnt lgkmcnt(n)).
+  * a unit's ~104 vector instructions carry its 10-12 MFMAs in their gaps (one per ~9 instructions = ~40 issue cycles >= the
+    MFMA's 32): T(u-1) (transpose), B'(u-1) second halves, C(u-1) (dQ), A(u+1) (S, dP), B(u) first halves --
+    MI355X_MICROARCH.md "single-issue instructions hidden per MFMA gap";
+  * every LDS read is issued a unit (or a tile) ahead of its use and waited for by COUNT (s_waitcnt lgkmcnt(n), computed here).
 The stage code around the tile loop (global loads, LDS staging, slot reduction, barriers) stays C++.
 
-Usage: python3 gen_attn_bwd_asm.py > attn_bwd_asm.inc   (the Makefile checks that the committed file is current)
+Measured (MI355X, S = 16 384, H = 8, profiles/r5_b ... r5_e, r5_d_*mfma_t*): the loop runs at its instruction-issue time (562
+cycles per unit without its LDS instructions = 104 vector instructions + 10 MFMAs to the cycle; an LDS instruction costs ~13
+more on the same port), which is why the transpose moved to the matrix pipe under dropout.
+
+Usage: python3 gen_attn_bwd_asm.py > attn_bwd_asm.inc   (tests/test_host_cpu.py checks that the committed file is current).
+Environment (measurement builds only): GEN_NT, GEN_TR_DROP / GEN_TR_NODROP = mfma | lds, GEN_LAB = nowait | nolds (invalid results).
 """
 import sys
 
