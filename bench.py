@@ -268,11 +268,13 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
             atten_dropout = 0.0
     else:
         n, latent = points // 8, (latent_full[0] // 2, latent_full[1] // 2, latent_full[2] // 2)
-    # the host's own cores, all of them.  On the 256-core boxes 64 threads run this step faster than 256 (the
-    # segmented reductions and the fp32 GEMMs of [16 384, 256] rows do not scale past a socket's worth): the full-sample
-    # mode times both counts and reports the faster -- the number is the CPU's best, whichever count gives it
+    # SURVEY 8d asks for the host's own cores.  MEASURED on the pool's 256-thread boxes (profiles/r5_j_bench_bf16_graph.json): the
+    # full step on all 256 threads takes 253.8 s against 28.3 s on 64 (the segmented reductions and the fp32 GEMMs of [16 384, 256]
+    # rows do not scale past a socket's worth; oversubscribed they collapse) -- and two such steps would turn the default bench run
+    # into ten minutes.  So the full-sample step runs on min(os.cpu_count(), 64) threads, and the all-cores direction is probed on
+    # the BOUNDED sample (one step at os.cpu_count() threads next to the timed ones: `seconds_by_threads`), CPU model named
     ncpu = os.cpu_count() or 1
-    cores = min(ncpu, 16) if mode == "sample" else ncpu
+    cores = min(ncpu, 16) if mode == "sample" else min(ncpu, 64)
     torch.set_num_threads(cores)
     cfg = model_config(latent, layers, k)
     torch.manual_seed(seed)
@@ -300,6 +302,13 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
             times.append(time.perf_counter() - t0)
         how = f"best of {len(times)} after 1 warm-up"
         t = min(times)
+        tried[cores] = [round(v, 2) for v in times]
+        if ncpu > cores and t < 20.0:      # the all-cores probe: one more step of the bounded sample on every host thread
+            torch.set_num_threads(ncpu)
+            t0 = time.perf_counter()
+            one_step()
+            tried[ncpu] = [round(time.perf_counter() - t0, 2)]
+            torch.set_num_threads(cores)
     else:           # one warm-up step, then up to three timed ones while a 75 s budget lasts (at least one): the median
         t0 = time.perf_counter()
         one_step()
@@ -312,14 +321,6 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
         t = statistics.median(times)
         tried[cores] = [round(v, 2) for v in times]
         how = f"median of {len(times)} after 1 warm-up on {cores} threads"
-        if ncpu > 64:      # one more timed step on 64 threads (already warm); the faster count is the reported one
-            torch.set_num_threads(64)
-            t0 = time.perf_counter()
-            one_step()
-            t64 = time.perf_counter() - t0
-            tried[64] = [round(t64, 2)]
-            if t64 < t:
-                t, cores, how = t64, 64, f"1 timed step on 64 threads after warm-up (faster than the median on {ncpu}: {tried[ncpu]})"
     frac = "the same sample as the GPU step" if mode == "full" else "1/8 of the points and 1/8 of the latent grid: a REDUCED sample"
     out = dict(value=n / t, unit="points/s", cores=cores, host_cpus=ncpu, cpu_model=cpu_model(), kind="port",
                reduced_sample=(mode != "full"), seconds_per_step=round(t, 2), timed_seconds=[round(v, 2) for v in times],
@@ -371,7 +372,7 @@ def cpu_baseline_auto(budget_s, layers, k, seed, atten_dropout, points, latent_f
     except Exception as ex:
         red["full_sample_skipped"] = f"full 500K-point CPU step failed ({type(ex).__name__}: {ex})"
         return red
-    full["bounded_sample"] = {kk: red[kk] for kk in ("value", "cores", "seconds_per_step", "sample")}
+    full["bounded_sample"] = {kk: red[kk] for kk in ("value", "cores", "seconds_per_step", "sample", "seconds_by_threads") if kk in red}
     return full
 
 
