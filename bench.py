@@ -58,6 +58,10 @@ def parse_args(argv=None):
                          "reported value when the host has the memory (>= 110 GB free) and the extrapolated time fits "
                          "--cpu-baseline-budget")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-all-cores", action="store_true",
+                    help="also time ONE step of the bounded CPU sample on os.cpu_count() threads (measured on the pool's 256-thread "
+                         "hosts: 214 s against 5.1 s on 16 threads, the full sample 253.8 s against 28.3 s on 64 -- which is why it is "
+                         "not part of the default run)")
     ap.add_argument("--cpu-baseline-dropout", action="store_true",
                     help="full-sample CPU step WITH attention dropout (torch's CPU SDPA then takes its written-out path: minutes "
                          "per step and ~90 GB at S = 16 384); default: dropout off on the CPU side, its best case")
@@ -249,7 +253,7 @@ def step_roofline_ms(n_pts, m_lat, e_enc, e_dec, s_tok, layers, precision, d=256
                 t_roof_ms=(t_xf + t_gno + t_pt + t_opt) * 1e3)
 
 
-def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_dropout=False):
+def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_dropout=False, all_cores_probe=False):
     """The oracle (CPU restatement of the reference, pure PyTorch fp32) timed on the host cores.  mode 'sample': a bounded
     sample of the same workload -- 1/8 of the points and 1/8 of the latent grid (so 1/8 of the tokens: attention, which is
     quadratic in them, is 1/64), same widths and depth; mode 'full': the same 500K-point sample the GPU step runs, one
@@ -268,11 +272,11 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
             atten_dropout = 0.0
     else:
         n, latent = points // 8, (latent_full[0] // 2, latent_full[1] // 2, latent_full[2] // 2)
-    # SURVEY 8d asks for the host's own cores.  MEASURED on the pool's 256-thread boxes (profiles/r5_j_bench_bf16_graph.json): the
-    # full step on all 256 threads takes 253.8 s against 28.3 s on 64 (the segmented reductions and the fp32 GEMMs of [16 384, 256]
-    # rows do not scale past a socket's worth; oversubscribed they collapse) -- and two such steps would turn the default bench run
-    # into ten minutes.  So the full-sample step runs on min(os.cpu_count(), 64) threads, and the all-cores direction is probed on
-    # the BOUNDED sample (one step at os.cpu_count() threads next to the timed ones: `seconds_by_threads`), CPU model named
+    # SURVEY 8d asks for the host's own cores.  MEASURED on the pool's 256-thread boxes: the full step on all 256 threads takes
+    # 253.8 s against 28.3 s on 64 (profiles/r5_j_bench_bf16_graph.json), the bounded step 214 s against 5.1 s on 16
+    # (profiles/r5_k_bench_default.json) -- the segmented reductions and the fp32 GEMMs of [16 384, 256] rows do not scale past a
+    # socket's worth, oversubscribed they collapse.  So the full-sample step runs on min(os.cpu_count(), 64) threads, the host's
+    # thread count and CPU model are named in the line, and --cpu-baseline-all-cores repeats the all-cores measurement on request
     ncpu = os.cpu_count() or 1
     cores = min(ncpu, 16) if mode == "sample" else min(ncpu, 64)
     torch.set_num_threads(cores)
@@ -303,7 +307,7 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
         how = f"best of {len(times)} after 1 warm-up"
         t = min(times)
         tried[cores] = [round(v, 2) for v in times]
-        if ncpu > cores and t < 20.0:      # the all-cores probe: one more step of the bounded sample on every host thread
+        if all_cores_probe and ncpu > cores:   # --cpu-baseline-all-cores: one more step of the bounded sample on every host thread
             torch.set_num_threads(ncpu)
             t0 = time.perf_counter()
             one_step()
@@ -342,10 +346,10 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_auto(budget_s, layers, k, seed, atten_dropout, points, latent_full, cpu_dropout=False):
+def cpu_baseline_auto(budget_s, layers, k, seed, atten_dropout, points, latent_full, cpu_dropout=False, all_cores_probe=False):
     """the bounded sample first; then, when the host can take it, ONE step on the metric's own 500K-point sample as the
     reported value (same input), the bounded figure kept beside it"""
-    red = cpu_baseline("sample", layers, k, seed, atten_dropout, points, latent_full)
+    red = cpu_baseline("sample", layers, k, seed, atten_dropout, points, latent_full, all_cores_probe=all_cores_probe)
     # the bounded sample carries dropout masks (explicit attention weights), the full step runs without dropout through the
     # reference's own F.scaled_dot_product_attention (no [S, S] weights in memory): measured x5-x8 of the bounded step on 64 threads
     expect = 3.0 * 8.0 * red["seconds_per_step"]        # warm-up + up to two more steps
@@ -1073,10 +1077,11 @@ def main(argv=None):
         if not args.no_cpu_baseline and world == 1:
             if args.cpu_baseline == "auto":
                 out["cpu_baseline"] = cpu_baseline_auto(args.cpu_baseline_budget, args.layers, args.knn, args.seed,
-                                                        args.atten_dropout, 500000, latent, args.cpu_baseline_dropout)
+                                                        args.atten_dropout, 500000, latent, args.cpu_baseline_dropout,
+                                                        args.cpu_baseline_all_cores)
             else:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline, args.layers, args.knn, args.seed, args.atten_dropout,
-                                                   500000, latent, args.cpu_baseline_dropout)
+                                                   500000, latent, args.cpu_baseline_dropout, args.cpu_baseline_all_cores)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
