@@ -958,7 +958,8 @@ def main(argv=None):
             "config": {"workload": f"{wl}: one {n_total}-point car-like surface sample, latent "
                                    f"{latent[0]}x{latent[1]}x{latent[2]}, {graph_txt}, "
                                    f"C=32 P=2 d=256 h=8 F=1024 L={args.layers} rope, attention dropout {args.atten_dropout} "
-                                   f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step",
+                                   f"(training mode), MSE + AdamW step; CSR build and geoembed stats inside the step (a decoder list that is the "
+                                   f"encoder's with its rows swapped shares the encoder's two lists)",
                        "points": n_total, "latent_tokens": list(latent), "edges": e_enc if world == 1 else n_total * args.knn,
                        "edges_decoder": e_dec if world == 1 else n_total * args.knn, "layers": args.layers,
                        "precision": args.precision, "points_per_gpu": n_total // world, "atten_dropout": args.atten_dropout,

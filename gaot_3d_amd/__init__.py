@@ -5,5 +5,7 @@ from .ops import get_precision, set_precision  # noqa: F401
 
 
 def clear_graph_cache(batch):
-    """Drop the per-batch neighbour lists (row-sorted edge lists) cached by the model on ``batch``."""
+    """Drop the per-batch neighbour lists (row-sorted edge lists) cached by the model on ``batch``: the next forward rebuilds
+    them.  (The per-sample FACT that a decoder edge list is the encoder's with its rows swapped -- `_gaot_flip`, see
+    `model/layers/integral_transform.graph_for` -- is about the inputs, not a list, and stays.)"""
     batch.__dict__.pop("_gaot_graphs", None)

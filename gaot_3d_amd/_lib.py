@@ -72,6 +72,10 @@ SIGNATURES = {
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gaot_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "gaot_colsum": (_i, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
+    "gaot_gemm_ex_partials": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _sz, _p, _p, _p]),
+    "gaot_rmsnorm_bwd_parts": (_i64, [_i64]),
+    "gaot_colsum_parts": (_i64, [_i64]),
+    "gaot_reduce_multi": (_i, [_p, _i, _p]),
     "gaot_rope": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _p, _i, _p]),
     "gaot_swiglu_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_swiglu_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
@@ -135,7 +139,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 9:
+    if lib.gaot_abi_version() != 10:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

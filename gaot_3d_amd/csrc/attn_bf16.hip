@@ -230,9 +230,11 @@ __device__ __forceinline__ void drop_select(f32x16& v, const f32x16& other, uint
 }
 
 // zero the dropped elements of a P tile that is already packed to bf16 (dword j = rows 2j, 2j+1 = the two keys of
-// pair word j): per dword one xor, one packed saturating 16-bit subtract (sign = dropped), one packed arithmetic
-// shift (sign -> 0xFFFF) and one and-not -- 2 VALU ops per element instead of compare + select on fp32.
-// awf = row word ^ 0x80008000 (halfwords as signed), tpk = (thr - 32768) in both halves.
+// pair word j): per dword one xor, one packed saturating 16-bit subtract (sign = KEPT), one packed arithmetic
+// shift (sign -> 0xFFFF) and one and -- 2 VALU ops per element instead of compare + select on fp32.  The subtraction is
+// (thr - 1) - x so that the plain two-operand v_and_b32 applies the mask (4 issue cycles; the and-not form is a three-operand
+// encoding: 5 -- tools/lab/inst_cost.hip).
+// awf = row word ^ 0x80008000 (halfwords as signed), tpk = (thr - 1 - 32768) in both halves (thr >= 1 whenever DROP runs).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf, const uint32_t* bw_tile, int hf, s16x2 tpk) {
@@ -243,9 +245,9 @@ __device__ __forceinline__ void drop_packed(bf16x8& f0, bf16x8& f1, uint32_t awf
     uint32_t pk[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, awf ^ wd[j]), tpk);
+        const s16x2 d = __builtin_elementwise_sub_sat(tpk, __builtin_bit_cast(s16x2, awf ^ wd[j]));   // < 0 iff x > thr - 1 iff kept
         const s16x2 m = d >> (short)15;
-        pk[j] &= ~__builtin_bit_cast(uint32_t, m);
+        pk[j] &= __builtin_bit_cast(uint32_t, m);
     }
     f0 = __builtin_bit_cast(bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
     f1 = __builtin_bit_cast(bf16x8, make_uint4(pk[4], pk[5], pk[6], pk[7]));
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
         aw = gdrop::row_word(gdrop::row_key(seed, bh), (uint32_t)(q0 + l31)) ^ 0x80008000u;
         ck = gdrop::col_key(seed, bh);
     }
-    const short ts = (short)((int)a.drop.thr - 32768);
+    const short ts = (short)((int)a.drop.thr - 1 - 32768);
     const s16x2 tpk = {ts, ts};
 
     // Static bound (FAST, the common case): the image's q rows carry scale * log2(e), so a score is at most |q| max_s |k_s| in
@@ -382,7 +384,19 @@ __global__ __launch_bounds__(256, OCC) void k_attn_fwd_bf16(FwdArgs a) {
                 if constexpr ((FSB & 2) != 0) __builtin_amdgcn_sched_barrier(0);
                 bf16x8 p0, p1;
                 acc_to_frags(sc, p0, p1);
-                {   // l stays undropped; two chains (a ones-row MFMA with the packed P was measured: 2-4 % slower than these adds)
+                if constexpr ((FSB & 8) != 0) {   // row sums of the PACKED (bf16-rounded, undropped) p -- the values the P V product uses: one v_dot2c_f32_bf16 per pair
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                    const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+                    const uint4 ua = __builtin_bit_cast(uint4, p0), ub = __builtin_bit_cast(uint4, p1);
+                    const uint32_t pw[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+                    float q0 = 0.f, q1 = 0.f;
+    #pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pw[j]), ones, q0, false);
+                        q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pw[j + 1]), ones, q1, false);
+                    }
+                    l += q0 + q1;
+                } else {   // l stays undropped; two chains (a ones-row MFMA with the packed P was measured: 2-4 % slower than these adds)
                     float q0 = 0.f, q1 = 0.f;
     #pragma unroll
                     for (int r = 0; r < 16; r += 2) { q0 += sc[r]; q1 += sc[r + 1]; }
@@ -2005,11 +2019,18 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // (K / V stages by LDS-DMA into two stage buffers -- no register staging, no ds_write, ONE barrier per 128 keys, 103 instead
     // of 112 registers -- measured 0.538 / 0.431 ms against 0.524 / 0.424 with / without dropout: the staging is not what the
     // forward waits on; profiles/r4_t_attn_fwd_dma_lab.txt; removed)
+    // row sums of the bound-based tile: with dropout one v_dot2c_f32_bf16 per pair of the packed p (-2 %: 0.524 -> 0.514 ms per layer,
+    // profiles/r5_l_attn_fwd_rowsum_lab.txt), without dropout the 16 fp32 adds (no difference measured there).
+    // GAOT_ATTN_FWD_LAB = 1 / 8 forces the adds / the dot products for both (measurement only).
+    static const int fwd_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_LAB"); return e ? atoi(e) : 0; }();
+    const bool dot2 = fwd_lab == 8 || (fwd_lab != 1 && a.drop.thr);
     if (a.drop.thr) {
-        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true>), fgrid, dim3(256), 0, st, a);
+        if (dot2) GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true, 8>), fgrid, dim3(256), 0, st, a);
+        else GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true>), fgrid, dim3(256), 0, st, a);
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true, false>), fgrid, dim3(256), 0, st, a);
     } else {
-        GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, false, true>), fgrid, dim3(256), 0, st, a);
+        if (dot2) GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, false, true, 8>), fgrid, dim3(256), 0, st, a);
+        else GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, false, true>), fgrid, dim3(256), 0, st, a);
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false, false>), fgrid, dim3(256), 0, st, a);
     }
     if (P > 1)

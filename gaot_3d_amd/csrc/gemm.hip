@@ -357,7 +357,8 @@ extern "C" size_t gaot_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                      int64_t ldc, int a_trans, int b_trans, int dt, const float* bias, int act, const float* residual,
                      int64_t ldr, float* preact, int precision, void* workspace, size_t workspace_bytes,
-                     gaot_stream_t stream) {
+                     gaot_stream_t stream, int* defer_splits = nullptr, int* defer_lanes = nullptr) {
+    if (defer_splits) { *defer_splits = 1; *defer_lanes = 4; }
     GAOT_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative size");
     GAOT_CHECK_ARG(act >= 0 && act <= 3, "bad activation id (the epilogue has none / gelu / relu / silu; others: gaot_act_fwd)");
     GAOT_CHECK_ARG(precision == 0 || precision == 1, "precision must be 0 (fp32) or 1 (bf16 operands)");
@@ -393,7 +394,10 @@ static int gemm_impl(const void* A, const void* B, void* C, int64_t M, int64_t N
     } else if (p.cfg == 0) launch_cfg<4, 1, 1, 1>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else if (p.cfg == 1) launch_cfg<4, 1, 1, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
     else launch_cfg<2, 2, 2, 2>(gk, a_trans, b_trans, precision, a_vec, b_vec, gk.splits, st);
-    if (gk.splits > 1) {
+    if (gk.splits > 1 && defer_splits) {      // the caller sums the partials later (gaot_reduce_multi), in the order k_splitk_reduce would
+        *defer_splits = gk.splits;
+        *defer_lanes = (gk.splits >= 64 && M * N <= 32768) ? 16 : 4;
+    } else if (gk.splits > 1) {
         if (gk.splits >= 64 && M * N <= 32768)
             GAOT_KLAUNCH(k_splitk_reduce<16>, dim3((unsigned)ceil_div(M * N, 16)), dim3(256), 0, st, part, gk.splits, g);
         else
@@ -420,4 +424,20 @@ extern "C" int gaot_gemm_ex(const void* A, const void* B, void* C, int64_t M, in
     const int dt = (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0) | (c_bf16 ? 4 : 0);
     return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, a_trans, b_trans, dt, bias, act, residual, ldr, preact, precision,
                      workspace, workspace_bytes, stream);
+}
+
+// gaot_gemm_ex (no epilogue) whose split-K completion is LEFT TO THE CALLER: when the plan splits the reduction, only the partial
+// products are written ([splits][M*N] fp32 at `workspace`, which the caller keeps) and *splits_out > 1; gaot_reduce_multi sums them
+// later -- with *lanes_out -- in exactly the order the in-call pass uses (bit-identical results).  *splits_out == 1: C is complete.
+// Weight gradients are read by nobody before the optimizer step: a training step hands all of them to ONE reduction launch.
+extern "C" int gaot_gemm_ex_partials(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                     int64_t ldb, int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int precision,
+                                     void* workspace, size_t workspace_bytes, int* splits_out, int* lanes_out,
+                                     gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(splits_out && lanes_out, "null pointer");
+    GAOT_CHECK_ARG(ldc == N, "the deferred completion writes a dense [M][N] result");
+    const int dt = (a_bf16 ? 1 : 0) | (b_bf16 ? 2 : 0);
+    return gemm_impl(A, B, C, M, N, K, lda, ldb, ldc, a_trans, b_trans, dt, nullptr, 0, nullptr, 0, nullptr, precision, workspace,
+                     workspace_bytes, stream, splits_out, lanes_out);
 }

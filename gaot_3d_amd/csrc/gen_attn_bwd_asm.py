@@ -39,6 +39,7 @@ TILE = 2048
 # "lds" = through a wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit).  LDS instructions cost ~13 issue
 # cycles each on the port the vector stream needs (profiles/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
 TR_DROP = os.environ.get("GEN_TR_DROP", "mfma")       # measured: 0.854 (mfma) against 0.896 ms for the compiled kernel on one box, lds 0.838 / 0.843
+DS_FORM = os.environ.get("GEN_DS", "fmac")           # dropout: dS = p (-delta') + (keep p) dP' (mul + fmac) | "select": p select(keep, dP' - delta', -delta') (measurement builds)
 TR_NODROP = os.environ.get("GEN_TR_NODROP", "lds")   # without dropout the unit is MFMA bound: 12 MFMAs cost more than the LDS round trip (0.726 against 0.684 ms)
 
 # ---- register map -----------------------------------------------------------------------------------------------------------
@@ -166,7 +167,8 @@ def gen_stage(drop: bool):
         if i == 0:
             st.ins(f"{MFMA} {vr(SB[b], 16)}, {vr(QA0, 4)}, {kf(kb, 0)}, {vr(LC, 16)}", needs)
         elif i == 1:
-            st.ins(f"{MFMA} {vr(DB[b], 16)}, {vr(DA0, 4)}, {vf(kb, 0)}, {vr(DC[t & 1], 16)}", needs)
+            # with dropout the row constants -delta' enter as a multiplicand of p instead (valu_unit): the product starts from 0
+            st.ins(f"{MFMA} {vr(DB[b], 16)}, {vr(DA0, 4)}, {vf(kb, 0)}, {'0' if (drop and DS_FORM != 'select') else vr(DC[t & 1], 16)}", needs)
         elif i == 2:
             st.ins(f"{MFMA} {vr(SB[b], 16)}, {vr(QA1, 4)}, {kf(kb, 1)}, {vr(SB[b], 16)}")
         else:
@@ -245,12 +247,22 @@ def gen_stage(drop: bool):
             seq.append(lambda p0=p0, r0=r0: st.ins(f"v_exp_f32 {vr(p0)}, {vr(S + r0)}"))
             seq.append(lambda p1=p1, r1=r1: st.ins(f"v_exp_f32 {vr(p1)}, {vr(S + r1)}"))
             if drop:
+                # dS = p (keep dP' - delta') = p (-delta') + (keep p) dP': the dP MFMA starts from C = 0 (DROP_FMAC), the kept p the dV product
+                # needs anyway carries the mask, and the two-operand v_mul_f32 / v_fmac_f32 cost 4 issue cycles where a second
+                # v_cndmask_b32_e64 costs 5 (tools/lab/inst_cost.hip): 13 instead of 14 cycles per element
                 seq.append(lambda pm0=pm0, p0=p0, m0=m0: st.ins(f"v_cndmask_b32_e64 {vr(pm0)}, 0, {vr(p0)}, {m0}"))
-                seq.append(lambda t0=t0, r0=r0, m0=m0: st.ins(f"v_cndmask_b32_e64 {vr(t0)}, {vr(DCt + r0)}, {vr(DP + r0)}, {m0}"))
+                if DS_FORM == "select":
+                    seq.append(lambda t0=t0, r0=r0, m0=m0: st.ins(f"v_cndmask_b32_e64 {vr(t0)}, {vr(DCt + r0)}, {vr(DP + r0)}, {m0}"))
                 seq.append(lambda pm1=pm1, p1=p1, m1=m1: st.ins(f"v_cndmask_b32_e64 {vr(pm1)}, 0, {vr(p1)}, {m1}"))
-                seq.append(lambda t1=t1, r1=r1, m1=m1: st.ins(f"v_cndmask_b32_e64 {vr(t1)}, {vr(DCt + r1)}, {vr(DP + r1)}, {m1}"))
-                seq.append(lambda t0=t0, p0=p0: st.ins(f"v_mul_f32 {vr(t0)}, {vr(p0)}, {vr(t0)}"))
-                seq.append(lambda t1=t1, p1=p1: st.ins(f"v_mul_f32 {vr(t1)}, {vr(p1)}, {vr(t1)}"))
+                if DS_FORM == "select":
+                    seq.append(lambda t1=t1, r1=r1, m1=m1: st.ins(f"v_cndmask_b32_e64 {vr(t1)}, {vr(DCt + r1)}, {vr(DP + r1)}, {m1}"))
+                    seq.append(lambda t0=t0, p0=p0: st.ins(f"v_mul_f32 {vr(t0)}, {vr(p0)}, {vr(t0)}"))
+                    seq.append(lambda t1=t1, p1=p1: st.ins(f"v_mul_f32 {vr(t1)}, {vr(p1)}, {vr(t1)}"))
+                else:
+                    seq.append(lambda t0=t0, p0=p0, r0=r0: st.ins(f"v_mul_f32 {vr(t0)}, {vr(p0)}, {vr(DCt + r0)}"))
+                    seq.append(lambda t1=t1, p1=p1, r1=r1: st.ins(f"v_mul_f32 {vr(t1)}, {vr(p1)}, {vr(DCt + r1)}"))
+                    seq.append(lambda t0=t0, pm0=pm0, r0=r0: st.ins(f"v_fmac_f32 {vr(t0)}, {vr(pm0)}, {vr(DP + r0)}"))
+                    seq.append(lambda t1=t1, pm1=pm1, r1=r1: st.ins(f"v_fmac_f32 {vr(t1)}, {vr(pm1)}, {vr(DP + r1)}"))
                 seq.append(lambda j=j, pm0=pm0, pm1=pm1: st.ins(f"v_cvt_pk_bf16_f32 {vr(PPK + j)}, {vr(pm0)}, {vr(pm1)}"))
             else:
                 seq.append(lambda t0=t0, p0=p0, r0=r0: st.ins(f"v_mul_f32 {vr(t0)}, {vr(p0)}, {vr(DP + r0)}"))

@@ -534,7 +534,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
         if (dweight) hipMemsetAsync(dweight, 0, sizeof(float) * dim, st);
         return GAOT_OK;
     }
-    GAOT_CHECK_ARG(x && weight && dy && rstd && dx && dweight && workspace, "null pointer");
+    GAOT_CHECK_ARG(x && weight && dy && rstd && dx && workspace, "null pointer");
     const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
     float* part = (float*)workspace;
     if (dim == 256 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)weight) & 15) == 0)
@@ -542,10 +542,12 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     else
         GAOT_KLAUNCH(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
                            dx_add, dx, part, rows, dim);
-    GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
+    // dweight == NULL: the gaot_rmsnorm_bwd_parts(rows) partial rows stay in the workspace for gaot_reduce_multi (32 lanes)
+    if (dweight) GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
+extern "C" int64_t gaot_rmsnorm_bwd_parts(int64_t rows) { return ceil_div(rows, 4 * RN_ROWS_PER_WAVE); }
 
 extern "C" size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N) {
     const int64_t chunks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 64)));
@@ -557,9 +559,9 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
     GAOT_ENTER();
     GAOT_CHECK_ARG(M >= 0 && N >= 0, "negative size");
     if (N == 0) return GAOT_OK;
-    GAOT_CHECK_ARG(out, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
+        GAOT_CHECK_ARG(out, "null pointer");
         hipMemsetAsync(out, 0, sizeof(float) * N, st);
         return GAOT_OK;
     }
@@ -573,7 +575,114 @@ extern "C" int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, flo
     else
         GAOT_KLAUNCH(k_colsum_part, dim3((unsigned)ceil_div(N, 32), (unsigned)chunks), dim3(256), 0, st, x, M, N, ld,
                            rpc, part);
-    GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
+    // out == NULL: the gaot_colsum_parts(M) partial rows stay in the workspace for gaot_reduce_multi (32 lanes)
+    if (out) GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(N, RP_COLS)), dim3(256), 0, st, part, chunks, N, out);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+extern "C" int64_t gaot_colsum_parts(int64_t M) { return std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(M, 64))); }
+
+// ---------------------------------------------------------------------------------------------
+// gaot_reduce_multi: out_j[i] = sum_{p < parts_j} part_j[p][i] for up to 64 (partials, output) pairs in ONE launch -- the
+// completion of every split-K weight gradient, RMSNorm weight gradient and bias column sum of a backward pass, deferred to
+// its end (nothing reads them before the optimizer step): ~90 5-us launches of a configs[1] step become two.  A pair keeps the
+// summation order of the pass it replaces: `lanes` part-lanes each sum every lanes-th partial, then the lane sums are added in
+// lane order (4: k_splitk_reduce<64>, 16: k_splitk_reduce<16>, 32: k_reduce_parts) -- bit-identical results, no atomics.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int RM_MAX = 64;
+struct ReduceTable {
+    const float* part[RM_MAX];
+    float* out[RM_MAX];
+    long long n[RM_MAX];
+    int parts[RM_MAX];
+    int lanes[RM_MAX];     // 4, 16 or 32
+    int vec[RM_MAX];       // outputs per thread: 4 (n % 4 == 0, 16-byte aligned) or 1
+    int wide[RM_MAX];      // lanes == 4, 16-byte columns, n >= 16 384: one thread per column, lane sums in registers
+    int blk0[RM_MAX + 1];  // first block of pair j
+    int count;
+};
+__global__ __launch_bounds__(256) void k_reduce_multi(const ReduceTable t) {
+    __shared__ float4 red[256];
+    int j = 0;
+    while (j + 1 < t.count && (int)blockIdx.x >= t.blk0[j + 1]) ++j;     // uniform: <= 64 scalar compares
+    const int lanes = t.lanes[j], cols = 256 / lanes, vec = t.vec[j];
+    const int o = threadIdx.x % cols, sl = threadIdx.x / cols;
+    const long long n = t.n[j];
+    const long long i = ((long long)(blockIdx.x - t.blk0[j]) * cols + o) * vec;
+    const float* __restrict__ part = t.part[j];
+    const int parts = t.parts[j];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t.wide[j]) {
+        // wide tables of a few partials (the Transformer's split-K weight gradients: n = 65 K .. 524 K outputs, 8 .. 32 partials):
+        // a thread owns one 16-byte column and keeps the FOUR lane sums itself -- no LDS, no barrier, every load independent and
+        // non-temporal (the partials were written once, long ago, and are read once); ((l0 + l1) + l2) + l3 as above
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const long long c = ((long long)(blockIdx.x - t.blk0[j]) * 256 + threadIdx.x) * 4;
+        if (c >= n) return;
+        f4v acc[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[l] = (f4v){0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ p0 = part + c;
+        int s = 0;
+        for (; s + 4 <= parts; s += 4) {
+            f4v a[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) a[l] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p0 + (long long)(s + l) * n));
+#pragma unroll
+            for (int l = 0; l < 4; ++l) acc[l] += a[l];
+        }
+        for (int l = 0; s < parts; ++s, ++l) acc[l] += __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p0 + (long long)s * n));
+        const f4v r = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+        *reinterpret_cast<f4v*>(t.out[j] + c) = r;
+        return;
+    }
+    if (i < n) {
+        if (vec == 4) {
+            for (int s = sl; s < parts; s += lanes) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v a = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(part + (long long)s * n + i));
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+        } else {
+            for (int s = sl; s < parts; s += lanes) v.x += part[(long long)s * n + i];
+        }
+    }
+    red[sl * cols + o] = v;
+    __syncthreads();
+    if (sl != 0 || i >= n) return;
+    v = red[o];
+    for (int l = 1; l < lanes; ++l) {
+        const float4 a = red[l * cols + o];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (vec == 4) *reinterpret_cast<float4*>(t.out[j] + i) = v;
+    else t.out[j][i] = v.x;
+}
+}  // namespace
+
+extern "C" int gaot_reduce_multi(const gaot_reduce_desc_t* descs, int count, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(count >= 0 && (count == 0 || descs), "bad descriptor list");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += RM_MAX) {
+        ReduceTable t;
+        t.count = std::min(RM_MAX, count - base);
+        long long blocks = 0;
+        for (int j = 0; j < t.count; ++j) {
+            const gaot_reduce_desc_t& d = descs[base + j];
+            GAOT_CHECK_ARG(d.part && d.out && d.n >= 0 && d.parts >= 1 && (d.lanes == 4 || d.lanes == 16 || d.lanes == 32),
+                           "reduce descriptor: null pointer, parts < 1 or lanes not in {4, 16, 32}");
+            t.part[j] = d.part; t.out[j] = d.out; t.n[j] = d.n; t.parts[j] = d.parts; t.lanes[j] = d.lanes;
+            t.vec[j] = (d.n % 4 == 0 && (((uintptr_t)d.part | (uintptr_t)d.out) & 15) == 0) ? 4 : 1;
+            t.wide[j] = (d.lanes == 4 && t.vec[j] == 4 && d.n >= 16384) ? 1 : 0;
+            t.blk0[j] = (int)blocks;
+            blocks += t.wide[j] ? ceil_div(d.n, 1024LL) : ceil_div(d.n, (long long)(256 / d.lanes) * t.vec[j]);
+            GAOT_CHECK_ARG(blocks < 0x7fffffff, "reduce descriptors: too many outputs for one launch");
+        }
+        t.blk0[t.count] = (int)blocks;
+        if (blocks > 0) GAOT_KLAUNCH(k_reduce_multi, dim3((unsigned)blocks), dim3(256), 0, st, t);
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -79,13 +79,15 @@ def _wb(w: Tensor, precision: Optional[int]) -> Tensor:
     return w
 
 
-def _dw_gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, precision) -> Tensor:
+def _dw_gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, precision, params=None) -> Tensor:
     """a weight-gradient product dW[m, n] = a^T b over the rows.  Nothing in the backward chain reads it, so with a side stream
     set (``ShardedStep(overlap_dw=True)`` -> ``comm.set_side_stream``) it is issued there, beside the chain's kernels and the
-    exchange steps, and joined once before the optimizer (``comm.side_join``); otherwise a plain call."""
+    exchange steps, and joined once before the optimizer (``comm.side_join``); otherwise a plain call -- whose split-K completion,
+    when the caller names the parameters the product is the gradient of (``params``) and ``ops.defer_ok`` vouches for them, is
+    left to the ONE reduction launch at the end of the backward pass."""
     from . import comm
     if comm.side_stream() is None:
-        return ops.gemm(a, b, m, n, k, lda, ldb, True, False, precision=precision)
+        return ops.gemm_dw(a, b, m, n, k, lda, ldb, precision, defer=ops.defer_ok(params))
     out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     comm.side_run(lambda: ops.gemm(a, b, m, n, k, lda, ldb, True, False, out=out, ldc=n, precision=precision), (a, b, out))
     return out
@@ -125,6 +127,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x2, w, z)
         ctx.act, ctx.has_bias, ctx.precision = act, bias is not None, precision
         ctx.wshape, ctx.xshape = weight.shape, x.shape
+        ctx.wparam, ctx.bparam = weight, bias     # the parameters themselves (the saved w may be a bf16 copy): ops.defer_ok
         ctx.res_shape = residual.shape if residual is not None else None
         return y.view(*x.shape[:-1], n)
 
@@ -142,11 +145,11 @@ class LinearFn(Function):
             dx = ops.gemm(dz, w, m, k, n, n, k, False, False, precision=ctx.precision).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             if n == 1:   # dW[0][:] = sum_m dz[m] x[m][:] -- put the wide dimension on the tile rows instead
-                dw = _dw_gemm(x2, dz, k, 1, m, k, 1, ctx.precision).view(ctx.wshape)
+                dw = _dw_gemm(x2, dz, k, 1, m, k, 1, ctx.precision, (ctx.wparam,)).view(ctx.wshape)
             else:
-                dw = _dw_gemm(dz, x2, n, k, m, n, k, ctx.precision).view(ctx.wshape)
+                dw = _dw_gemm(dz, x2, n, k, m, n, k, ctx.precision, (ctx.wparam,)).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dz, m, n, n)
+            db = ops.colsum(dz, m, n, n, defer=ops.defer_ok((ctx.bparam,)))
         if ctx.res_shape is not None and ctx.needs_input_grad[5]:
             dres = dy2.view(ctx.res_shape)
         return dx, dw, db, None, None, dres
@@ -217,7 +220,7 @@ class RMSNormFn(Function):
         if dy is None:
             dy = torch.zeros_like(x)
         d = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd)
+        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, defer=ops.defer_ok((w,)))
         return dx, dw, None
 
 
@@ -278,7 +281,7 @@ class RMSNormResFn(Function):
         if dy is None:
             dy = torch.zeros_like(x)
         d = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, None if dres is None else dres.reshape(x.shape))
+        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, None if dres is None else dres.reshape(x.shape), defer=ops.defer_ok((w,)))
         return dx, dw, None
 
 
@@ -532,6 +535,7 @@ class FFNFn(Function):
         empty = w2c.new_empty(0)
         ctx.save_for_backward(xa, wcat, w2c, ag, u, wcat_t if wcat_t is not None else empty, w2t if w2t is not None else empty)
         ctx.res_is_x = res_is_x
+        ctx.wparams = (w1, w3, w2)
         ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
         return y.view(*x.shape[:-1], d)
 
@@ -550,10 +554,10 @@ class FFNFn(Function):
             dyb = ops.cast_bf16(dy2)
             du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,
                           out_dtype=torch.bfloat16)
-            dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1).view(w2shape)
+            dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         else:
             du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
-            dw2 = _dw_gemm(dy2, u, d, f, m, d, f, 1).view(w2shape)
+            dw2 = _dw_gemm(dy2, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -565,7 +569,7 @@ class FFNFn(Function):
             else:
                 dx = ops.gemm(dag, wcat, m, d, 2 * f, 2 * f, d, False, False, residual=dy2 if ctx.res_is_x else None, ldr=d,
                               precision=1).view(xshape)
-        dwcat = _dw_gemm(dag, x2, 2 * f, d, m, 2 * f, d, 1)
+        dwcat = _dw_gemm(dag, x2, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
         dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
         return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None
 
@@ -714,6 +718,7 @@ class MultiLinearFn(Function):
         m = x2.shape[0]
         ntot = sum(w.shape[0] for w in ws)
         ctx.fused = len(ws) > 1 and _adjacent(ws) and all(ctx.needs_input_grad[3 + i] for i in range(len(ws)))
+        ctx.wparams = tuple(weights)
         if ctx.fused:   # the weights are slices of one buffer (colocate): one [ntot, k] matrix, one GEMM
             wcat = _wb(ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, k), (k, 1)), precision)
             xb = bf16_copy_of(x, (m, k)) if wcat.dtype == torch.bfloat16 else None
@@ -753,7 +758,7 @@ class MultiLinearFn(Function):
             (wcat,) = ws
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(d, wcat, m, k, ntot, ntot, k, False, False, precision=ctx.precision)
-            dwcat = _dw_gemm(d, x2, ntot, k, m, ntot, k, ctx.precision)
+            dwcat = _dw_gemm(d, x2, ntot, k, m, ntot, k, ctx.precision, ctx.wparams)
             for shp in ctx.wshapes:
                 n = shp[0]
                 dws.append(dwcat[col:col + n].view(shp))
@@ -764,7 +769,7 @@ class MultiLinearFn(Function):
             blk = d[:, col:]
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(blk, w, m, k, n, ntot, k, False, False, residual=dx, ldr=k, precision=ctx.precision)
-            dws.append(_dw_gemm(blk, x2, n, k, m, ntot, k, ctx.precision).view(ctx.wshapes[i])
+            dws.append(_dw_gemm(blk, x2, n, k, m, ntot, k, ctx.precision, ctx.wparams[i:i + 1]).view(ctx.wshapes[i])
                        if ctx.needs_input_grad[3 + i] else None)
             col += n
         return (dx.view(ctx.xshape) if dx is not None else None, None, None, *dws)

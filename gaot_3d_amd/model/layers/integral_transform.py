@@ -17,19 +17,47 @@ from ... import ops
 from .mlp import LinearChannelMLP, activation_name
 
 
+def _is_flip_of_encoder(cache_owner, slot, dec_ei: torch.Tensor, enc_ei: torch.Tensor) -> bool:
+    """Is this decoder edge list the encoder's with its two rows swapped (the shipped configuration: knn encoder, "flipped"
+    decoder)?  A fact about the SAMPLE's inputs, found once per pair of tensors (object identity + in-place version) with two
+    device comparisons and kept on the batch beside -- not inside -- the neighbour-list cache, so `clear_graph_cache` (a step that
+    rebuilds its lists) does not repeat the host synchronisation.  Never evaluated while a hipGraph is being captured."""
+    facts = cache_owner.__dict__.setdefault("_gaot_flip", {})
+    ent = facts.get(slot)
+    if ent is not None and ent[0] is dec_ei and ent[1] == dec_ei._version and ent[2] is enc_ei and ent[3] == enc_ei._version:
+        return ent[4]
+    if dec_ei.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False
+    flip = bool(dec_ei.shape == enc_ei.shape and dec_ei.dtype == enc_ei.dtype and dec_ei.device == enc_ei.device
+                and torch.equal(dec_ei[0], enc_ei[1]) and torch.equal(dec_ei[1], enc_ei[0]))
+    facts[slot] = (dec_ei, dec_ei._version, enc_ei, enc_ei._version, flip)
+    return flip
+
+
 def graph_for(edge_index: torch.Tensor, num_src: int, num_dst: int, cache_owner=None, key=None):
     """Row-sorted neighbour lists for one edge_index; cached on the batch object so that encoder GNO, GeoEmbed and the
     backward pass share one build per sample and scale.  An entry is valid only for the very tensor it was built from
     (object identity and in-place version counter; the entry keeps the tensor alive, so its address cannot be handed to
     another edge list meanwhile): edges rebuilt or re-uploaded per forward replace the entry of their slot, they never
-    hit a stale one, and the cache holds one entry per (side, scale)."""
+    hit a stale one, and the cache holds one entry per (side, scale).
+    A decoder list that is the encoder's with the rows swapped needs no build of its own: sorted by query it IS the encoder's
+    list sorted by source and vice versa (same edge order, same stable sort: identical arrays), so the decoder's graph shares the
+    encoder's two lists -- two radix-sort builds per step instead of four (0.36 ms at E = 4 M, ~5 ms at E = 64 M)."""
     if cache_owner is not None:
         cache = cache_owner.__dict__.setdefault("_gaot_graphs", {})
         k = (key, num_src, num_dst)
         ent = cache.get(k)
         if ent is not None and ent[0] is edge_index and ent[1] == edge_index._version:
             return ent[2]
-        g = ops.build_graph(edge_index, num_src, num_dst)
+        g = None
+        if isinstance(key, tuple) and len(key) == 2 and key[0] == "dec":
+            enc = cache.get((("enc", key[1]), num_dst, num_src))
+            if (enc is not None and enc[1] == enc[0]._version
+                    and _is_flip_of_encoder(cache_owner, key[1], edge_index, enc[0])):
+                ge = enc[2]
+                g = ops.BipartiteGraph(ge.by_src, ge.by_dst, num_src, num_dst)
+        if g is None:
+            g = ops.build_graph(edge_index, num_src, num_dst)
         cache[k] = (edge_index, edge_index._version, g)
         return g
     return ops.build_graph(edge_index, num_src, num_dst)

@@ -3,6 +3,7 @@ pass raw pointers to libgaot3d_hip.so.  Every function requires CUDA(HIP) tensor
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -248,10 +249,118 @@ def gemm(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, a_tra
     return (out, pre) if want_preact else out
 
 
-def colsum(x: Tensor, m: int, n: int, ld: int) -> Tensor:
+# ---- deferred completion of fixed-order reductions (include/gaot3d_hip.h, ABI 10) -------------------------------------------------
+# Weight gradients are read by nobody before the optimizer step.  Their producers (split-K dy^T x products, RMSNorm weight
+# gradients, bias column sums) leave their partials in a workspace; ONE gaot_reduce_multi launch at the end of the backward pass
+# (an autograd-engine final callback: it runs before loss.backward() / torch.autograd.grad() return) sums them in the very order
+# the in-call passes use -- the values are bit-identical, ~90 launches of ~5 us per configs[1] step become two.
+class _ReduceDesc(C.Structure):   # gaot_reduce_desc_t
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("parts", C.c_int32), ("lanes", C.c_int32)]
+
+
+_DEFER = {"enabled": os.environ.get("GAOT_DEFER_REDUCE", "1") != "0", "task": -1, "pending": [], "seen": set()}
+
+
+def defer_reductions(enabled: bool) -> bool:
+    """switch the deferral on / off (default on; GAOT_DEFER_REDUCE=0); returns the previous setting"""
+    prev, _DEFER["enabled"] = _DEFER["enabled"], bool(enabled)
+    return prev
+
+
+def defer_ok(params) -> bool:
+    """May the gradients of these parameters be completed at the end of the running backward pass?  Only inside a backward pass,
+    and only for plain leaf parameters that nothing can observe earlier: no gradient to accumulate into yet (AccumulateGrad then
+    takes the returned tensor itself, no arithmetic on it), no tensor / post-accumulate hooks (gradient buckets of a sharded step,
+    user hooks), no process group with peers (DDP's reducer), no create_graph / anomaly mode; a parameter that turns up a second
+    time in the same pass completes everything pending first.  ``params=None`` (callers that cannot name their parameters): no."""
+    if params is None or not _DEFER["enabled"]:
+        return False
+    # a process group with peers: DistributedDataParallel / FSDP hang C++ post hooks on the gradient accumulators (invisible from
+    # Python) that copy a gradient into a bucket the moment it is accumulated -- never defer beside them
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0 or torch.is_grad_enabled() or torch.is_anomaly_enabled():   # not in a backward pass / create_graph / NaN checks
+        return False
+    if _DEFER["task"] != task:
+        # a new backward pass: whatever a pass that died half-way left behind is dropped with it
+        _DEFER["pending"], _DEFER["seen"] = [], set()
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+        _DEFER["task"] = task
+    ok = True
+    for p in params:
+        if p is None:
+            continue
+        if (not p.is_leaf) or p.grad_fn is not None or p.grad is not None or p._backward_hooks \
+                or getattr(p, "_post_accumulate_grad_hooks", None):
+            ok = False
+        if id(p) in _DEFER["seen"]:
+            # the parameter is used twice in this graph: the engine is about to ADD this gradient to the one deferred earlier --
+            # complete everything pending now (same stream, ahead of that add) and take the in-call pass
+            _flush_pending()
+            ok = False
+    if ok:
+        _DEFER["seen"].update(id(p) for p in params if p is not None)
+    return ok
+
+
+def _defer(part: Tensor, out: Tensor, n: int, parts: int, lanes: int) -> None:
+    # `out` is about to be handed to autograd: keep its STORAGE alive, not the tensor -- a second reference to the returned tensor
+    # (a view of it holds one too: its base) would make AccumulateGrad clone it, a copy of values that do not exist yet
+    _DEFER["pending"].append((part, out.untyped_storage(), out.data_ptr(), int(n), int(parts), int(lanes)))
+
+
+def flush_deferred() -> None:
+    """sum every pending partial table into its output (one launch per 64 tables); called by the autograd engine at the end of the
+    backward pass that deferred them"""
+    _DEFER["task"], _DEFER["seen"] = -1, set()
+    _flush_pending()
+
+
+def _flush_pending() -> None:
+    pend, _DEFER["pending"] = _DEFER["pending"], []
+    if not pend:
+        return
+    arr = (_ReduceDesc * len(pend))()
+    for i, (part, _keep, out_ptr, n, parts, lanes) in enumerate(pend):
+        arr[i].part, arr[i].out, arr[i].n, arr[i].parts, arr[i].lanes = part.data_ptr(), out_ptr, n, parts, lanes
+    check(_lib.load().gaot_reduce_multi(arr, len(pend), _stream()), "gaot_reduce_multi")
+
+
+def deferred_pending() -> int:
+    return len(_DEFER["pending"])
+
+
+def gemm_dw(a: Tensor, b: Tensor, m: int, n: int, k: int, lda: int, ldb: int, precision: Optional[int] = None,
+            defer: bool = False) -> Tensor:
+    """the weight-gradient product dW[m, n] = a^T b (a [k, lda], b [k, ldb], reduction over the k rows); ``defer``: its split-K
+    completion waits for flush_deferred (see defer_ok)"""
+    if not defer:
+        return gemm(a, b, m, n, k, lda, ldb, True, False, precision=precision)
+    lib = _lib.load()
+    dev = a.device
+    out = torch.empty(m, n, dtype=torch.float32, device=dev)
+    nb = lib.gaot_gemm_workspace_bytes(m, n, k)
+    ws = _ws(nb, dev) if nb else None
+    prec = _PRECISION["mode"] if precision is None else precision
+    splits, lanes = C.c_int(0), C.c_int(0)
+    check(lib.gaot_gemm_ex_partials(_ptr(a), _ptr(b), _ptr(out), m, n, k, lda, ldb, n, 1, 0, int(a.dtype == torch.bfloat16),
+                                    int(b.dtype == torch.bfloat16), prec, _ptr(ws), ws.numel() if ws is not None else 0,
+                                    C.byref(splits), C.byref(lanes), _stream()), "gaot_gemm_ex_partials")
+    if splits.value > 1:
+        _defer(ws, out, m * n, splits.value, lanes.value)
+    return out
+
+
+def colsum(x: Tensor, m: int, n: int, ld: int, defer: bool = False) -> Tensor:
     lib = _lib.load()
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     ws = _ws(lib.gaot_colsum_workspace_bytes(m, n), x.device)
+    if defer and m > 0 and n > 0:
+        check(lib.gaot_colsum(_ptr(x), m, n, ld, None, _ptr(ws), ws.numel(), _stream()), "gaot_colsum")
+        _defer(ws, out, n, lib.gaot_colsum_parts(m), 32)
+        return out
     check(lib.gaot_colsum(_ptr(x), m, n, ld, _ptr(out), _ptr(ws), ws.numel(), _stream()), "gaot_colsum")
     return out
 
@@ -317,7 +426,8 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, want_bf16: bool = False):
     return y, rstd, yb
 
 
-def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None):
+def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None, defer: bool = False):
+    """``defer``: the weight gradient's partial rows are summed by flush_deferred (see defer_ok)"""
     lib = _lib.load()
     d = x.shape[-1]
     rows = x.numel() // d
@@ -326,8 +436,11 @@ def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional
     ws = _ws(lib.gaot_rmsnorm_bwd_workspace_bytes(rows, d), x.device)
     if dx_add is not None:
         dx_add = _req(dx_add, torch.float32, "dx_add")
-    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx), _ptr(dw), rows, d, _ptr(ws),
-                               ws.numel(), _stream()), "gaot_rmsnorm_bwd")
+    defer = defer and rows > 0
+    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx), None if defer else _ptr(dw), rows, d,
+                               _ptr(ws), ws.numel(), _stream()), "gaot_rmsnorm_bwd")
+    if defer:
+        _defer(ws, dw, d, lib.gaot_rmsnorm_bwd_parts(rows), 32)
     return dx, dw
 
 

@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 9
+#define GAOT_ABI_VERSION 10
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -239,6 +239,29 @@ int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const
 size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N);
 int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, float* out, void* workspace, size_t workspace_bytes,
                 gaot_stream_t stream);
+/* Deferred completion of fixed-order reductions (ABI 10).  The weight gradients of a backward pass (split-K products dy^T x of the
+ * nn.Linear sites, reference attn.py:104-106,127,146-156; RMSNorm weights, attn.py:205-230; bias column sums) are read by nobody
+ * before the optimizer step, so their final "sum the partials" passes -- ~90 launches of ~5 us in a configs[1] step -- can be
+ * handed to ONE launch at the end of the backward pass:
+ *   gaot_gemm_ex_partials : gaot_gemm_ex (no epilogue, dense C) that leaves the split-K partials [splits][M*N] in `workspace` when
+ *                           its plan splits K (*splits_out > 1; the caller keeps the workspace alive); *splits_out == 1: C is complete
+ *   gaot_rmsnorm_bwd with dweight == NULL, gaot_colsum with out == NULL: the gaot_rmsnorm_bwd_parts(rows) x dim /
+ *                           gaot_colsum_parts(M) x N partial rows stay in the workspace (lanes = 32)
+ *   gaot_reduce_multi     : out_j[i] = sum_p part_j[p*n_j + i] for every descriptor, `lanes` part-lanes summing every lanes-th
+ *                           partial and the lane sums added in lane order -- the order of the in-call passes, bit-identical results */
+typedef struct {
+    const float* part;   /* [parts][n] */
+    float* out;          /* [n] */
+    int64_t n;
+    int32_t parts;
+    int32_t lanes;       /* 4, 16 (what gaot_gemm_ex_partials reports) or 32 */
+} gaot_reduce_desc_t;
+int gaot_gemm_ex_partials(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldc, int a_trans, int b_trans, int a_bf16, int b_bf16, int precision, void* workspace,
+                          size_t workspace_bytes, int* splits_out, int* lanes_out, gaot_stream_t stream);
+int64_t gaot_rmsnorm_bwd_parts(int64_t rows);
+int64_t gaot_colsum_parts(int64_t M);
+int gaot_reduce_multi(const gaot_reduce_desc_t* descs, int count, gaot_stream_t stream);
 int gaot_rope(float* x, int64_t rows, int64_t ld, int col0, int nheads, int head_dim, int seq_len, const float* freqs,
               int inverse, gaot_stream_t stream);
 int gaot_swiglu_fwd(const float* ag, float* u, int64_t rows, int F, gaot_stream_t stream);

@@ -363,6 +363,37 @@ def test_integral_transform_other_shapes_golden(precision):
 
 
 @pytest.mark.gpu
+def test_flipped_decoder_graph_shares_the_encoder_lists():
+    """the shipped configuration's decoder edge list is the encoder's with its rows swapped (a separate tensor): sorted by query
+    it IS the encoder's list sorted by source and vice versa, so `graph_for` hands the decoder the encoder's two lists instead of
+    two more radix-sort builds -- identical arrays to a build of its own, and a list that is NOT the flip still gets its own"""
+    from gaot_3d_amd import ops
+    from gaot_3d_amd.data import make_synthetic_sample
+    from gaot_3d_amd.model.layers.integral_transform import graph_for
+    batch, tokens = make_synthetic_sample(20000, (8, 8, 4), k=5, seed=3, device=DEV)
+    n, m = batch.pos.shape[0], tokens.shape[0]
+    enc, dec = batch.encoder_edge_index_s0, batch.decoder_edge_index_s0
+    assert dec.data_ptr() != enc.data_ptr() and torch.equal(dec, enc.flip(0))
+    ge = graph_for(enc, n, m, batch, ("enc", 0))
+    gd = graph_for(dec, m, n, batch, ("dec", 0))
+    assert gd.by_dst is ge.by_src and gd.by_src is ge.by_dst and (gd.num_src, gd.num_dst) == (m, n)
+    own = ops.build_graph(dec, m, n)
+    for a, b in ((gd.by_dst, own.by_dst), (gd.by_src, own.by_src)):
+        assert a.num_rows == b.num_rows
+        for f in ("rowptr", "perm", "key", "other"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+    import gaot_3d_amd
+    gaot_3d_amd.clear_graph_cache(batch)            # the lists go, the fact about the inputs stays
+    assert "_gaot_graphs" not in batch.__dict__ and batch.__dict__["_gaot_flip"][0][4] is True
+    other = dec.clone()
+    other[:, [0, 7]] = other[:, [7, 0]]             # same edge set, another order: not the flip -> its own build
+    batch.decoder_edge_index_s0 = other
+    ge = graph_for(enc, n, m, batch, ("enc", 0))
+    g2 = graph_for(other, m, n, batch, ("dec", 0))
+    assert g2.by_dst is not ge.by_src and torch.equal(g2.by_dst.rowptr, own.by_dst.rowptr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_integral_transform_hidden_widths_golden(precision):
     """kernel-MLP hidden widths other than 64 (`in_/out_gno_channel_mlp_hidden_layers` are free lists, magno.py:32,36) against
