@@ -102,6 +102,7 @@ SIGNATURES = {
     "gaot_cast_bf16_transpose_multi": (_i, [_p, _p, _p, _i, _p]),
     "gaot_swiglu_fwd_bf16": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_ffn_w13_swiglu": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "gaot_ffn_w2_bwd_swiglu": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_fwd": (_i, [_p, _p, _i64, _i, _p]),

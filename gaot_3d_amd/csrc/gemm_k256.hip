@@ -26,7 +26,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // what the epilogue writes: fp32 C, bf16 C, or the attention kernels' bf16 image of a fused q|k|v projection (RoPE applied to
 // the q and k heads from a [S][16] (cos, sin) table, q pre-scaled): the fp32 projection then never exists in HBM
-enum { OUT_F32 = 0, OUT_BF16 = 1, OUT_QKV_IMAGE = 2, OUT_SWIGLU = 3 };
+// OUT_SWIGLU_BWD (gaot_ffn_w2_bwd_swiglu): the product is du = dy W2 (N = F columns); the epilogue reads a | g (bf16 [M][2F]) at the
+// tile's own positions and writes da | dg (bf16 [M][2F]) -- du itself never exists in HBM and the stand-alone SwiGLU backward pass
+// (a read of a | g, a read of du, a write of da | dg) is gone
+enum { OUT_F32 = 0, OUT_BF16 = 1, OUT_QKV_IMAGE = 2, OUT_SWIGLU = 3, OUT_SWIGLU_BWD = 4 };
 struct ImageArgs {
     const float* table;   // [S][16][2] = (cos, sin) of position * frequency, or null (no RoPE)
     int S, nq, nk;        // rows per sequence, number of q heads, of k heads (32 columns each; the rest are v heads)
@@ -36,7 +39,7 @@ struct ImageArgs {
     int pack_g;
     // OUT_SWIGLU (gaot_ffn_w13_swiglu): W = [w1; w3] ([2F][256]); a wave's two 32-column tiles are columns n .. n+31 of w1 x and the
     // SAME columns of w3 x, so the epilogue writes a | g (bf16 [M][2F], kept for the backward) and u = silu(a) g (bf16 [M][F])
-    void* u;
+    void* u;              // OUT_SWIGLU_BWD: the a | g input (read only)
     int F;
 };
 
@@ -55,21 +58,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
     const bool wave_ok = MODE == OUT_SWIGLU ? n0 < im.F : n0 < N;   // N % 64 == 0 (F % 32 == 0): all inside or all outside
 
     // the wave's weight slice as MFMA fragments: element (n = l31, k = 16 s + 8 hf + 0..7) of column tile jt
+    // OUT_SWIGLU_BWD's epilogue needs 8 registers more than there are beside 128 of weights and 64 of accumulators: the last RELOAD
+    // weight fragments of column tile 1 are not kept across the epilogue but fetched again (L2 hits, 16 bytes per lane each) at the
+    // top of every row block, long before the k-steps that use them -- no scratch (a kernel with scratch pays ~5 us of idle queue
+    // on either side of its launch)
+    constexpr int RELOAD = MODE == OUT_SWIGLU_BWD ? 3 : 0;
     bf16x8 bw[2][16];
+    const bf16_t* wrow1 = nullptr;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         int n = (MODE == OUT_SWIGLU ? n0 + jt * im.F : n0 + 32 * jt) + l31;
         n = n < N ? n : N - 1;
         const bf16_t* p = W + (int64_t)n * ldw + 8 * hf;
+        if (jt == 1) wrow1 = p;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bw[jt][s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+        for (int s = 0; s < 16; ++s)
+            if (!(jt == 1 && s >= 16 - RELOAD)) bw[jt][s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
     }
 
     const int64_t abytes = (int64_t)M * lda * 2, cbytes = (int64_t)M * ldc * (C16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(abytes > 0x7fffffff ? 0x7fffffff : abytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(cbytes > 0x7fffffff ? 0x7fffffff : cbytes), 0x00020000);
-    const int64_t ubytes = MODE == OUT_SWIGLU ? (int64_t)M * im.F * 2 : 0;
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(MODE == OUT_SWIGLU ? im.u : C, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
+    const int64_t ubytes = MODE == OUT_SWIGLU ? (int64_t)M * im.F * 2 : (MODE == OUT_SWIGLU_BWD ? (int64_t)M * im.F * 4 : 0);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((MODE == OUT_SWIGLU || MODE == OUT_SWIGLU_BWD) ? im.u : C, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == OUT_QKV_IMAGE ? im.table : nullptr), 0,
                                                                          MODE == OUT_QKV_IMAGE && im.table ? im.S * 128 : 0, 0x00020000);
     auto stage = [&](int t, int buf) {
@@ -92,6 +103,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
         const int buf = (t - t0) & 1;
         __builtin_amdgcn_s_barrier();            // block t has landed for every wave; nobody still reads the other buffer
         if (t + 1 < t1) stage(t + 1, buf ^ 1);
+        if constexpr (RELOAD > 0) {
+            const bf16_t* pw = wrow1;
+            asm volatile("" : "+v"(pw));         // a new value every row block: the loads stay inside the loop
+#pragma unroll
+            for (int s = 16 - RELOAD; s < 16; ++s) bw[1][s] = *reinterpret_cast<const bf16x8*>(pw + 16 * s);
+        }
         f32x16 acc[2][2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -159,7 +176,53 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                         acc[jt][i][4 * q + 2] = v2 * sc; acc[jt][i][4 * q + 3] = v3 * sc;
                     }
                 }
-                if constexpr (C16) {
+                if constexpr (MODE == OUT_SWIGLU_BWD) {
+                    // the lane's columns of this tile: 8q + 4hf .. + 3 (q = 0..3) of du, of a and of g; da | dg leave through the same
+                    // half-wave pairing as every bf16 result.  Arithmetic of k_swiglu_bwd_bf16 (rowops.hip) on the ROUNDED du.
+                    const unsigned grow = (m < M && wave_ok) ? (unsigned)m * (unsigned)im.F * 4u : 0x80000000u;
+                    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                    auto rb = [](float v) { return __uint_as_float((unsigned)__builtin_bit_cast(bf16_t, (__bf16)v) << 16); };
+                    const unsigned orow = (m < M && wave_ok) ? (unsigned)m * (unsigned)ldc * 2u : 0x80000000u;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {   // the runs (qq, qq + 2) leave together (half-wave pairing): 4 loads live at a time
+                        u32x2v av[2], gv[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {   // one address register (row + half-wave), the column in the scalar offset
+                            const int nsc = (ncol + 8 * (qq + 2 * h)) * 2;
+                            av[h] = __builtin_bit_cast(u32x2v, __builtin_amdgcn_raw_buffer_load_b64(urs, grow + 8 * hf, nsc, 0));
+                            gv[h] = __builtin_bit_cast(u32x2v, __builtin_amdgcn_raw_buffer_load_b64(urs, grow + 8 * hf, nsc + im.F * 2, 0));
+                        }
+                        unsigned pa[2][2], pg[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int q = qq + 2 * h;
+                            float da[4], dg[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned aw = av[h][e >> 1], gw = gv[h][e >> 1];
+                                const float a = __uint_as_float((e & 1) ? (aw & 0xffff0000u) : (aw << 16));
+                                const float g = __uint_as_float((e & 1) ? (gw & 0xffff0000u) : (gw << 16));
+                                const float d = rb(acc[jt][i][4 * q + e]);
+                                const float sg = 1.f / (1.f + __expf(-a));
+                                da[e] = d * g * sg * (1.f + a * (1.f - sg));
+                                dg[e] = d * a * sg;
+                            }
+                            pa[h][0] = pack2(da[0], da[1]); pa[h][1] = pack2(da[2], da[3]);
+                            pg[h][0] = pack2(dg[0], dg[1]); pg[h][1] = pack2(dg[2], dg[3]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(pa[0][0], pa[1][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(pa[0][1], pa[1][1], false, false);
+                        const u32x4 va = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pg[0][0], pg[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pg[0][1], pg[1][1], false, false);
+                        const u32x4 vg = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                        const int nsc = (ncol + 8 * qq) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b128(va, crs, orow + 32 * hf, nsc, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(vg, crs, orow + 32 * hf, nsc + im.F * 2, 0);
+                        __builtin_amdgcn_sched_barrier(0);   // keep the next runs' loads behind these stores: 256 registers, no scratch
+                    }
+                } else if constexpr (C16) {
                     unsigned pk[4][2];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -321,6 +384,23 @@ extern "C" int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, voi
     }
     const ImageArgs im{nullptr, 1, 0, 0, 1.0f, 1, u, F};
     return launch_k256<OUT_SWIGLU>(x_bf16, w13_bf16, ag, (int)rows, 2 * F, (int)lda, (int)ldw, 2 * F, im, (hipStream_t)stream);
+}
+
+// The input gradient of the FFN's second projection with the SwiGLU backward in its epilogue (reference attn.py:155-157, autograd of
+// w2(silu(w1 x) * w3 x)): dy [rows][256] bf16, w2t = W2^T ([F][256] bf16), ag = w1 x | w3 x (bf16 [rows][2F], saved by the forward)
+// -> dag = d(a) | d(g) (bf16 [rows][2F]).  Stands in for gaot_gemm_ex (du = dy W2, bf16 result) + gaot_swiglu_bwd_bf16: du is
+// rounded to bf16 exactly as the stored one was, so the values are the two-pass values.
+extern "C" int gaot_ffn_w2_bwd_swiglu(const void* dy_bf16, const void* w2t_bf16, const void* ag, void* dag, int64_t rows, int64_t lda,
+                                      int64_t ldw, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(dy_bf16 && w2t_bf16 && ag && dag && rows > 0 && F > 0, "bad argument");
+    if (F % 64 != 0 || !gaot_gemm_k256_applicable(dy_bf16, w2t_bf16, dag, rows, (int64_t)F, KK, lda, ldw, 2 * (int64_t)F, 1) ||
+        ((uintptr_t)ag % 16) != 0 || rows * (int64_t)F * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_ffn_w2_bwd_swiglu: needs d_model = 256, F a multiple of 64 and 16-byte aligned bf16 buffers");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const ImageArgs im{nullptr, 1, 0, 0, 1.0f, 1, const_cast<void*>(ag), F};
+    return launch_k256<OUT_SWIGLU_BWD>(dy_bf16, w2t_bf16, dag, (int)rows, F, (int)lda, (int)ldw, 2 * F, im, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

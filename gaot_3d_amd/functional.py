@@ -3,7 +3,7 @@ kernels through the C ABI (gaot_3d_amd.ops).  PyTorch only owns the device buffe
 Functions.  Nothing here falls back to ATen math or to the CPU."""
 from __future__ import annotations
 
-
+import os
 from typing import List, Optional
 
 import torch
@@ -490,6 +490,9 @@ class SwiGLUFn(Function):
         return ops.swiglu_bwd(ag, d, ctx.f), None
 
 
+_FFN_BWD_FUSED = os.environ.get("GAOT_FFN_BWD_FUSED", "0") == "1"
+
+
 class FFNFn(Function):
     """w2(silu(w1 x) * w3 x) [+ residual] (reference FFN.forward, attn.py:150-157) for the bf16 path with the
     intermediates kept as bf16 in memory: [rows, 2F] = w1 x | w3 x, silu(a)*g and both of their gradients are written
@@ -552,13 +555,21 @@ class FFNFn(Function):
             # (csrc/gemm_k256.hip: 41 -> 18 us at configs[1]) for one rounding pass over dy and a 0.5 MB weight transpose;
             # the weight-gradient GEMM reads the same bf16 rows (half the A traffic)
             dyb = ops.cast_bf16(dy2)
-            du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,
-                          out_dtype=torch.bfloat16)
+            if _FFN_BWD_FUSED:
+                # measurement only (GAOT_FFN_BWD_FUSED=1): the SwiGLU backward in that product's epilogue (gaot_ffn_w2_bwd_swiglu: du
+                # never reaches HBM).  Built, bit-compatible, and SLOWER: 54.9 us against 22.8 + 24.8 us at [16 384, 1024] -- a lane
+                # of the transposed product owns a row, so the epilogue's reads of a | g touch 32 rows per instruction where the
+                # stand-alone pass streams at 6.7 TB/s (profiles/r5_t_ffn_bwd_fusion_lab.txt); the step: 21.98 against 21.93 ms
+                dag = ops.ffn_w2_bwd_swiglu(dyb, w2t if w2t.numel() else w2c.t().contiguous(), ag, f)
+            else:
+                du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,
+                              out_dtype=torch.bfloat16)
+                dag = ops.swiglu_bwd_bf16(ag, du, f)
             dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         else:
             du = ops.gemm(dy2, w2c, m, f, d, d, f, False, False, precision=1, out_dtype=torch.bfloat16)
             dw2 = _dw_gemm(dy2, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
-        dag = ops.swiglu_bwd_bf16(ag, du, f)
+            dag = ops.swiglu_bwd_bf16(ag, du, f)
         dx = None
         if ctx.needs_input_grad[0]:
             if d == 256 and wcat.dtype == torch.bfloat16 and (2 * f) % 64 == 0 and 2 * f >= 512:

@@ -759,6 +759,19 @@ def ffn_w13_swiglu(xb: Tensor, w13b: Tensor, f: int):
     return ag, u
 
 
+def ffn_w2_bwd_swiglu(dyb: Tensor, w2t: Tensor, ag: Tensor, f: int) -> Tensor:
+    """dy [rows, 256] bf16, W2^T [F, 256] bf16, a | g bf16 [rows, 2F] -> d(a) | d(g) bf16 [rows, 2F]: the du = dy W2 product with the
+    SwiGLU backward in its epilogue (include/gaot3d_hip.h: gaot_ffn_w2_bwd_swiglu)"""
+    lib = _lib.load()
+    if any(t.dtype != torch.bfloat16 or not t.is_contiguous() for t in (dyb, w2t, ag)):
+        raise GaotError("ffn_w2_bwd_swiglu: contiguous bf16 operands expected")
+    dag = torch.empty_like(ag)
+    with _timed("ffn_w2_bwd_swiglu"):
+        check(lib.gaot_ffn_w2_bwd_swiglu(_ptr(dyb), _ptr(w2t), _ptr(ag), _ptr(dag), dyb.shape[0], dyb.shape[1], w2t.shape[1], int(f),
+                                         _stream()), "gaot_ffn_w2_bwd_swiglu")
+    return dag
+
+
 def swiglu_bwd_bf16(ag: Tensor, du: Tensor, f: int) -> Tensor:
     lib = _lib.load()
     dag = torch.empty_like(ag)

@@ -288,6 +288,11 @@ int gaot_swiglu_fwd_bf16(const void* ag, void* u, int64_t rows, int F, gaot_stre
 int gaot_ffn_w13_swiglu(const void* x_bf16, const void* w13_bf16, void* ag, void* u, int64_t rows, int64_t lda, int64_t ldw, int F,
                         gaot_stream_t stream);
 int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows, int F, gaot_stream_t stream);
+/* the input gradient of the FFN's second projection with the SwiGLU backward in its epilogue (ABI 10; reference attn.py:155-157):
+ * dy [rows][256] bf16, w2t = W2^T ([F][256] bf16), ag as saved by gaot_ffn_w13_swiglu -> dag = d(a) | d(g) (bf16 [rows][2F]); same
+ * values as gaot_gemm_ex (du = dy W2, bf16 result) followed by gaot_swiglu_bwd_bf16, du never written.  F % 64 == 0 */
+int gaot_ffn_w2_bwd_swiglu(const void* dy_bf16, const void* w2t_bf16, const void* ag, void* dag, int64_t rows, int64_t lda,
+                           int64_t ldw, int F, gaot_stream_t stream);
 /* Activations outside the GEMM epilogue's none / gelu / relu / silu: the rest of the reference's `activation_fn(name)`
  * surface (src/model/layers/mlp.py:27-35: any F.<name>, torch's default parameters).  act ids: 0 none, 1 gelu (erf), 2 relu,
  * 3 silu, 4 tanh, 5 leaky_relu, 6 elu, 7 sigmoid, 8 softplus, 9 selu, 10 relu6, 11 hardswish, 12 mish, 13 gelu (tanh form).

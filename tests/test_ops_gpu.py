@@ -336,6 +336,29 @@ def test_ffn_w13_swiglu_fused_equals_two_launches(rows, f):
     assert float((u.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("rows,f", [(1, 128), (300, 1024), (4097, 192), (16384, 1024)])
+def test_ffn_w2_bwd_swiglu_fused_equals_two_launches(rows, f):
+    """gaot_ffn_w2_bwd_swiglu (du = dy W2 with the SwiGLU backward in the K = 256 GEMM's epilogue, du never written) against
+    gaot_gemm_ex (bf16 du) followed by gaot_swiglu_bwd_bf16: d(a) | d(g) within one bf16 ulp of the two-launch values (same
+    arithmetic on the same rounded du) and of the fp64 formula (reference attn.py:155-157, autograd of silu(a) * g)"""
+    from gaot_3d_amd import ops
+    dy = gen(rows, 256, seed=rows + 1).bfloat16().to(DEV)
+    w2t = (gen(f, 256, seed=f + 1) * 0.2).bfloat16().to(DEV)
+    ag = gen(rows, 2 * f, seed=rows + f).bfloat16().to(DEV)
+    dag = ops.ffn_w2_bwd_swiglu(dy, w2t, ag, f)
+    du = ops.gemm(dy, w2t, rows, f, 256, 256, 256, False, True, precision=1, out_dtype=torch.bfloat16)
+    dag2 = ops.swiglu_bwd_bf16(ag, du, f)
+    torch.cuda.synchronize()
+    peak = float(dag2.float().abs().max())
+    err = float((dag.float() - dag2.float()).abs().max())
+    print(f"[parity] ffn_w2_bwd_swiglu rows={rows} f={f}: max_abs={err:.3e} peak={peak:.3e}")
+    assert err <= 2.0 ** -7 * peak + 1e-6
+    a, g, d = ag.double()[:, :f], ag.double()[:, f:], du.double()
+    sg = torch.sigmoid(a)
+    ref = torch.cat([d * g * sg * (1 + a * (1 - sg)), d * a * sg], dim=1)
+    assert float((dag.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
+
+
 def test_gemm_bf16_in_memory_rejects_unsupported():
     from gaot_3d_amd import ops
     from gaot_3d_amd._lib import GaotError
