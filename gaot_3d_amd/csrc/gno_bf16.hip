@@ -49,8 +49,10 @@ struct FwdLdsB {
     static constexpr int weights_end = imgL + imgL_floats;
 };
 
-template <int NH, int T>
-__global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const float* __restrict__ y_pos,
+// PIPE: 0 = loads at the point of use, 1 = ids / coordinates pipelined, 2 = and the f rows requested ahead of the MLP.
+// NW waves per workgroup share one copy of the weight images: 4 (two workgroups per CU) or 12 (one workgroup: THREE waves per SIMD)
+template <int NH, int T, int PIPE = 2, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_gno_fwd_bf16(MlpPtrs mlp, const float* __restrict__ y_pos,
                                                          const float* __restrict__ x_pos, const float* __restrict__ f_y,
                                                          const int* __restrict__ src_s, const int* __restrict__ dst_s,
                                                          const int* __restrict__ rowptr, int64_t E, float* __restrict__ out,
@@ -58,24 +60,25 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
     constexpr int C = 32, H = 64, KB = 2;
     using L = FwdLdsB<NH>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* stage_all = lds + L::weights_end;             // [4 waves][T][32][C]
-    int* ids_all = (int*)(stage_all + 4 * T * 32 * C);   // [4 waves][T][2][32]
+    float* stage_all = lds + L::weights_end;             // [NW waves][T][32][C]
+    int* ids_all = (int*)(stage_all + NW * T * 32 * C);  // [NW waves][T][2][32]
+    constexpr int NTH = NW * 64;
 
     // ---- layer 0 weights (fp32, transposed) and all biases ------------------------------------------
-    for (int i = threadIdx.x; i < IN0P * H; i += 256) {
+    for (int i = threadIdx.x; i < IN0P * H; i += NTH) {
         const int k = i / H, j = i % H;
         lds[L::w0 + i] = (k < IN0) ? mlp.w[0][j * IN0 + k] : 0.f;
     }
-    for (int i = threadIdx.x; i < H; i += 256) lds[L::b0 + i] = mlp.b[0][i];
+    for (int i = threadIdx.x; i < H; i += NTH) lds[L::b0 + i] = mlp.b[0][i];
 #pragma unroll
     for (int l = 1; l < NH; ++l)
-        for (int i = threadIdx.x; i < H; i += 256) lds[L::bl + (l - 1) * H + i] = mlp.b[l][i];
-    for (int i = threadIdx.x; i < C; i += 256) lds[L::bL + i] = mlp.b[NH][i];
+        for (int i = threadIdx.x; i < H; i += NTH) lds[L::bl + (l - 1) * H + i] = mlp.b[l][i];
+    for (int i = threadIdx.x; i < C; i += NTH) lds[L::bL + i] = mlp.b[NH][i];
     // ---- bf16 fragment images: hidden layer l, fragment (ob,kb,s), lane, element j ---------------------
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
         bf16_t* im = reinterpret_cast<bf16_t*>(lds + L::img + (l - 1) * L::img_hidden_floats);
-        for (int i = threadIdx.x; i < KB * KB * 2 * 64 * 8; i += 256) {
+        for (int i = threadIdx.x; i < KB * KB * 2 * 64 * 8; i += NTH) {
             const int j = i & 7, ln = (i >> 3) & 63, fr = i >> 9;   // fr = (ob*KB + kb)*2 + s
             const int s = fr & 1, kb = (fr >> 1) % KB, ob = (fr >> 1) / KB;
             const int row = 32 * ob + (ln & 31), col = 32 * kb + kmap(s, j, ln >> 5);
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
     }
     {
         bf16_t* im = reinterpret_cast<bf16_t*>(lds + L::imgL);
-        for (int i = threadIdx.x; i < KB * 2 * 64 * 8; i += 256) {
+        for (int i = threadIdx.x; i < KB * 2 * 64 * 8; i += NTH) {
             const int j = i & 7, ln = (i >> 3) & 63, fr = i >> 9;   // fr = kb*2 + s
             const int s = fr & 1, kb = fr >> 1;
             im[i] = (bf16_t)f2bf(mlp.w[NH][(ln & 31) * H + 32 * kb + kmap(s, j, ln >> 5)]);
@@ -99,24 +102,81 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
     int* ids = ids_all + wave * (T * 2 * 32);
 
     const int64_t n_macro = (E + 32 * T - 1) / (32 * T);
-    for (int64_t mt = (int64_t)blockIdx.x * 4 + wave; mt < n_macro; mt += (int64_t)gridDim.x * 4) {
-        const int64_t base = mt * 32 * T;
-        float bin[T][3];
+    const int64_t mt0 = (int64_t)blockIdx.x * NW + wave, mstep = (int64_t)gridDim.x * NW;
+    // Software pipeline over the wave's macro tiles (PIPE): the edge's endpoint ids are loaded TWO tiles ahead and its coordinates
+    // gathered ONE tile ahead, so the id -> coordinate -> first MFMA chain (two dependent global round trips at the top of every
+    // tile, covered only by the SIMD's other wave) runs under the previous tile's MLP; the f rows of the tile are requested as
+    // soon as its ids are in LDS and arrive during the MLP instead of after its last layer.
+    int ps[T], pq[T];          // ids of the tile after next (PIPE) / scratch
+    float pbin[T][3];          // coordinates of the next tile (PIPE)
+    int cs[T], cq[T];          // ids of the next tile (PIPE)
+    auto load_ids = [&](int64_t mt, int (&s_)[T], int (&q_)[T]) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const int64_t e = base + 32 * t + l31;
-            const bool valid = e < E;
-            const int s = valid ? src_s[e] : 0;
-            const int q = valid ? dst_s[e] : 0;
-            const float* ys = y_pos + (int64_t)s * 3;
-            const float* xq = x_pos + (int64_t)q * 3;
-            bin[t][0] = ys[hf];
-            bin[t][1] = hf ? xq[0] : ys[2];
-            bin[t][2] = xq[1 + hf];
-            if (hf == 0) {
-                ids[(t * 2 + 0) * 32 + l31] = s;
-                ids[(t * 2 + 1) * 32 + l31] = valid ? q : -1;
+            const int64_t e = mt * 32 * T + 32 * t + l31;
+            const bool valid = mt < n_macro && e < E;
+            s_[t] = valid ? src_s[e] : 0;
+            q_[t] = valid ? dst_s[e] : -1;
+        }
+    };
+    auto gather_pos = [&](const int (&s_)[T], const int (&q_)[T], float (&b_)[T][3]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float* ys = y_pos + (int64_t)s_[t] * 3;
+            const float* xq = x_pos + (int64_t)(q_[t] < 0 ? 0 : q_[t]) * 3;
+            b_[t][0] = ys[hf];
+            b_[t][1] = hf ? xq[0] : ys[2];
+            b_[t][2] = xq[1 + hf];
+        }
+    };
+    if constexpr (PIPE != 0) {
+        load_ids(mt0, cs, cq);
+        load_ids(mt0 + mstep, ps, pq);
+        gather_pos(cs, cq, pbin);
+    }
+    for (int64_t mt = mt0; mt < n_macro; mt += mstep) {
+        const int64_t base = mt * 32 * T;
+        float bin[T][3];
+        if constexpr (PIPE != 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bin[t][0] = pbin[t][0]; bin[t][1] = pbin[t][1]; bin[t][2] = pbin[t][2];
+                if (hf == 0) {
+                    ids[(t * 2 + 0) * 32 + l31] = cs[t];
+                    ids[(t * 2 + 1) * 32 + l31] = cq[t];
+                }
+                cs[t] = ps[t]; cq[t] = pq[t];
             }
+            gather_pos(cs, cq, pbin);                 // next tile's coordinates (its ids arrived during the previous tile)
+            load_ids(mt + 2 * mstep, ps, pq);         // ids of the tile after next
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int64_t e = base + 32 * t + l31;
+                const bool valid = e < E;
+                const int s = valid ? src_s[e] : 0;
+                const int q = valid ? dst_s[e] : 0;
+                const float* ys = y_pos + (int64_t)s * 3;
+                const float* xq = x_pos + (int64_t)q * 3;
+                bin[t][0] = ys[hf];
+                bin[t][1] = hf ? xq[0] : ys[2];
+                bin[t][2] = xq[1 + hf];
+                if (hf == 0) {
+                    ids[(t * 2 + 0) * 32 + l31] = s;
+                    ids[(t * 2 + 1) * 32 + l31] = valid ? q : -1;
+                }
+            }
+        }
+        float fv[PIPE == 2 ? T : 1][16];
+        if constexpr (PIPE == 2) {
+            wave_lds_fence();  // ids visible to the whole wave
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sidx = ids[(t * 2 + 0) * 32 + mfma32_row(r, hf)];
+                    fv[t][r] = f_y[(int64_t)sidx * C + l31];
+                }
         }
         // ---- layer 0 on the exact-fp32 MFMA, GELU, round to bf16 fragments ---------------------------
         bf16x8 hb[T][KB][2];
@@ -195,9 +255,13 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int el = mfma32_row(r, hf);
-                const int s = ids[(t * 2 + 0) * 32 + el];
-                const float fv = f_y[(int64_t)s * C + l31];
-                stage[(t * 32 + el) * C + l31] = acc[r] * fv;
+                if constexpr (PIPE == 2) {
+                    stage[(t * 32 + el) * C + l31] = acc[r] * fv[t][r];
+                } else {
+                    const int s = ids[(t * 2 + 0) * 32 + el];
+                    const float fval = f_y[(int64_t)s * C + l31];
+                    stage[(t * 32 + el) * C + l31] = acc[r] * fval;
+                }
             }
         }
         wave_lds_fence();
@@ -208,17 +272,17 @@ __global__ __launch_bounds__(256, 2) void k_gno_fwd_bf16(MlpPtrs mlp, const floa
     }
 }
 
-size_t fwd_lds_bytes_b(int nh, int t) {
+size_t fwd_lds_bytes_b(int nh, int t, int nw) {
     const int weights = IN0P * 64 + 64 + (nh - 1) * 64 + 32 + (nh - 1) * (2 * 2 * 2 * 64 * 8 / 2) + (2 * 2 * 64 * 8 / 2);
-    return sizeof(float) * (size_t)(weights + 4 * t * 32 * 32) + sizeof(int) * (size_t)(4 * t * 2 * 32);
+    return sizeof(float) * (size_t)(weights + nw * t * 32 * 32) + sizeof(int) * (size_t)(nw * t * 2 * 32);
 }
 
-template <int NH>
-int launch_fwd_b(const MlpPtrs& p, const float* y_pos, const float* x_pos, const float* f_y, const int* src_s,
+template <int NH, int PIPE, int NW>
+int launch_fwd_v(const MlpPtrs& p, const float* y_pos, const float* x_pos, const float* f_y, const int* src_s,
                  const int* dst_s, const int* rowptr, int64_t E, float* out, float* part, hipStream_t st) {
     constexpr int T = 2;
-    const size_t lds = fwd_lds_bytes_b(NH, T);
-    auto kern = k_gno_fwd_bf16<NH, T>;
+    const size_t lds = fwd_lds_bytes_b(NH, T, NW);
+    auto kern = k_gno_fwd_bf16<NH, T, PIPE, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -229,9 +293,26 @@ int launch_fwd_b(const MlpPtrs& p, const float* y_pos, const float* x_pos, const
         attr_set = true;
     }
     const int64_t n_macro = ceil_div(E, 32 * T);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_macro, 4), 256 * 2));
-    GAOT_KLAUNCH(kern, dim3(grid), dim3(256), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_macro, NW), NW == 4 ? 256 * 2 : 256));
+    GAOT_KLAUNCH(kern, dim3(grid), dim3(NW * 64), lds, st, p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part);
     return GAOT_OK;
+}
+
+template <int NH>
+int launch_fwd_b(const MlpPtrs& p, const float* y_pos, const float* x_pos, const float* f_y, const int* src_s,
+                 const int* dst_s, const int* rowptr, int64_t E, float* out, float* part, hipStream_t st) {
+    // Shipped: 12 waves per workgroup (one weight image per CU, THREE waves per SIMD; 127 KB of LDS at three hidden layers) with the
+    // id / coordinate loads pipelined.  Measured at E = 4 M (profiles/r5_w_gno_fwd_variants_lab.txt; nh = 3 / 2 / 4): round-4 form
+    // 0.402 / 0.317 / 0.466 ms, 4 waves + full pipeline 0.390 / 0.300 / 0.435, 12 waves + id pipeline 0.377 / 0.277 / 0.421,
+    // 12 waves alone 0.377 / 0.279 / 0.427.  GAOT_GNO_FWD_VARIANT (measurement only) = 0: 4 waves, no pipeline | 1: 4 waves, ids +
+    // coordinates + f rows pipelined | 2: the shipped form | 3: 12 waves, no pipeline
+    static const int variant = [] { const char* e = getenv("GAOT_GNO_FWD_VARIANT"); return e ? atoi(e) : 2; }();
+    switch (variant) {
+        case 0: return launch_fwd_v<NH, 0, 4>(p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part, st);
+        case 1: return launch_fwd_v<NH, 2, 4>(p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part, st);
+        case 3: return launch_fwd_v<NH, 0, 12>(p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part, st);
+        default: return launch_fwd_v<NH, 1, 12>(p, y_pos, x_pos, f_y, src_s, dst_s, rowptr, E, out, part, st);
+    }
 }
 
 }  // namespace
