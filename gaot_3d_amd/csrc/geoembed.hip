@@ -110,15 +110,31 @@ __global__ void k_geo_moments(const float* __restrict__ src_pos, const float* __
     double m[NM];
 #pragma unroll
     for (int i = 0; i < NM; ++i) m[i] = 0.0;
-    for (int i = b + gl; i < e; i += G) {
-        const int s = src_sorted[i];
-        const float fx = src_pos[(int64_t)s * 3 + 0], fy = src_pos[(int64_t)s * 3 + 1], fz = src_pos[(int64_t)s * 3 + 2];
-        const float dx = fx - qxf, dy = fy - qyf, dz = fz - qzf;          // fp32 difference and norm, as the reference
-        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-        const double ux = (double)fx - (double)qxf, uy = (double)fy - (double)qyf, uz = (double)fz - (double)qzf;
-        m[1] += dist; m[2] += (double)dist * (double)dist;
-        m[3] += ux; m[4] += uy; m[5] += uz;
-        m[6] += ux * ux; m[7] += ux * uy; m[8] += ux * uz; m[9] += uy * uy; m[10] += uy * uz; m[11] += uz * uz;
+    // four of the lane's edges per trip: their ids, then their 12 coordinate words, are requested TOGETHER (the one-edge loop was a
+    // chain of two dependent round trips per edge -- 488 edges per token at 8 M points: 3.9 ms); the sums are formed in the same
+    // order as before, edge by edge, so the moments are bit-identical
+    constexpr int U = 4;
+    for (int i0 = b + gl; i0 < e; i0 += U * G) {
+        int sidx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sidx[u] = (i0 + u * G < e) ? src_sorted[i0 + u * G] : -1;
+        float f[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t o = (int64_t)(sidx[u] < 0 ? 0 : sidx[u]) * 3;
+            f[u][0] = src_pos[o + 0]; f[u][1] = src_pos[o + 1]; f[u][2] = src_pos[o + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (sidx[u] < 0) break;
+            const float fx = f[u][0], fy = f[u][1], fz = f[u][2];
+            const float dx = fx - qxf, dy = fy - qyf, dz = fz - qzf;          // fp32 difference and norm, as the reference
+            const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+            const double ux = (double)fx - (double)qxf, uy = (double)fy - (double)qyf, uz = (double)fz - (double)qzf;
+            m[1] += dist; m[2] += (double)dist * (double)dist;
+            m[3] += ux; m[4] += uy; m[5] += uz;
+            m[6] += ux * ux; m[7] += ux * uy; m[8] += ux * uz; m[9] += uy * uy; m[10] += uy * uz; m[11] += uz * uz;
+        }
     }
 #pragma unroll
     for (int i = 1; i < NM; ++i) m[i] = grp_sum(m[i]);
