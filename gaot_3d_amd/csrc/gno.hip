@@ -742,7 +742,7 @@ extern "C" int gaot_gno_fwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
         if (rc != GAOT_OK) return rc;
     }
     const int64_t n = num_queries * 8;   // four channels per thread
-    GAOT_KLAUNCH((k_segment_fixup<32>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_dst,
+    GAOT_KLAUNCH((k_segment_fixup<32>), dim3(segment_fixup_grid(n)), dim3(256), 0, st, rowptr_dst,
                        num_queries, part, out, 1);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -849,10 +849,10 @@ extern "C" int gaot_gno_bwd(const gaot_mlp_t* mlp, const float* y_pos, const flo
     if (num_sources > 0) {
         const int64_t n = num_sources * 8;   // four channels per thread
         if (precision == 1)
-            GAOT_KLAUNCH((k_segment_fixup<32, 4>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
+            GAOT_KLAUNCH((k_segment_fixup<32, 4>), dim3(segment_fixup_grid(n)), dim3(256), 0, st, rowptr_src,
                                num_sources, part, grad_f_y, 0);
         else
-            GAOT_KLAUNCH((k_segment_fixup<32, 5>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, rowptr_src,
+            GAOT_KLAUNCH((k_segment_fixup<32, 5>), dim3(segment_fixup_grid(n)), dim3(256), 0, st, rowptr_src,
                                num_sources, part, grad_f_y, 0);
     }
     GAOT_LAUNCH_CHECK();
