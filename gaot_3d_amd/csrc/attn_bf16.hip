@@ -1821,6 +1821,138 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_attn_fwd_asm: the bound-based forward tile (k_attn_fwd_bf16<4, 4, DROP, true, 8>) with ONE wave per SIMD and a hand-scheduled
+// tile loop (gen_attn_fwd_asm.py -> attn_fwd_asm.inc).  Workgroup = 4 waves x 4 query tiles = 512 queries of one head; the keys
+// stream through LDS in stages of 128 (the compiled kernel's staging, two barriers per stage), and the tile loop of a stage --
+// 16 (key tile, query tile) units = 64 MFMAs, 1 024 vector instructions with dropout -- is ONE asm statement.  It owns v48-v152 and
+// the AGPRs a32-a95 (the four O^T accumulators), reads a0-a31 (the Q fragments); the AGPRs live ACROSS the statements, the row sums
+// travel as in / out operands.  Same arithmetic as the compiled tile (same packs, same mask words, row sums of the packed p); the
+// K / V^T fragments and the mask's column words of a key tile are read from LDS once for the four query tiles.
+// Launches whose sequence length is not a multiple of 512, or that split the key range, keep the compiled kernel.
+// ------------------------------------------------------------------------------------------------
+#include "attn_fwd_asm.inc"
+struct FwdAsmLds {
+    static constexpr int QT = GAOT_ATTN_FWD_ASM_QT, KT = GAOT_ATTN_FWD_ASM_KT;
+    static constexpr int STAGE = 0;                              // K tiles, then V tiles
+    static constexpr int BW = STAGE + 2 * KT * TILE_BYTES;       // uint32[16 * KT] column words of the stage
+    static constexpr int TOTAL = BW + 16 * KT * 4;
+    static constexpr int QUERIES = 4 * QT * 32, KEYS = KT * 32;
+};
+template <bool DROP, int LAB = 0>     // LAB 1 (measurement only, results invalid): the stage code without the tile loop
+__global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
+    using L = FwdAsmLds;
+    constexpr int QT = L::QT, KT = L::KT;
+    __shared__ __attribute__((aligned(1024))) char lds[L::TOTAL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int head = blockIdx.x % a.H, b = blockIdx.z, qblk = blockIdx.x / a.H;
+    const int hkv = head / (a.H / a.HKV);
+    const int64_t q0 = (int64_t)qblk * L::QUERIES + wave * (QT * 32);
+    const int64_t rowbase = (int64_t)b * a.S;
+    const bf16_t* qp = a.qkv + rowbase * a.ld + head * D;
+    const bf16_t* kp = a.qkv + rowbase * a.ld + (a.H + hkv) * D;
+    const bf16_t* vp = a.qkv + rowbase * a.ld + (a.H + a.HKV + hkv) * D;
+
+    // ---- the wave's Q rows -> AGPR fragments (B operand of S^T = K Q^T); |q|^2 of every row for the static bound ----------------
+    float q2max = 0.f;
+    static_for<0, QT>([&](auto qc) {
+        constexpr int qt = decltype(qc)::value;
+        const int64_t qi = q0 + 32 * qt + l31;              // S % 512 == 0: always a row of the sequence
+        float q2 = 0.f;
+        static_for<0, 2>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const uint4 f = *reinterpret_cast<const uint4*>(qp + qi * a.ld + 16 * s + 8 * hf);
+            agpr_write4<8 * qt + 4 * s>(f);
+            const unsigned w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+                q2 = fmaf(lo, lo, fmaf(hi, hi, q2));
+            }
+        });
+        q2 += xhalf(q2);
+        q2max = fmaxf(q2max, q2);
+    });
+    {
+        constexpr float BOUND2 = 54.f * 54.f;               // see k_attn_fwd_bf16 (FAST)
+        float k2 = a.kmax2[((int64_t)b * KN_BLOCKS + lane) * a.HKV + hkv];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
+        const int over = __syncthreads_or(!(q2max * k2 <= BOUND2));
+        // the adaptive kernel runs on the compiled kernel's grid (128 queries per workgroup): this workgroup stands for four of them
+        if (threadIdx.x < 4)
+            a.redo[(qblk * 4 + threadIdx.x) * a.H + head + (int64_t)(a.S / 128) * a.H * b] = over ? 1 : 0;
+        if (over) return;
+    }
+    uint32_t aw[QT] = {0, 0, 0, 0}, ck = 0;
+    if constexpr (DROP) {
+        const unsigned long long seed = *a.drop.seed;
+        const int bh = a.drop.bh(b, head);
+        const uint32_t rk = gdrop::row_key(seed, bh);
+        ck = gdrop::col_key(seed, bh);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) aw[qt] = gdrop::row_word(rk, (uint32_t)(q0 + 32 * qt + l31)) ^ 0x80008000u;
+    }
+    const uint32_t ts = (uint32_t)((int)a.drop.thr - 1 - 32768) & 0xffffu;
+    const uint32_t tpk = ts | (ts << 16);
+    asm volatile(GAOT_ATTN_FWD_ASM_ZERO_ACC ::: GAOT_ATTN_FWD_ASM_ACC_CLOBBERS);
+    float l0[QT] = {0.f, 0.f, 0.f, 0.f}, l1[QT] = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS addresses of the tile loop (32-bit LDS byte addresses; tile offsets are immediates of the loop) ----------------
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned a_k0 = lbase + L::STAGE + tile_off(l31, hf), a_k1 = lbase + L::STAGE + tile_off(l31, 2 + hf);
+    unsigned a_v0, a_v1;
+    {
+        const int i = lane & 15, grp = (lane >> 4) & 1, col = 16 * grp + 4 * (i & 3), r0 = 4 * hf + (i >> 2), r1 = r0 + 8;
+        a_v0 = lbase + L::STAGE + tile_off(r0, col >> 3) + ((col & 7) << 1);
+        a_v1 = lbase + L::STAGE + tile_off(r1, col >> 3) + ((col & 7) << 1);
+    }
+    const unsigned a_w = lbase + L::BW + hf * 32;
+    uint32_t* bw_s = reinterpret_cast<uint32_t*>(lds + L::BW);
+
+    uint4 regs[KT];
+    stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, 0, a.S);
+    for (int64_t k0 = 0; k0 < a.S; k0 += L::KEYS) {
+        __syncthreads();
+        stage_storeN<KT>(regs, lds + L::STAGE);
+        if constexpr (DROP) stage_col_words<KT>(bw_s, ck, k0);
+        __syncthreads();
+        if (k0 + L::KEYS < a.S) stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, k0 + L::KEYS, a.S);
+        if constexpr (LAB == 1) continue;
+        if constexpr (DROP)
+            asm volatile(GAOT_ATTN_FWD_STAGE_ASM_DROP
+                         : [l00] "+v"(l0[0]), [l01] "+v"(l0[1]), [l02] "+v"(l0[2]), [l03] "+v"(l0[3]),
+                           [l10] "+v"(l1[0]), [l11] "+v"(l1[1]), [l12] "+v"(l1[2]), [l13] "+v"(l1[3])
+                         : [a_k0] "v"(a_k0), [a_k1] "v"(a_k1), [a_v0] "v"(a_v0), [a_v1] "v"(a_v1), [a_w] "v"(a_w),
+                           [aw0] "v"(aw[0]), [aw1] "v"(aw[1]), [aw2] "v"(aw[2]), [aw3] "v"(aw[3]), [tpk] "s"(tpk)
+                         : GAOT_ATTN_FWD_STAGE_ASM_CLOBBERS);
+        else
+            asm volatile(GAOT_ATTN_FWD_STAGE_ASM_NODROP
+                         : [l00] "+v"(l0[0]), [l01] "+v"(l0[1]), [l02] "+v"(l0[2]), [l03] "+v"(l0[3]),
+                           [l10] "+v"(l1[0]), [l11] "+v"(l1[1]), [l12] "+v"(l1[2]), [l13] "+v"(l1[3])
+                         : [a_k0] "v"(a_k0), [a_k1] "v"(a_k1), [a_v0] "v"(a_v0), [a_v1] "v"(a_v1)
+                         : GAOT_ATTN_FWD_STAGE_ASM_CLOBBERS);
+    }
+    // ---- epilogue: o = acc / l (and 1 / (1 - p)), lse = log l (the bound-based tile carries no reference value) --------------------
+    static_for<0, QT>([&](auto qc) {
+        constexpr int qt = decltype(qc)::value;
+        float l = l0[qt] + l1[qt];
+        l += xhalf(l);
+        const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
+        float o[16];
+        static_for<0, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            o[r] = agpr_read<32 + 16 * qt + r>() * inv;
+        });
+        const int64_t qi = q0 + 32 * qt + l31;
+        float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hf) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+        if (hf == 0) a.lse[((int64_t)b * a.H + head) * a.S + qi] = logf(l);
+    });
+}
+
 // dq[b, q, head, :] = scale / (1-p) * sum over the key slabs (slab order) of the fused kernel's partials, rotated back
 __global__ void k_attn_dq_reduce(const bf16_t* __restrict__ part, int nslab, int B, int S, int H, int ld, float qsc,
                                  const float* __restrict__ freqs, float* __restrict__ dqkv) {
@@ -2024,7 +2156,23 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // GAOT_ATTN_FWD_LAB = 1 / 8 forces the adds / the dot products for both (measurement only).
     static const int fwd_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_LAB"); return e ? atoi(e) : 0; }();
     const bool dot2 = fwd_lab == 8 || (fwd_lab != 1 && a.drop.thr);
-    if (a.drop.thr) {
+    // whole-sequence launches with S a multiple of 512 and at least half a workgroup per CU: the one-wave-per-SIMD kernel with the
+    // generated tile loop (k_attn_fwd_asm) does the bound-based pass; GAOT_ATTN_FWD_ASM=0 keeps the compiled kernel (measurement)
+    const bool fwd_asm = [] { const char* e = getenv("GAOT_ATTN_FWD_ASM"); return !e || atoi(e) != 0; }();   // read per call: tests switch it
+    if (fwd_asm && fwd_lab == 0 && P == 1 && S % FwdAsmLds::QUERIES == 0 && (int64_t)(S / FwdAsmLds::QUERIES) * H * B >= 128) {
+        const dim3 agrid((unsigned)((S / FwdAsmLds::QUERIES) * H), 1, (unsigned)B);
+        static const int asm_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_ASM_LAB"); return e ? atoi(e) : 0; }();
+        if (asm_lab == 1) {
+            if (a.drop.thr) GAOT_KLAUNCH((k_attn_fwd_asm<true, 1>), agrid, dim3(256), 0, st, a);
+            else GAOT_KLAUNCH((k_attn_fwd_asm<false, 1>), agrid, dim3(256), 0, st, a);
+        } else if (a.drop.thr) {
+            GAOT_KLAUNCH((k_attn_fwd_asm<true>), agrid, dim3(256), 0, st, a);
+            GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true, false>), fgrid, dim3(256), 0, st, a);
+        } else {
+            GAOT_KLAUNCH((k_attn_fwd_asm<false>), agrid, dim3(256), 0, st, a);
+            GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, false, false>), fgrid, dim3(256), 0, st, a);
+        }
+    } else if (a.drop.thr) {
         if (dot2) GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true, 8>), fgrid, dim3(256), 0, st, a);
         else GAOT_KLAUNCH((k_attn_fwd_bf16<4, 4, true, true>), fgrid, dim3(256), 0, st, a);
         GAOT_KLAUNCH((k_attn_fwd_bf16<3, 4, true, false>), fgrid, dim3(256), 0, st, a);

@@ -61,6 +61,25 @@ def test_attn_bwd_asm_include_is_current_and_owns_its_agprs(tmp_path):
                         bad.append(ln.strip())
         assert not bad, f"{name}: compiler-generated code touches the asm's AGPRs: {bad[:5]}"
         assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body) or "LAB" in name, f"{name} needs scratch"
+    # the forward's generated tile loop (k_attn_fwd_asm): same contract for its include and its a0-a95 (Q fragments, O^T accumulators)
+    gen = subprocess.run([sys.executable, os.path.join(csrc, "gen_attn_fwd_asm.py")], capture_output=True, text=True, check=True,
+                         env={k: v for k, v in os.environ.items() if not k.startswith("GEN_")}).stdout
+    assert gen == open(os.path.join(csrc, "attn_fwd_asm.inc")).read(), "attn_fwd_asm.inc is stale: python3 gen_attn_fwd_asm.py > attn_fwd_asm.inc"
+    kernels = re.findall(r"^(_ZN\S*k_attn_fwd_asm\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", txt, re.S | re.M)
+    assert len(kernels) >= 2, "k_attn_fwd_asm<true> / <false> not found in the device assembly"
+    for name, body in kernels:
+        inside, bad = False, []
+        for ln in body.split("\n"):
+            if "#ASMSTART" in ln:
+                inside = True
+            elif "#ASMEND" in ln:
+                inside = False
+            elif not inside and not ln.strip().startswith(";"):
+                for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", ln):
+                    if int(m.group(1)) < 96:
+                        bad.append(ln.strip())
+        assert not bad, f"{name}: compiler-generated code touches the asm's AGPRs: {bad[:5]}"
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), f"{name} needs scratch"
 
 
 def test_hot_path_kernels_need_no_scratch(tmp_path):

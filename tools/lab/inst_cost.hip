@@ -120,6 +120,34 @@ DEFKERNEL(k_mfma_mul4, L_MFMA_MUL4)
 DEFKERNEL(k_mfma_exp4, L_MFMA_EXP4)
 #define L_MFMA_PKMUL8(i) L_MFMA(i) L_PKMUL(0) L_PKMUL(1) L_PKMUL(2) L_PKMUL(3) L_PKMUL(4) L_PKMUL(5) L_PKMUL(6) L_PKMUL(7)
 DEFKERNEL(k_mfma_pkmul8, L_MFMA_PKMUL8)
+#define L_PKSUB8(i) L_PKSUBI16(0) L_PKSUBI16(1) L_PKSUBI16(2) L_PKSUBI16(3) L_PKSUBI16(4) L_PKSUBI16(5) L_PKSUBI16(6) L_PKSUBI16(7)
+#define L_MFMA_PKSUB8(i) L_MFMA(i) L_PKSUB8(i)
+DEFKERNEL(k_mfma_pksub8, L_MFMA_PKSUB8)
+#define L_CVTPK8(i) L_CVTPK(0) L_CVTPK(1) L_CVTPK(2) L_CVTPK(3) L_CVTPK(4) L_CVTPK(5) L_CVTPK(6) L_CVTPK(7)
+#define L_MFMA_CVTPK8(i) L_MFMA(i) L_CVTPK8(i)
+DEFKERNEL(k_mfma_cvtpk8, L_MFMA_CVTPK8)
+#define L_XOR8(i) L_XOR(0) L_XOR(1) L_XOR(2) L_XOR(3) L_XOR(4) L_XOR(5) L_XOR(6) L_XOR(7)
+#define L_MFMA_XOR8(i) L_MFMA(i) L_XOR8(i)
+DEFKERNEL(k_mfma_xor8, L_MFMA_XOR8)
+#define L_CND8(i) L_CND64(0) L_CND64(1) L_CND64(2) L_CND64(3) L_CND64(4) L_CND64(5) L_CND64(6) L_CND64(7)
+#define L_MFMA_CND8(i) L_MFMA(i) L_CND8(i)
+DEFKERNEL(k_mfma_cnd8, L_MFMA_CND8)
+#define L_DOT8(i) L_DOT2C(0) L_DOT2C(1) L_DOT2C(2) L_DOT2C(3) L_DOT2C(4) L_DOT2C(5) L_DOT2C(6) L_DOT2C(7)
+#define L_MFMA_DOT8(i) L_MFMA(i) L_DOT8(i)
+DEFKERNEL(k_mfma_dot8, L_MFMA_DOT8)
+#define L_FMA8(i) L_FMA(0) L_FMA(1) L_FMA(2) L_FMA(3) L_FMA(4) L_FMA(5) L_FMA(6) L_FMA(7)
+#define L_MFMA_FMA8(i) L_MFMA(i) L_FMA8(i)
+DEFKERNEL(k_mfma_fma8, L_MFMA_FMA8)
+#define L_PKFMA8(i) L_PKFMA(0) L_PKFMA(1) L_PKFMA(2) L_PKFMA(3) L_PKFMA(4) L_PKFMA(5) L_PKFMA(6) L_PKFMA(7)
+#define L_MFMA_PKFMA8(i) L_MFMA(i) L_PKFMA8(i)
+DEFKERNEL(k_mfma_pkfma8, L_MFMA_PKFMA8)
+#define L_EXP8(i) L_EXP(0) L_EXP(1) L_EXP(2) L_EXP(3) L_EXP(4) L_EXP(5) L_EXP(6) L_EXP(7)
+#define L_MFMA_EXP8(i) L_MFMA(i) L_EXP8(i)
+DEFKERNEL(k_mfma_exp8, L_MFMA_EXP8)
+// the MFMA with its B operand in AGPRs and a VGPR destination (the attention tile loops' S product)
+#define L_MFMA_AB(i) "v_mfma_f32_32x32x16_bf16 v[16:31], v[40:43], a[" S(16 * i) ":" S(16 * i + 3) "], 0\n"
+#define L_MFMAAB_MUL8(i) L_MFMA_AB(i) "v_mul_f32 v32, v40, v41\n v_mul_f32 v33, v40, v41\n v_mul_f32 v34, v40, v41\n v_mul_f32 v35, v40, v41\n v_mul_f32 v36, v40, v41\n v_mul_f32 v37, v40, v41\n v_mul_f32 v38, v40, v41\n v_mul_f32 v39, v40, v41\n"
+DEFKERNEL(k_mfmaab_mul8, L_MFMAAB_MUL8)
 #define L_DSREAD(i) "ds_read_b128 v[" S(16 + 2 * i) ":" S(19 + 2 * i) "], v48\n"
 #define L_DSREADTR(i) "ds_read_b64_tr_b16 v[" S(16 + 2 * i) ":" S(17 + 2 * i) "], v48\n"
 
@@ -145,6 +173,11 @@ int main() {
         {"v_mfma_f32_32x32x16_bf16 (8 chains)", k_mfma, 1}, {"v_mfma_f32_16x16x32_bf16 (8 chains)", k_mfma16, 1},
         {"group: 1 MFMA32 + 4 v_mul", k_mfma_mul4, 1}, {"group: 1 MFMA32 + 7 v_mul", k_mfma_mul7, 1}, {"group: 1 MFMA32 + 8 v_mul", k_mfma_mul8, 1},
         {"group: 1 MFMA32 + 16 v_mul", k_mfma_mul16, 1}, {"group: 1 MFMA32 + 4 v_exp", k_mfma_exp4, 1}, {"group: 1 MFMA32 + 8 v_pk_mul_f32", k_mfma_pkmul8, 1},
+        {"group: 1 MFMA32 + 8 v_pk_fma_f32", k_mfma_pkfma8, 1}, {"group: 1 MFMA32 + 8 v_pk_sub_i16", k_mfma_pksub8, 1},
+        {"group: 1 MFMA32 + 8 v_cvt_pk_bf16_f32", k_mfma_cvtpk8, 1}, {"group: 1 MFMA32 + 8 v_xor_b32", k_mfma_xor8, 1},
+        {"group: 1 MFMA32 + 8 v_cndmask_b32_e64", k_mfma_cnd8, 1}, {"group: 1 MFMA32 + 8 v_dot2c_f32_bf16", k_mfma_dot8, 1},
+        {"group: 1 MFMA32 + 8 v_fma_f32", k_mfma_fma8, 1}, {"group: 1 MFMA32 + 8 v_exp_f32", k_mfma_exp8, 1},
+        {"group: 1 MFMA32 (B in AGPRs, D in VGPRs) + 8 v_mul_f32", k_mfmaab_mul8, 1},
     };
     for (auto& c : cases) {
         c.k<<<256, 256>>>(d, 10, 1.0f);
