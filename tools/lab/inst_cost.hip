@@ -148,6 +148,23 @@ DEFKERNEL(k_mfma_exp8, L_MFMA_EXP8)
 #define L_MFMA_AB(i) "v_mfma_f32_32x32x16_bf16 v[16:31], v[40:43], a[" S(16 * i) ":" S(16 * i + 3) "], 0\n"
 #define L_MFMAAB_MUL8(i) L_MFMA_AB(i) "v_mul_f32 v32, v40, v41\n v_mul_f32 v33, v40, v41\n v_mul_f32 v34, v40, v41\n v_mul_f32 v35, v40, v41\n v_mul_f32 v36, v40, v41\n v_mul_f32 v37, v40, v41\n v_mul_f32 v38, v40, v41\n v_mul_f32 v39, v40, v41\n"
 DEFKERNEL(k_mfmaab_mul8, L_MFMAAB_MUL8)
+// DEPENDENT MFMAs (every one accumulates into a[0:15]) with n independent v_mul_f32 between them: what a k-step chain costs
+#define L_MFMAD "v_mfma_f32_32x32x16_bf16 a[0:15], v[40:43], v[44:47], a[0:15]\n"
+#define L_MUL4 "v_mul_f32 v32, v40, v41\n v_mul_f32 v33, v40, v41\n v_mul_f32 v34, v40, v41\n v_mul_f32 v35, v40, v41\n"
+#define L_MFMAD_0(i) L_MFMAD
+DEFKERNEL(k_mfmad_0, L_MFMAD_0)
+#define L_MFMAD_4(i) L_MFMAD L_MUL4
+DEFKERNEL(k_mfmad_4, L_MFMAD_4)
+#define L_MFMAD_8(i) L_MFMAD L_MUL4 L_MUL4
+DEFKERNEL(k_mfmad_8, L_MFMAD_8)
+#define L_MFMAD_12(i) L_MFMAD L_MUL4 L_MUL4 L_MUL4
+DEFKERNEL(k_mfmad_12, L_MFMAD_12)
+#define L_MFMAD_16(i) L_MFMAD L_MUL4 L_MUL4 L_MUL4 L_MUL4
+DEFKERNEL(k_mfmad_16, L_MFMAD_16)
+// two chains alternating (a[0:15], a[16:31]) with 4 v_mul_f32 after each: a dependent MFMA is then two issues behind its predecessor
+#define L_MFMAD2 "v_mfma_f32_32x32x16_bf16 a[16:31], v[40:43], v[44:47], a[16:31]\n"
+#define L_MFMAD_ALT4(i) L_MFMAD L_MUL4 L_MFMAD2 L_MUL4
+DEFKERNEL(k_mfmad_alt4, L_MFMAD_ALT4)
 #define L_DSREAD(i) "ds_read_b128 v[" S(16 + 2 * i) ":" S(19 + 2 * i) "], v48\n"
 #define L_DSREADTR(i) "ds_read_b64_tr_b16 v[" S(16 + 2 * i) ":" S(17 + 2 * i) "], v48\n"
 
@@ -178,6 +195,9 @@ int main() {
         {"group: 1 MFMA32 + 8 v_cndmask_b32_e64", k_mfma_cnd8, 1}, {"group: 1 MFMA32 + 8 v_dot2c_f32_bf16", k_mfma_dot8, 1},
         {"group: 1 MFMA32 + 8 v_fma_f32", k_mfma_fma8, 1}, {"group: 1 MFMA32 + 8 v_exp_f32", k_mfma_exp8, 1},
         {"group: 1 MFMA32 (B in AGPRs, D in VGPRs) + 8 v_mul_f32", k_mfmaab_mul8, 1},
+        {"group: DEPENDENT MFMA32 alone", k_mfmad_0, 1}, {"group: DEPENDENT MFMA32 + 4 v_mul", k_mfmad_4, 1}, {"group: DEPENDENT MFMA32 + 8 v_mul", k_mfmad_8, 1},
+        {"group: DEPENDENT MFMA32 + 12 v_mul", k_mfmad_12, 1}, {"group: DEPENDENT MFMA32 + 16 v_mul", k_mfmad_16, 1},
+        {"group: two dependent chains alternating, 4 v_mul after each MFMA (2 MFMAs per line)", k_mfmad_alt4, 1},
     };
     for (auto& c : cases) {
         c.k<<<256, 256>>>(d, 10, 1.0f);
