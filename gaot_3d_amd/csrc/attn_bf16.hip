@@ -1826,8 +1826,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
 // tile loop (gen_attn_fwd_asm.py -> attn_fwd_asm.inc).  Workgroup = 4 waves x 4 query tiles = 512 queries of one head; the keys
 // stream through LDS in stages of 128 (the compiled kernel's staging, two barriers per stage), and the tile loop of a stage --
 // 16 (key tile, query tile) units = 64 MFMAs, 1 024 vector instructions with dropout -- is ONE asm statement.  It owns v48-v152 and
-// the AGPRs a32-a95 (the four O^T accumulators), reads a0-a31 (the Q fragments); the AGPRs live ACROSS the statements, the row sums
-// travel as in / out operands.  Same arithmetic as the compiled tile (same packs, same mask words, row sums of the packed p); the
+// the AGPRs a32-a159 (the four O^T accumulators and the four row-sum accumulators: two more MFMAs per unit against a fragment of
+// ones), reads a0-a31 (the Q fragments); the AGPRs live ACROSS the statements.  Same arithmetic as the compiled tile (same packs, same mask words, row sums of the packed p); the
 // K / V^T fragments and the mask's column words of a key tile are read from LDS once for the four query tiles.
 // Launches whose sequence length is not a multiple of 512, or that split the key range, keep the compiled kernel.
 // ------------------------------------------------------------------------------------------------
@@ -1919,6 +1919,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
         __syncthreads();
         if (k0 + L::KEYS < a.S) stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, k0 + L::KEYS, a.S);
         if constexpr (LAB == 1) continue;
+#if GAOT_ATTN_FWD_ASM_LSUM_MFMA
+        // (the row sums accumulate in a96-a159 through two MFMAs per unit against a fragment of ones)
+        if constexpr (DROP)
+            asm volatile(GAOT_ATTN_FWD_STAGE_ASM_DROP
+                         :: [a_k0] "v"(a_k0), [a_k1] "v"(a_k1), [a_v0] "v"(a_v0), [a_v1] "v"(a_v1), [a_w] "v"(a_w),
+                            [aw0] "v"(aw[0]), [aw1] "v"(aw[1]), [aw2] "v"(aw[2]), [aw3] "v"(aw[3]), [tpk] "s"(tpk)
+                         : GAOT_ATTN_FWD_STAGE_ASM_CLOBBERS);
+        else
+            asm volatile(GAOT_ATTN_FWD_STAGE_ASM_NODROP
+                         :: [a_k0] "v"(a_k0), [a_k1] "v"(a_k1), [a_v0] "v"(a_v0), [a_v1] "v"(a_v1)
+                         : GAOT_ATTN_FWD_STAGE_ASM_CLOBBERS);
+#else
         if constexpr (DROP)
             asm volatile(GAOT_ATTN_FWD_STAGE_ASM_DROP
                          : [l00] "+v"(l0[0]), [l01] "+v"(l0[1]), [l02] "+v"(l0[2]), [l03] "+v"(l0[3]),
@@ -1932,12 +1944,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
                            [l10] "+v"(l1[0]), [l11] "+v"(l1[1]), [l12] "+v"(l1[2]), [l13] "+v"(l1[3])
                          : [a_k0] "v"(a_k0), [a_k1] "v"(a_k1), [a_v0] "v"(a_v0), [a_v1] "v"(a_v1)
                          : GAOT_ATTN_FWD_STAGE_ASM_CLOBBERS);
+#endif
     }
     // ---- epilogue: o = acc / l (and 1 / (1 - p)), lse = log l (the bound-based tile carries no reference value) --------------------
     static_for<0, QT>([&](auto qc) {
         constexpr int qt = decltype(qc)::value;
+#if GAOT_ATTN_FWD_ASM_LSUM_MFMA
+        const float l = agpr_read<96 + 16 * qt>();          // every row of the ones-product is the complete row sum of the lane's query
+        (void)l0; (void)l1;
+#else
         float l = l0[qt] + l1[qt];
         l += xhalf(l);
+#endif
         const float inv = DROP ? a.drop.inv_keep / l : 1.f / l;
         float o[16];
         static_for<0, 16>([&](auto rc) {

@@ -27,6 +27,11 @@ KT = int(os.environ.get("GEN_FWD_KT", "8"))            # key tiles per stage (25
                   # staging, the loop's prologue -- is ~700 cycles per stage)
 TILE = 2048
 MFMA = "v_mfma_f32_32x32x16_bf16"
+# row sums l[q] = sum_k p[q][k] of the (undropped, packed) p: "dot2" = 8 v_dot2c_f32_bf16 per unit into two chains per query tile (in / out
+# operands of the statement), "mfma" = two more MFMAs per unit against a fragment of ones into a second accumulator per query tile
+# (a96-a159: every row of it is the row sum) -- 16 issue cycles instead of 32-68 (the dot products pay 8.5 cycles beside an MFMA)
+LSUM = os.environ.get("GEN_FWD_LSUM", "dot2")   # measured (profiles/r5_aa): mfma 0.4277 ms against 0.4190 for dot2 (compiled kernel 0.507):
+                                                # the two extra MFMAs cost more (clock) than the eight dot products they replace
 
 V0 = 48
 SC = [48, 64]                 # score tile S^T / p (16 regs), two buffers
@@ -35,19 +40,22 @@ KF = [96, 104]                # K row fragments of a key tile: k-step 0 (4 regs)
 VT = [112, 120]               # V^T fragments: k-step 0, k-step 1; two sets
 BW = [128, 136]               # the key tile's 8 pair words of the mask; two sets
 XT = 144                      # the mask's 8 pair words: xor, subtract, shift in place
-ONES = 152                    # bf16 (1.0, 1.0)
-V_END = 153
+ONES = 152                    # bf16 (1.0, 1.0) x 4 registers (one A fragment of ones; the dot products use the first)
+V_END = 156
 A_QF, A_ACC = 0, 32           # a0-a31 Q fragments [qt][s] x 4, a32-a95 O^T accumulators [qt] x 16
-A_END = A_ACC + 16 * QT
+A_L = A_ACC + 16 * QT         # a96-a159 row-sum accumulators [qt] x 16 (LSUM = "mfma")
+A_END = A_L + (16 * QT if LSUM == "mfma" else 0)
 
 
 def qf(qt, s): return ar(A_QF + 8 * qt + 4 * s, 4)
 def acc(qt): return ar(A_ACC + 16 * qt, 16)
+def lacc(qt): return ar(A_L + 16 * qt, 16)
 
 
 def gen_stage(drop: bool):
     st = Stream()
-    nv = 16 + 8 * (6 if drop else 2)          # vector instructions of a unit: 64 with dropout, 32 without
+    ndot = 1 if LSUM == "dot2" else 0
+    nv = 16 + 8 * ((5 if drop else 1) + ndot)          # vector instructions of a unit: 64 / 56 with dropout, 32 / 24 without
 
     def load_tile(kt):
         b = kt & 1
@@ -73,6 +81,13 @@ def gen_stage(drop: bool):
         kt, qt, b = u // QT, u % QT, u & 1
         st.ins(f"{MFMA} {acc(qt)}, {vr(VT[kt & 1] + 4 * s, 4)}, {vr(PK[b] + 4 * s, 4)}, {acc(qt)}", (f"v{kt}",) if qt == 0 and s == 0 else ())
 
+    def mfma_L(u, s):
+        """row sums of unit u's packed p BEFORE the mask is applied: issued inside unit u, behind its packs, ahead of its and-block"""
+        if os.environ.get("GEN_FWD_LAB", "") == "nomfma":
+            return
+        kt, qt, b = u // QT, u % QT, u & 1
+        st.ins(f"{MFMA} {lacc(qt)}, {vr(ONES, 4)}, {vr(PK[b] + 4 * s, 4)}, {lacc(qt)}")
+
     def valu_unit(u):
         """breadth first: no instruction reads the result of the one in front of it (a dependent pair costs the vector unit a bubble:
         the depth-first order -- pack, row sum, xor, subtract, shift, and per pair -- measured 0.494 ms against 0.529 for the compiled
@@ -88,14 +103,15 @@ def gen_stage(drop: bool):
             for j in range(8):
                 nd = (f"w{kt}",) if (qt == 0 and j == 0) else ()
                 seq.append(lambda j=j, nd=nd: st.ins(f"v_xor_b32 {vr(XT + j)}, {vr(W + j)}, %[aw{qt}]", nd))
-                seq.append(lambda j=j: st.ins(f"v_dot2c_f32_bf16 %[l{j & 1}{qt}], {vr(P + j)}, {vr(ONES)}"))   # l stays undropped
+                if ndot:
+                    seq.append(lambda j=j: st.ins(f"v_dot2c_f32_bf16 %[l{j & 1}{qt}], {vr(P + j)}, {vr(ONES)}"))   # l stays undropped
             for j in range(8):
                 seq.append(lambda j=j: st.ins(f"v_pk_sub_i16 {vr(XT + j)}, %[tpk], {vr(XT + j)} clamp"))       # < 0 iff kept
             for j in range(8):
                 seq.append(lambda j=j: st.ins(f"v_pk_ashrrev_i16 {vr(XT + j)}, 15, {vr(XT + j)} op_sel_hi:[0,1]"))   # the inline 15 for BOTH halves
             for j in range(8):
                 seq.append(lambda j=j: st.ins(f"v_and_b32 {vr(P + j)}, {vr(P + j)}, {vr(XT + j)}"))
-        else:
+        elif ndot:
             for j in range(8):
                 seq.append(lambda j=j: st.ins(f"v_dot2c_f32_bf16 %[l{j & 1}{qt}], {vr(P + j)}, {vr(ONES)}"))
         assert len(seq) == nv
@@ -110,10 +126,17 @@ def gen_stage(drop: bool):
     #   predecessor stalls the wave -- the loop without vector instructions runs at 60 cycles per MFMA, profiles/r5_ac) BEHIND the
     #   row-sum block: v_dot2c_f32_bf16 costs 8.5 instead of 4 cycles while the matrix pipe runs (tools/lab/inst_cost.hip), so that
     #   block stays clear of the MFMAs' 32 cycles.
-    P = {"S0": 1, "S1": 9, "PV0": 16, "PV1": 40 if drop else 29}
-    assert P["PV1"] < nv - 1 and nv - P["S1"] >= 12
+    if LSUM == "mfma":
+        # six MFMAs per unit; the packs end at 24, the and-block starts at nv - 8: L0 / L1 read the unmasked packs in between
+        # (without the mask the packs stay intact: the row-sum MFMAs of unit u - 1 ride in unit u like its PV products -- six MFMAs
+        # at four-instruction spacing, the unit is bound by the matrix pipe: 6 x 32 cycles)
+        P = {"S0": 1, "S1": 9, "PV0": 16, "L0": 26, "L1": 34, "PV1": 43} if drop else {"S0": 0, "S1": 4, "PV0": 8, "PV1": 12, "L0": 16, "L1": 20}
+    else:
+        P = {"S0": 1, "S1": 9, "PV0": 16, "PV1": 40 if drop else 29}
+    assert P["PV1"] < nv - 1 and nv - P["S1"] >= 12 and max(P.values()) < nv
     # ---- prologue ----------------------------------------------------------------------------------------------------------------
-    st.ins(f"v_mov_b32 {vr(ONES)}, 0x3f803f80")
+    for i in range(4 if LSUM == "mfma" else 1):
+        st.ins(f"v_mov_b32 {vr(ONES + i)}, 0x3f803f80")
     load_tile(0)
     mfma_S(0, 0)
     mfma_S(0, 1)
@@ -133,6 +156,12 @@ def gen_stage(drop: bool):
         if u + 1 < NU:
             at(P["S0"], lambda u=u: mfma_S(u + 1, 0))
             at(P["S1"], lambda u=u: mfma_S(u + 1, 1))
+        if LSUM == "mfma" and drop:
+            at(P["L0"], lambda u=u: mfma_L(u, 0))
+            at(P["L1"], lambda u=u: mfma_L(u, 1))
+        if LSUM == "mfma" and not drop and u > 0:
+            at(P["L0"], lambda u=u: mfma_L(u - 1, 0))
+            at(P["L1"], lambda u=u: mfma_L(u - 1, 1))
         if qt == 1 and kt >= 1 and kt + 1 < KT:
             # the other fragment set was last read by PV(kt-1, QT-1), issued in unit (kt, 0): free from unit (kt, 1) on
             at(P["PV1"] + 2, lambda kt=kt: load_tile(kt + 1))
@@ -141,10 +170,14 @@ def gen_stage(drop: bool):
                 e()
             if lab != "novalu":
                 fn()
+
     u = NU - 1
     st.ins("s_nop 1")
     mfma_PV(u, 0)
     mfma_PV(u, 1)
+    if LSUM == "mfma" and not drop:
+        mfma_L(u, 0)
+        mfma_L(u, 1)
     st.ins("s_waitcnt lgkmcnt(0)")
     st.ins("s_nop 7")
     st.ins("s_nop 7")
@@ -178,6 +211,7 @@ def main():
     out.append("#define GAOT_ATTN_FWD_ASM_ACC_CLOBBERS " + ", ".join(f'"a{i}"' for i in range(A_ACC, A_END)) + ', "memory"')
     out.append(f"#define GAOT_ATTN_FWD_ASM_QT {QT}")
     out.append(f"#define GAOT_ATTN_FWD_ASM_KT {KT}")
+    out.append(f"#define GAOT_ATTN_FWD_ASM_LSUM_MFMA {1 if LSUM == 'mfma' else 0}")
     print("\n".join(out))
 
 
