@@ -5,7 +5,9 @@ counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coale
 value is kept alongside).  usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [tag]"""
 import collections, csv, glob, json, sys
 
-NAMES = [("k_attn_fwd_bf16", "attn_fwd"), ("k_attn_bwd_dkv_kb", "attn_bwd_dkv"), ("k_attn_bwd_dkv_bf16", "attn_bwd_dkv"), ("k_attn_bwd_dq_kb", "attn_bwd_dq"), ("k_attn_bwd_dq_bf16", "attn_bwd_dq"),
+# (the forward's main pass only: k_attn_fwd_asm or the compiled bound-based kernel <4, 4, ...>; the adaptive fallback launch <3, 4, ...> that
+# follows it finds no flagged workgroup in the benchmark and would halve the per-launch average)
+NAMES = [("k_attn_fwd_asm", "attn_fwd"), ("k_attn_fwd_bf16<4", "attn_fwd"), ("k_attn_bwd_dkv_kb", "attn_bwd_dkv"), ("k_attn_bwd_dkv_bf16", "attn_bwd_dkv"), ("k_attn_bwd_dq_kb", "attn_bwd_dq"), ("k_attn_bwd_dq_bf16", "attn_bwd_dq"),
          ("k_attn_fwd_f32", "attn_fwd"), ("k_attn_bwd_dkv_f32", "attn_bwd_dkv"), ("k_attn_bwd_dq_f32", "attn_bwd_dq"),
          ("k_gno_fwd_bf16<3", "gno_fwd_nh3"), ("k_gno_fwd_bf16<2", "gno_fwd_nh2"), ("k_gno_bwd3_bf16<3", "gno_bwd_nh3"),
          ("k_gno_bwd3_bf16<2", "gno_bwd_nh2"), ("k_attn_bwd_fused", "attn_bwd"), ("k_attn_bwd_asm", "attn_bwd"),
