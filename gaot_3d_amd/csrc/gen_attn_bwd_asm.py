@@ -39,6 +39,8 @@ TILE = 2048
 # "lds" = through a wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit).  LDS instructions cost ~13 issue
 # cycles each on the port the vector stream needs (profiles/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
 TR_DROP = os.environ.get("GEN_TR_DROP", "mfma")       # measured: 0.854 (mfma) against 0.896 ms for the compiled kernel on one box, lds 0.838 / 0.843
+ORDER = os.environ.get("GEN_ORDER", "depth")      # the unit's vector stream: "depth" (pair by pair; shipped) | "breadth" (two pairs at a time, kind by kind, in
+                                                   # place: measured 0.8166 / 0.8188 against 0.8185 / 0.8179 ms, profiles/r5_ag -- nothing; the forward's loop gained 4 % from it)
 DS_FORM = os.environ.get("GEN_DS", "fmac")           # dropout: dS = p (-delta') + (keep p) dP' (mul + fmac) | "select": p select(keep, dP' - delta', -delta') (measurement builds)
 TR_NODROP = os.environ.get("GEN_TR_NODROP", "lds")   # without dropout the unit is MFMA bound: 12 MFMAs cost more than the LDS round trip (0.726 against 0.684 ms)
 
@@ -229,21 +231,58 @@ def gen_stage(drop: bool):
 
     # ---- the vector stream of a unit: a list of closures, one per instruction --------------------------------------------------
     def valu_unit(u):
+        """ORDER (GEN_ORDER): "depth" = pair by pair (exp, exp, select, select, multiply, multiply-add, pack, pack: every instruction
+        reads a result one or two instructions old); "breadth" = two pairs at a time, kind by kind, everything in place -- p in the score
+        registers, dS in the dP registers (dP <- (keep p) dP', then += p (-delta')), only the kept p in temporaries -- so that no
+        instruction reads a result younger than four instructions (the forward's tile loop gained 4 % from this order)"""
         t, kb, b = u // KB, u % KB, u & 1
         S, DP, DCt = SB[b], DB[b], DC[t & 1]
         seq = []
+        def M(j, h): return f"s[{SM0 + 4 * j + 2 * h}:{SM0 + 4 * j + 2 * h + 1}]"
         if drop:
-            for j in range(8):
-                x = XR[j & 1]
-                m0, m1 = f"s[{SM0 + 4 * j}:{SM0 + 4 * j + 1}]", f"s[{SM0 + 4 * j + 2}:{SM0 + 4 * j + 3}]"
-                nd = (f"w8{t}",) if (j == 0) else ()
-                seq.append(lambda x=x, j=j, nd=nd: st.ins(f"v_xor_b32 {vr(x)}, {vr(W8 + j)}, %[bsel{kb}]", nd))
-                seq.append(lambda x=x, m0=m0: st.ins(f"v_cmp_ge_u32_sdwa {m0}, {vr(x)}, %[thr] src0_sel:WORD_0 src1_sel:DWORD"))
-                seq.append(lambda x=x, m1=m1: st.ins(f"v_cmp_ge_u32_sdwa {m1}, {vr(x)}, %[thr] src0_sel:WORD_1 src1_sel:DWORD"))
+            if ORDER == "breadth":
+                for j in range(0, 8, 2):
+                    nd = (f"w8{t}",) if (j == 0) else ()
+                    seq.append(lambda j=j, nd=nd: st.ins(f"v_xor_b32 {vr(XR[0])}, {vr(W8 + j)}, %[bsel{kb}]", nd))
+                    seq.append(lambda j=j: st.ins(f"v_xor_b32 {vr(XR[1])}, {vr(W8 + j + 1)}, %[bsel{kb}]"))
+                    for h in range(2):
+                        for jj in range(2):
+                            seq.append(lambda j=j, h=h, jj=jj: st.ins(f"v_cmp_ge_u32_sdwa {M(j + jj, h)}, {vr(XR[jj])}, %[thr] src0_sel:WORD_{h} src1_sel:DWORD"))
+            else:
+                for j in range(8):
+                    x = XR[j & 1]
+                    nd = (f"w8{t}",) if (j == 0) else ()
+                    seq.append(lambda x=x, j=j, nd=nd: st.ins(f"v_xor_b32 {vr(x)}, {vr(W8 + j)}, %[bsel{kb}]", nd))
+                    seq.append(lambda x=x, j=j: st.ins(f"v_cmp_ge_u32_sdwa {M(j, 0)}, {vr(x)}, %[thr] src0_sel:WORD_0 src1_sel:DWORD"))
+                    seq.append(lambda x=x, j=j: st.ins(f"v_cmp_ge_u32_sdwa {M(j, 1)}, {vr(x)}, %[thr] src0_sel:WORD_1 src1_sel:DWORD"))
+        if ORDER == "breadth":
+            T4 = TMP[0][:4]
+            for j in range(0, 8, 2):
+                rs = [2 * j, 2 * j + 1, 2 * j + 2, 2 * j + 3]
+                for r in rs:
+                    seq.append(lambda r=r: st.ins(f"v_exp_f32 {vr(S + r)}, {vr(S + r)}"))
+                if drop:
+                    for i, r in enumerate(rs):
+                        seq.append(lambda i=i, r=r: st.ins(f"v_cndmask_b32_e64 {vr(T4[i])}, 0, {vr(S + r)}, {M(r // 2, r & 1)}"))
+                    for i, r in enumerate(rs):
+                        seq.append(lambda i=i, r=r: st.ins(f"v_mul_f32 {vr(DP + r)}, {vr(T4[i])}, {vr(DP + r)}"))
+                    for r in rs:
+                        seq.append(lambda r=r: st.ins(f"v_fmac_f32 {vr(DP + r)}, {vr(S + r)}, {vr(DCt + r)}"))
+                    seq.append(lambda j=j: st.ins(f"v_cvt_pk_bf16_f32 {vr(PPK + j)}, {vr(T4[0])}, {vr(T4[1])}"))
+                    seq.append(lambda j=j: st.ins(f"v_cvt_pk_bf16_f32 {vr(PPK + j + 1)}, {vr(T4[2])}, {vr(T4[3])}"))
+                else:
+                    for r in rs:
+                        seq.append(lambda r=r: st.ins(f"v_mul_f32 {vr(DP + r)}, {vr(S + r)}, {vr(DP + r)}"))
+                    seq.append(lambda j=j, rs=rs: st.ins(f"v_cvt_pk_bf16_f32 {vr(PPK + j)}, {vr(S + rs[0])}, {vr(S + rs[1])}"))
+                    seq.append(lambda j=j, rs=rs: st.ins(f"v_cvt_pk_bf16_f32 {vr(PPK + j + 1)}, {vr(S + rs[2])}, {vr(S + rs[3])}"))
+                seq.append(lambda j=j, rs=rs: st.ins(f"v_cvt_pk_bf16_f32 {vr(DSPK + j)}, {vr(DP + rs[0])}, {vr(DP + rs[1])}"))
+                seq.append(lambda j=j, rs=rs: st.ins(f"v_cvt_pk_bf16_f32 {vr(DSPK + j + 1)}, {vr(DP + rs[2])}, {vr(DP + rs[3])}"))
+            assert len(seq) == nv, (len(seq), nv)
+            return seq
         for j in range(8):
             r0, r1 = 2 * j, 2 * j + 1
             p0, p1, pm0, pm1, t0, t1 = TMP[j & 1]
-            m0, m1 = f"s[{SM0 + 4 * j}:{SM0 + 4 * j + 1}]", f"s[{SM0 + 4 * j + 2}:{SM0 + 4 * j + 3}]"
+            m0, m1 = M(j, 0), M(j, 1)
             seq.append(lambda p0=p0, r0=r0: st.ins(f"v_exp_f32 {vr(p0)}, {vr(S + r0)}"))
             seq.append(lambda p1=p1, r1=r1: st.ins(f"v_exp_f32 {vr(p1)}, {vr(S + r1)}"))
             if drop:
