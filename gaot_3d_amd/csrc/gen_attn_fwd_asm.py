@@ -133,6 +133,8 @@ def gen_stage(drop: bool):
         P = {"S0": 1, "S1": 9, "PV0": 16, "L0": 26, "L1": 34, "PV1": 43} if drop else {"S0": 0, "S1": 4, "PV0": 8, "PV1": 12, "L0": 16, "L1": 20}
     else:
         P = {"S0": 1, "S1": 9, "PV0": 16, "PV1": 40 if drop else 29}
+        if os.environ.get("GEN_FWD_POS") and drop:      # measurement builds: "S0,S1,PV0,PV1"
+            P = dict(zip(("S0", "S1", "PV0", "PV1"), (int(x) for x in os.environ["GEN_FWD_POS"].split(","))))
     assert P["PV1"] < nv - 1 and nv - P["S1"] >= 12 and max(P.values()) < nv
     # ---- prologue ----------------------------------------------------------------------------------------------------------------
     for i in range(4 if LSUM == "mfma" else 1):
