@@ -1829,7 +1829,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
 // the AGPRs a32-a159 (the four O^T accumulators and the four row-sum accumulators: two more MFMAs per unit against a fragment of
 // ones), reads a0-a31 (the Q fragments); the AGPRs live ACROSS the statements.  Same arithmetic as the compiled tile (same packs, same mask words, row sums of the packed p); the
 // K / V^T fragments and the mask's column words of a key tile are read from LDS once for the four query tiles.
-// Launches whose sequence length is not a multiple of 512, or that split the key range, keep the compiled kernel.
+// Few-head launches split the key range over blockIdx.y exactly as the compiled kernel does (parts combined by k_attn_combine).
+// Launches whose sequence length is not a multiple of 512 (or whose key ranges are not multiples of 256) keep the compiled kernel.
 // ------------------------------------------------------------------------------------------------
 #include "attn_fwd_asm.inc"
 struct FwdAsmLds {
@@ -1880,8 +1881,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
         for (int o = 32; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
         const int over = __syncthreads_or(!(q2max * k2 <= BOUND2));
         // the adaptive kernel runs on the compiled kernel's grid (128 queries per workgroup): this workgroup stands for four of them
+        // (blockIdx.y = key-range part of a few-head launch: the compiled grid's y, same flag layout)
         if (threadIdx.x < 4)
-            a.redo[(qblk * 4 + threadIdx.x) * a.H + head + (int64_t)(a.S / 128) * a.H * b] = over ? 1 : 0;
+            a.redo[(qblk * 4 + threadIdx.x) * a.H + head + (int64_t)(a.S / 128) * a.H * (blockIdx.y + gridDim.y * b)] = over ? 1 : 0;
         if (over) return;
     }
     uint32_t aw[QT] = {0, 0, 0, 0}, ck = 0;
@@ -1910,14 +1912,17 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
     const unsigned a_w = lbase + L::BW + hf * 32;
     uint32_t* bw_s = reinterpret_cast<uint32_t*>(lds + L::BW);
 
+    // keys [lo, hi) of this workgroup: the whole sequence, or part blockIdx.y of a few-head launch (chunk % 256 == 0; the parts'
+    // normalised O / lse are combined by k_attn_combine as for the compiled kernel)
+    const int64_t lo = (int64_t)blockIdx.y * a.chunk, hi = min((int64_t)a.S, lo + a.chunk);
     uint4 regs[KT];
-    stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, 0, a.S);
-    for (int64_t k0 = 0; k0 < a.S; k0 += L::KEYS) {
+    stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, lo, a.S);
+    for (int64_t k0 = lo; k0 < hi; k0 += L::KEYS) {
         __syncthreads();
         stage_storeN<KT>(regs, lds + L::STAGE);
         if constexpr (DROP) stage_col_words<KT>(bw_s, ck, k0);
         __syncthreads();
-        if (k0 + L::KEYS < a.S) stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, k0 + L::KEYS, a.S);
+        if (k0 + L::KEYS < hi) stage_loadN<KT>(regs, kp, a.ld, vp, a.ld, k0 + L::KEYS, a.S);
         if constexpr (LAB == 1) continue;
 #if GAOT_ATTN_FWD_ASM_LSUM_MFMA
         // (the row sums accumulate in a96-a159 through two MFMAs per unit against a fragment of ones)
@@ -1963,11 +1968,11 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_asm(FwdArgs a) {
             o[r] = agpr_read<32 + 16 * qt + r>() * inv;
         });
         const int64_t qi = q0 + 32 * qt + l31;
-        float* op = a.o + (rowbase + qi) * (a.H * D) + head * D;
+        float* op = a.o + blockIdx.y * a.o_part + (rowbase + qi) * (a.H * D) + head * D;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(op + 8 * g + 4 * hf) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
-        if (hf == 0) a.lse[((int64_t)b * a.H + head) * a.S + qi] = logf(l);
+        if (hf == 0) a.lse[blockIdx.y * a.lse_part + ((int64_t)b * a.H + head) * a.S + qi] = logf(l);
     });
 }
 
@@ -2174,11 +2179,12 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // GAOT_ATTN_FWD_LAB = 1 / 8 forces the adds / the dot products for both (measurement only).
     static const int fwd_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_LAB"); return e ? atoi(e) : 0; }();
     const bool dot2 = fwd_lab == 8 || (fwd_lab != 1 && a.drop.thr);
-    // whole-sequence launches with S a multiple of 512 and at least half a workgroup per CU: the one-wave-per-SIMD kernel with the
-    // generated tile loop (k_attn_fwd_asm) does the bound-based pass; GAOT_ATTN_FWD_ASM=0 keeps the compiled kernel (measurement)
+    // launches with S a multiple of 512 and at least half a workgroup per CU (key-range parts included): the one-wave-per-SIMD kernel
+    // with the generated tile loop (k_attn_fwd_asm) does the bound-based pass; GAOT_ATTN_FWD_ASM=0 keeps the compiled kernel (measurement)
     const bool fwd_asm = [] { const char* e = getenv("GAOT_ATTN_FWD_ASM"); return !e || atoi(e) != 0; }();   // read per call: tests switch it
-    if (fwd_asm && fwd_lab == 0 && P == 1 && S % FwdAsmLds::QUERIES == 0 && (int64_t)(S / FwdAsmLds::QUERIES) * H * B >= 128) {
-        const dim3 agrid((unsigned)((S / FwdAsmLds::QUERIES) * H), 1, (unsigned)B);
+    if (fwd_asm && fwd_lab == 0 && S % FwdAsmLds::QUERIES == 0 && (P == 1 || a.chunk % FwdAsmLds::KEYS == 0) &&
+        (int64_t)(S / FwdAsmLds::QUERIES) * H * B * fgrid.y >= 128) {
+        const dim3 agrid((unsigned)((S / FwdAsmLds::QUERIES) * H), fgrid.y, (unsigned)B);
         static const int asm_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_ASM_LAB"); return e ? atoi(e) : 0; }();
         if (asm_lab == 1) {
             if (a.drop.thr) GAOT_KLAUNCH((k_attn_fwd_asm<true, 1>), agrid, dim3(256), 0, st, a);
