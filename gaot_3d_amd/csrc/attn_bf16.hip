@@ -1607,6 +1607,10 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
     const int rep = a.H / a.HKV;
     const int64_t key0 = (int64_t)slab * L::KEYS + wave * (32 * KB);
     const int64_t rowbase = (int64_t)b * a.S;
+    // query range of this workgroup (blockIdx.y): few heads per launch -- the heads of one rank of a sharded step -- split the queries
+    // over parts exactly as k_attn_bwd_fused does (chunk % 128 == 0); a part's dK / dV go to its own copy (summed by k_sum_cols),
+    // its dQ slab partials cover its own queries
+    const int64_t q_lo = (int64_t)blockIdx.y * a.chunk, q_hi = min((int64_t)a.S, q_lo + a.chunk);
     // ---- the wave's K / V rows -> AGPR fragments; K rows once through a wave-private tile for the transposed (K^T) fragments ----
     asm volatile(GAOT_ATTN_BWD_ASM_ZERO_ACC ::: GAOT_ATTN_BWD_ASM_ACC_CLOBBERS);
     {
@@ -1725,7 +1729,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             }
         };
         uint4 regs[NST];
-        stage_load(regs, 0);
+        stage_load(regs, q_lo);
         float lt = 0.f, et = 0.f;
         auto load_consts = [&](int64_t qbase) {
             if (threadIdx.x < QS) {
@@ -1733,7 +1737,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
                 et = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(del_rs, threadIdx.x * 4, (int)qbase * 4, 0));
             }
         };
-        load_consts(0);
+        load_consts(q_lo);
         uint32_t rk = 0, bsel[KB] = {0, 0, 0, 0};
         if constexpr (DROP) {
             const int bh = a.drop.bh(b, head);
@@ -1751,7 +1755,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
         float* lse_w = reinterpret_cast<float*>(lds + L::LSE);
         float* del_w = reinterpret_cast<float*>(lds + L::DEL);
         uint32_t* aw_w = reinterpret_cast<uint32_t*>(lds + L::AW);
-        for (int64_t q0 = 0; q0 < a.S; q0 += QS) {
+        for (int64_t q0 = q_lo; q0 < q_hi; q0 += QS) {
             if constexpr (LAB != 3) __syncthreads();     // A: every wave is done with the staged tiles and has written its slots of the previous stage
             stage_store(regs);
             if (threadIdx.x < QS) {
@@ -1768,9 +1772,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
                     aw_w[QS / 2 + 4 + u] = (w0 >> 16) | (w1 & 0xffff0000u);
                 }
             }
-            if (q0 > 0 && LAB < 2) reduce_slots(q0 - QS);
+            if (q0 > q_lo && LAB < 2) reduce_slots(q0 - QS);
             if constexpr (LAB != 3) __syncthreads();     // B
-            if (q0 + QS < a.S) {
+            if (q0 + QS < q_hi) {
                 stage_load(regs, q0 + QS);
                 load_consts(q0 + QS);
             }
@@ -1794,7 +1798,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
                              : GAOT_ATTN_BWD_STAGE_ASM_CLOBBERS);
         }
         __syncthreads();
-        reduce_slots(((a.S - 1) / QS) * (int64_t)QS);
+        reduce_slots(q_lo + ((q_hi - 1 - q_lo) / QS) * (int64_t)QS);
     }
     const float vsc = DROP ? a.drop.inv_keep : 1.f;
     const float ksc = vsc / LOG2E;
@@ -1808,8 +1812,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_bwd_asm(FusedArgs fa) {
             dv[r] = agpr_read<64 + 16 * kb + r>();
         });
         if (ki < a.S) {
-            float* dkp = a.dqkv + (rowbase + ki) * a.ld + (a.H + hkv) * D;
-            float* dvp = a.dqkv + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
+            float* dkp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + hkv) * D;
+            float* dvp = a.dqkv + blockIdx.y * a.dqkv_part + (rowbase + ki) * a.ld + (a.H + a.HKV + hkv) * D;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 t = make_float4(dk[4 * g] * ksc, dk[4 * g + 1] * ksc, dk[4 * g + 2] * ksc, dk[4 * g + 3] * ksc);
@@ -2283,9 +2287,9 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             // k_attn_bwd_asm (one wave per SIMD, hand-scheduled tile loop, dS transposed on the matrix pipe with dropout / through LDS
             // without) is the default for whole-sequence launches: same box, S = 16 384, H = 8 (profiles/r5_d_attn_bwd_asm_mfma_t2.txt):
             // 0.798 against 0.836 ms with dropout (-4.5 %), 0.669 against 0.717 ms without (-6.7 %); dK / dV bit-identical to the compiled
-            // kernel, dQ within 5e-5 of peak (four slots of four key blocks instead of eight of two).  Few heads per launch (query-range
-            // parts) keep the compiled kernel.  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
-            if ((variant == 2 || (variant == 0 && lab == 0 && !want_stamps)) && nyf == 1) {
+            // kernel, dQ within 5e-5 of peak (four slots of four key blocks instead of eight of two).  Few heads per launch: query-range
+            // parts as in the compiled kernel (ranges that are multiples of 128 queries; others keep the compiled kernel).  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
+            if ((variant == 2 || (variant == 0 && lab == 0 && !want_stamps)) && (nyf == 1 || chunk_f % AsmLds<true>::QS == 0)) {
                 if (lab == 1) rc = drop ? go(k_attn_bwd_asm<true, 1>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 1>, AsmLds<false>::TOTAL, 256);
                 else if (lab == 2) rc = drop ? go(k_attn_bwd_asm<true, 2>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 2>, AsmLds<false>::TOTAL, 256);
                 else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds<false>::TOTAL, 256);

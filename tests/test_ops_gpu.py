@@ -228,7 +228,9 @@ def test_attention_forward_asm_kernel_equals_compiled_kernel(b, s, h, hkv, p, mo
     ob, lb, _ = ops.attn_fwd_bf16(big, freqs, b, s, h, hkv, scale, p, seed)
     torch.cuda.synchronize()
     assert torch.isfinite(oa).all() and torch.isfinite(la).all()
-    assert float((oa - ob).abs().max()) <= 3e-4 * float(ob.abs().max()) + 1e-7 and float((la - lb).abs().max()) <= 3e-4
+    # (rows whose sum is dominated by one huge p: the packed row sum carries that p's bf16 rounding, 2^-9, the fp32 sum of the compiled
+    # tile does not -- the two forms differ by up to that much there)
+    assert float((oa - ob).abs().max()) <= 4e-3 * float(ob.abs().max()) + 1e-7 and float((la - lb).abs().max()) <= 4e-3
 
 
 @pytest.mark.parametrize("m,k,ns", [(8, 64, (64, 64, 64)), (300, 256, (256, 128, 128)), (1000, 64, (128, 128))])
