@@ -115,18 +115,21 @@ __global__ void k_geo_moments(const float* __restrict__ src_pos, const float* __
     // order as before, edge by edge, so the moments are bit-identical
     constexpr int U = 4;
     for (int i0 = b + gl; i0 < e; i0 += U * G) {
+        // (unconditional loads on clamped indices: a guarded load compiles to a branch with its own wait -- four dependent round trips)
         int sidx[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) sidx[u] = (i0 + u * G < e) ? src_sorted[i0 + u * G] : -1;
+        for (int u = 0; u < U; ++u) sidx[u] = src_sorted[min(i0 + u * G, e - 1)];
         float f[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t o = (int64_t)(sidx[u] < 0 ? 0 : sidx[u]) * 3;
+            const int64_t o = (int64_t)sidx[u] * 3;
             f[u][0] = src_pos[o + 0]; f[u][1] = src_pos[o + 1]; f[u][2] = src_pos[o + 2];
         }
 #pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(f[u][0]), "+v"(f[u][1]), "+v"(f[u][2]));   // all twelve words requested HERE, not inside the guards below
+#pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (sidx[u] < 0) break;
+            if (i0 + u * G >= e) break;
             const float fx = f[u][0], fy = f[u][1], fz = f[u][2];
             const float dx = fx - qxf, dy = fy - qyf, dz = fz - qzf;          // fp32 difference and norm, as the reference
             const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
