@@ -280,7 +280,8 @@ def defer_ok(params) -> bool:
     dist = torch.distributed
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return False
-    task = torch._C._current_graph_task_id()
+    get_task = getattr(torch._C, "_current_graph_task_id", None)      # (a private hook of the autograd engine: without it, no deferral)
+    task = get_task() if get_task is not None else -1
     if task < 0 or torch.is_grad_enabled() or torch.is_anomaly_enabled():   # not in a backward pass / create_graph / NaN checks
         return False
     if _DEFER["task"] != task:
