@@ -231,6 +231,29 @@ def dump_graph_structure(graph, path):
     graph.instantiate()
 
 
+def graph_node_counts(graph):
+    """node census of a captured step through the HIP graph API (the graph must have been created with keep_graph=True and not
+    yet be instantiated): every kernel node -- ours AND whatever ATen / the runtime put there -- plus memcpy / memset nodes"""
+    import ctypes as C
+    import collections
+    hip = C.CDLL("libamdhip64.so")
+    g = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, C.byref(n)) != 0:
+        return None
+    nodes = (C.c_void_p * n.value)()
+    hip.hipGraphGetNodes(g, nodes, C.byref(n))
+    names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "child_graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+    cnt = collections.Counter()
+    for i in range(n.value):
+        t = C.c_int(-1)
+        hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t))
+        cnt[names.get(t.value, f"type{t.value}")] += 1
+    out = dict(cnt)
+    out["total"] = n.value
+    return out
+
+
 def step_roofline_ms(n_pts, m_lat, e_enc, e_dec, s_tok, layers, precision, d=256, f=1024, c=32, out=1):
     """t_roof = sum over stages of max(bytes / HBM rate, flops / matrix rate of the arithmetic used).
     Transformer per layer forward 8 S d^2 + 4 S^2 d + 6 S d F (+ 4 S d^2 skip_proj in the decoder half), backward 2x;
@@ -483,6 +506,9 @@ def main(argv=None):
     from gaot_3d_amd.model import init_model
     from gaot_3d_amd.optim import AdamW   # fused multi-tensor HIP step, same semantics as torch.optim.AdamW (tests)
     gaot_3d_amd.set_precision(args.precision)
+    # deferred weight-gradient reductions are opt-in (ops.defer_ok): this step qualifies -- every parameter has one consumer, all of
+    # them gaot operators, no hooks, no process group at N = 1 (with one initialised, defer_ok declines by itself)
+    ops.defer_reductions(os.environ.get("GAOT_DEFER_REDUCE", "1") != "0")
     if args.points is None:
         args.points = WORKLOADS[args.workload][6]
     if world > 1 and args.workload not in ("cfg1", "cfg4"):
@@ -542,10 +568,12 @@ def main(argv=None):
     # ONE whole step (CSR build, forward, loss, backward, gradient exchange, AdamW) into a hipGraph after the warm-up and
     # replay it: the timed region then measures the device work.  --no-graph times the eager launches instead.
     last_step_ms = []      # device ms of every timed step of the latest measure() call
+    last_capture = {"error": None, "nodes": None}     # of the latest measure() call: why a capture failed / the node census
 
     def measure(step, steps, warmup, use_graph):
         graph = None
         loss = None
+        last_capture["error"], last_capture["nodes"] = None, None
         if use_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -556,15 +584,22 @@ def main(argv=None):
             torch.cuda.synchronize()
             try:
                 dot = os.environ.get("GAOT_BENCH_GRAPH_DOT")    # diagnostic: node / edge structure of the captured step
-                graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
+                graph = torch.cuda.CUDAGraph(keep_graph=True)
                 # N>1: ProcessGroupNCCL's watchdog thread polls events of earlier collectives while this thread captures;
                 # under the default "global" capture mode that query is an error that aborts the process
                 with torch.cuda.graph(graph, capture_error_mode="global" if world == 1 else "thread_local"):
                     loss = step()
+                try:
+                    last_capture["nodes"] = graph_node_counts(graph)
+                except Exception as ex:
+                    last_capture["nodes"] = {"error": f"{type(ex).__name__}: {ex}"}
                 if dot:
-                    dump_graph_structure(graph, dot)
-            except Exception as ex:  # capture is a launch optimisation only; fall back to eager launches
+                    dump_graph_structure(graph, dot)        # instantiates
+                else:
+                    graph.instantiate()
+            except Exception as ex:  # capture is a launch optimisation only; the eager launches are timed and the line SAYS so
                 print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); timing eager launches", file=sys.stderr)
+                last_capture["error"] = f"{type(ex).__name__}: {str(ex)[:200]}"
                 graph = None
                 torch.cuda.synchronize()
         for _ in range(warmup):
@@ -672,6 +707,7 @@ def main(argv=None):
     model, step, edge_counts, step_ctx = build(n_total, args.atten_dropout, args.parallel)
     elapsed, graph, loss, t_host_main = measure(step, args.steps, args.warmup, use_graph)
     main_step_ms = list(last_step_ms)
+    main_capture = dict(last_capture)
     eager_rec = seg_rec = None
     exchange_profile = {}
 
@@ -968,6 +1004,10 @@ def main(argv=None):
             "loss": float(loss.detach()),
             "launch": launch_txt,
             "kernel_launches_per_step": launches,
+            # census of the REPLAYED graph (HIP graph API): kernel nodes = our launches + whatever ATen / the runtime added
+            "graph_nodes_per_step": main_capture["nodes"],
+            "foreign_kernel_nodes_per_step": (main_capture["nodes"]["kernel"] - launches
+                                              if main_capture["nodes"] and "kernel" in main_capture["nodes"] else None),
             "host_ms_per_step_timed_region": round(host_ms / args.steps * 1e3, 3),
             # wall / host time of the two instrumented eager steps (right after a capture the eager allocations go back
             # to hipMalloc, so with a captured graph these overstate a warmed-up eager step)
@@ -992,7 +1032,12 @@ def main(argv=None):
         launch_txt = (f"segmented hipGraph replay: {graph.num_segments} graph launches + {graph.num_exchanges} eagerly issued "
                       f"exchange steps per step, no collective captured")
     else:
-        launch_txt = "hipGraph replay of one captured step" if graph is not None else "eager"
+        if graph is not None:
+            launch_txt = "hipGraph replay of one captured step"
+        elif main_capture["error"]:
+            launch_txt = f"eager (hipGraph capture failed: {main_capture['error']})"
+        else:
+            launch_txt = "eager"
     out = make_out(elapsed, launch_txt, t_host_main, main_step_ms) if rank == 0 else None
     if world > 1:
         # one line that explains a flat curve: per rank, the device time inside exchange steps (per collective kind, with the

@@ -3,6 +3,7 @@ pass raw pointers to libgaot3d_hip.so.  Every function requires CUDA(HIP) tensor
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -258,51 +259,88 @@ class _ReduceDesc(C.Structure):   # gaot_reduce_desc_t
     _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("parts", C.c_int32), ("lanes", C.c_int32)]
 
 
-_DEFER = {"enabled": os.environ.get("GAOT_DEFER_REDUCE", "1") != "0", "task": -1, "pending": [], "seen": set()}
+# The deferral is OPT-IN (round 6): a step that knows every parameter has ONE consumer that goes through these operators
+# (bench.py, sharding.ShardedStep at world size 1, a trainer after reading INTEGRATION.md §5) calls ``defer_reductions(True)`` or sets
+# GAOT_DEFER_REDUCE=1.  Off, every reduction completes inside the call that produced it.
+_DEFER = {"enabled": os.environ.get("GAOT_DEFER_REDUCE", "0") == "1",
+          "stack": [],            # [(graph-task id, {id(param)})]: the running backward pass and the passes it is nested in
+          "pending": [], "pending_bytes": 0,
+          "cap_bytes": int(os.environ.get("GAOT_DEFER_CAP_MB", "1024")) << 20}
 
 
 def defer_reductions(enabled: bool) -> bool:
-    """switch the deferral on / off (default on; GAOT_DEFER_REDUCE=0); returns the previous setting"""
+    """switch the deferral on / off (default OFF; GAOT_DEFER_REDUCE=1 turns it on); returns the previous setting.  Whatever is
+    pending is completed first and the per-pass bookkeeping is dropped."""
     prev, _DEFER["enabled"] = _DEFER["enabled"], bool(enabled)
+    _flush_pending()
+    _DEFER["stack"].clear()
     return prev
 
 
+def _task_done(task: int) -> None:
+    """final callback of graph task ``task``: complete what is pending, forget the pass (and any nested pass above it that died
+    without its callback).  A callback that runs outside every autograd node belongs to a TOP-LEVEL pass: nothing below it on the
+    stack can be alive (a pass that raised half-way never runs its callbacks) -- drop it all."""
+    _flush_pending()
+    st = _DEFER["stack"]
+    node = getattr(torch._C, "_current_autograd_node", None)
+    if node is None or node() is None:
+        st.clear()
+        return
+    for i, (t, _s) in enumerate(st):
+        if t == task:
+            del st[i:]
+            break
+
+
 def defer_ok(params) -> bool:
-    """May the gradients of these parameters be completed at the end of the running backward pass?  Only inside a backward pass,
-    and only for plain leaf parameters that nothing can observe earlier: no gradient to accumulate into yet (AccumulateGrad then
-    takes the returned tensor itself, no arithmetic on it), no tensor / post-accumulate hooks (gradient buckets of a sharded step,
-    user hooks), no process group with peers (DDP's reducer), no create_graph / anomaly mode; a parameter that turns up a second
-    time in the same pass completes everything pending first.  ``params=None`` (callers that cannot name their parameters): no."""
+    """May the gradients of these parameters be completed at the end of the running backward pass?  Only when the caller opted in
+    (``defer_reductions(True)``), inside a backward pass, and only for plain contiguous leaf parameters that nothing can observe
+    earlier: no gradient to accumulate into yet (AccumulateGrad then takes the returned tensor itself, no arithmetic on it), no
+    tensor / post-accumulate hooks (gradient buckets of a sharded step, user hooks), NO initialised process group whatever its
+    size (DistributedDataParallel's reducer hooks the gradient accumulators in C++ at world size 1 too), no create_graph /
+    anomaly mode.  A parameter that turns up a second time -- in this pass or in a pass this one is nested in -- completes
+    everything pending first and takes the in-call pass.  A NESTED pass (reentrant ``torch.utils.checkpoint``, a custom Function
+    calling ``torch.autograd.grad`` in its backward) first completes what the enclosing pass left pending, then defers on its own
+    list, completed by its own final callback.  ``params=None`` (callers that cannot name their parameters): no.
+
+    What this cannot see: a gradient that reaches one of these parameters through a plain torch op in the same
+    pass (a weight regulariser, weight tying through torch ops) -- the engine would add it to a buffer whose values do not exist
+    yet.  Hence opt-in."""
     if params is None or not _DEFER["enabled"]:
         return False
-    # a process group with peers: DistributedDataParallel / FSDP hang C++ post hooks on the gradient accumulators (invisible from
-    # Python) that copy a gradient into a bucket the moment it is accumulated -- never defer beside them
     dist = torch.distributed
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         return False
     get_task = getattr(torch._C, "_current_graph_task_id", None)      # (a private hook of the autograd engine: without it, no deferral)
     task = get_task() if get_task is not None else -1
     if task < 0 or torch.is_grad_enabled() or torch.is_anomaly_enabled():   # not in a backward pass / create_graph / NaN checks
         return False
-    if _DEFER["task"] != task:
-        # a new backward pass: whatever a pass that died half-way left behind is dropped with it
-        _DEFER["pending"], _DEFER["seen"] = [], set()
-        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
-        _DEFER["task"] = task
+    st = _DEFER["stack"]
+    if not st or st[-1][0] != task:
+        at = next((i for i, (t, _s) in enumerate(st) if t == task), -1)
+        if at >= 0:
+            del st[at + 1:]                 # nested passes above this one ended without their callback (they raised)
+        else:
+            # a pass we have not seen: top-level, or nested in the one on top of the stack.  What that one left pending is
+            # completed NOW (its partials are all written, same stream; the storages are kept alive) -- never dropped
+            _flush_pending()
+            st.append((task, set()))
+            torch.autograd.Variable._execution_engine.queue_callback(functools.partial(_task_done, task))
     ok = True
     for p in params:
         if p is None:
             continue
         if (not p.is_leaf) or p.grad_fn is not None or p.grad is not None or p._backward_hooks \
-                or getattr(p, "_post_accumulate_grad_hooks", None):
+                or getattr(p, "_post_accumulate_grad_hooks", None) or not p.is_contiguous():
             ok = False
-        if id(p) in _DEFER["seen"]:
-            # the parameter is used twice in this graph: the engine is about to ADD this gradient to the one deferred earlier --
-            # complete everything pending now (same stream, ahead of that add) and take the in-call pass
+        if any(id(p) in seen for _t, seen in st):
+            # the parameter is used twice: the engine is about to ADD this gradient to the one deferred earlier -- complete
+            # everything pending now (same stream, ahead of that add) and take the in-call pass
             _flush_pending()
             ok = False
     if ok:
-        _DEFER["seen"].update(id(p) for p in params if p is not None)
+        st[-1][1].update(id(p) for p in params if p is not None)
     return ok
 
 
@@ -310,17 +348,20 @@ def _defer(part: Tensor, out: Tensor, n: int, parts: int, lanes: int) -> None:
     # `out` is about to be handed to autograd: keep its STORAGE alive, not the tensor -- a second reference to the returned tensor
     # (a view of it holds one too: its base) would make AccumulateGrad clone it, a copy of values that do not exist yet
     _DEFER["pending"].append((part, out.untyped_storage(), out.data_ptr(), int(n), int(parts), int(lanes)))
+    # the partial tables stay allocated until the flush (configs[1]: ~70 MB per layer, 0.7 GB per pass): past the cap, complete now
+    _DEFER["pending_bytes"] += part.numel() * part.element_size()
+    if _DEFER["pending_bytes"] > _DEFER["cap_bytes"]:
+        _flush_pending()
 
 
 def flush_deferred() -> None:
-    """sum every pending partial table into its output (one launch per 64 tables); called by the autograd engine at the end of the
-    backward pass that deferred them"""
-    _DEFER["task"], _DEFER["seen"] = -1, set()
+    """sum every pending partial table into its output (one launch per 64 tables) -- safe at any time: the partials of a pending
+    entry are complete in stream order the moment it is queued"""
     _flush_pending()
 
 
 def _flush_pending() -> None:
-    pend, _DEFER["pending"] = _DEFER["pending"], []
+    pend, _DEFER["pending"], _DEFER["pending_bytes"] = _DEFER["pending"], [], 0
     if not pend:
         return
     arr = (_ReduceDesc * len(pend))()

@@ -22,6 +22,15 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+_LOUD_SKIPS = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    """parity tests that skipped themselves (host too small for the whole-step oracle, ...) are named in the summary even under -q"""
+    for line in _LOUD_SKIPS:
+        terminalreporter.write_line(line, yellow=True)
+
+
 def pytest_runtest_logreport(report):
     """Keep the achieved errors: every `[parity] ...` line a test prints (max-abs / max-rel / cosine against the oracle or
     the goldens) is appended to $GAOT_PARITY_LOG (default gpurun_out/parity_last.txt on a GPU box); tools/gpu_pass.sh
@@ -31,6 +40,7 @@ def pytest_runtest_logreport(report):
     lines = [ln for ln in (report.capstdout or "").splitlines() if ln.startswith("[parity]") or ln.startswith("[train]")]
     if not lines:
         return
+    _LOUD_SKIPS.extend(ln for ln in lines if ": skipped" in ln)
     path = os.environ.get("GAOT_PARITY_LOG")
     if path is None:
         import torch

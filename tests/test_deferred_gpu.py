@@ -153,3 +153,133 @@ def test_reduce_multi_matches_torch_and_keeps_the_in_call_order():
     # a bad descriptor is refused
     arr[0].lanes = 8
     assert lib.gaot_reduce_multi(arr, 1, ops._stream()) != 0
+
+
+def _block_and_input(layers=3, s=4096, d=256):
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers.attn import AttentionConfig, FFNConfig, TransformerBlock
+    torch.manual_seed(0)
+    blocks = torch.nn.ModuleList([
+        TransformerBlock(d, d, attn_config=AttentionConfig(hidden_size=d, num_heads=8, num_kv_heads=8, atten_dropout=0.0),
+                         ffn_config=FFNConfig(hidden_size=1024)) for _ in range(layers)]).to(DEV).train()
+    x = torch.randn(1, s, d, device=DEV, requires_grad=True)
+    return blocks, x
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_reentrant_checkpoint_around_a_block_is_bit_identical(precision):
+    """VERDICT r5 #4a / ADVICE r5 (high): the middle block in torch.utils.checkpoint(use_reentrant=True) runs its backward as a
+    NESTED graph task; the outer pass's pending partials must be completed, not dropped"""
+    import gaot_3d_amd
+    from torch.utils.checkpoint import checkpoint
+    from gaot_3d_amd import ops
+    blocks, x = _block_and_input()
+    gaot_3d_amd.set_precision(precision)
+
+    def run(defer):
+        prev = ops.defer_reductions(defer)
+        try:
+            for p in blocks.parameters():
+                p.grad = None
+            x.grad = None
+            h = blocks[0](x)
+            h = checkpoint(blocks[1], h, use_reentrant=True)
+            h = blocks[2](h)
+            h.square().mean().backward()
+            assert ops.deferred_pending() == 0
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in blocks.parameters()] + [x.grad.clone()]
+        finally:
+            ops.defer_reductions(prev)
+    try:
+        g0, g1 = run(False), run(True)
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    names = [n for n, _ in blocks.named_parameters()] + ["x"]
+    for n, a, b in zip(names, g0, g1):
+        assert torch.isfinite(b).all(), n
+        assert torch.equal(a, b), f"{n}: deferred != in-call under a reentrant checkpoint, max diff {(a - b).abs().max().item():.3e}"
+
+
+def test_autograd_grad_inside_a_custom_backward_is_bit_identical():
+    """a custom Function whose backward calls torch.autograd.grad on a graph holding a gaot block: a nested task that must return
+    COMPLETE gradients, and must not lose what the enclosing pass had pending"""
+    import gaot_3d_amd
+    from gaot_3d_amd import ops
+    blocks, x = _block_and_input()
+    inner = blocks[1]
+    inner_params = list(inner.parameters())
+
+    class Nested(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, h, *params):
+            ctx.save_for_backward(h)
+            with torch.no_grad():
+                return inner(h)
+
+        @staticmethod
+        def backward(ctx, dy):
+            (h,) = ctx.saved_tensors
+            with torch.enable_grad():
+                hi = h.detach().requires_grad_(True)
+                y = inner(hi)
+            gs = torch.autograd.grad(y, [hi] + inner_params, dy)
+            return gs
+
+    gaot_3d_amd.set_precision("bf16")
+
+    def run(defer):
+        prev = ops.defer_reductions(defer)
+        try:
+            for p in blocks.parameters():
+                p.grad = None
+            x.grad = None
+            h = blocks[0](x)
+            h = Nested.apply(h, *inner_params)
+            h = blocks[2](h)
+            h.square().mean().backward()
+            assert ops.deferred_pending() == 0
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in blocks.parameters()] + [x.grad.clone()]
+        finally:
+            ops.defer_reductions(prev)
+    try:
+        g0, g1 = run(False), run(True)
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    for n, a, b in zip([n for n, _ in blocks.named_parameters()] + ["x"], g0, g1):
+        assert torch.equal(a, b), f"{n}: max diff {(a - b).abs().max().item():.3e}"
+
+
+def test_one_rank_ddp_gets_complete_gradients(tmp_path):
+    """DistributedDataParallel's reducer hooks the gradient accumulators at world size 1 too and copies a gradient
+    into its bucket the moment it is accumulated -- beside ANY initialised process group the in-call pass is taken"""
+    import torch.distributed as dist
+    import gaot_3d_amd
+    from gaot_3d_amd import ops
+    blocks, x = _block_and_input(layers=2)
+    gaot_3d_amd.set_precision("bf16")
+
+    def run(net, defer):
+        prev = ops.defer_reductions(defer)
+        try:
+            for p in blocks.parameters():
+                p.grad = None
+            net(x.detach()).square().mean().backward()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in blocks.parameters()]
+        finally:
+            ops.defer_reductions(prev)
+    seq = torch.nn.Sequential(*blocks)
+    try:
+        g0 = run(seq, False)
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1)
+        try:
+            ddp = torch.nn.parallel.DistributedDataParallel(seq)
+            g1 = run(ddp, True)
+        finally:
+            dist.destroy_process_group()
+    finally:
+        gaot_3d_amd.set_precision("fp32")
+    for (n, _), a, b in zip(blocks.named_parameters(), g0, g1):
+        assert torch.equal(a, b), f"{n}: max diff {(a - b).abs().max().item():.3e}"

@@ -464,6 +464,16 @@ def _fullsize_oracle_skip_reason():
     return None
 
 
+def _skip_or_fail_fullsize(case, why):
+    """the two whole-step oracle tests are the most valuable parity tests of the suite: a host too small for them must not drop
+    them silently -- the skip is printed as a `[parity] ... skipped` line (tests/conftest.py copies those into the parity log and
+    the terminal summary), and GAOT_REQUIRE_FULLSIZE=1 turns it into a failure"""
+    print(f"[parity] {case}: skipped -- {why}")
+    if os.environ.get("GAOT_REQUIRE_FULLSIZE") == "1":
+        pytest.fail(f"GAOT_REQUIRE_FULLSIZE=1 and {case} cannot run: {why}")
+    pytest.skip(why)
+
+
 def test_model_full_size_vs_oracle():
     """The WHOLE configs[1] step -- 500 000 points, 4 M edges per direction, 16 384 tokens, L = 10, RoPE, attention dropout
     off -- against the oracle (CPU restatement of the reference, fp32) on the same sample and weights: predictions, loss and
@@ -477,8 +487,7 @@ def test_model_full_size_vs_oracle():
     import parity as PAR
     why = _fullsize_oracle_skip_reason()
     if why is not None:
-        print(f"[parity] test_model_full_size_vs_oracle skipped: {why}")
-        pytest.skip(why)
+        _skip_or_fail_fullsize("test_model_full_size_vs_oracle", why)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     latent, n, k, layers = (64, 64, 32), 500000, 8, 10
     cfg = bench.model_config(latent, layers, k, 0.0)
@@ -534,8 +543,7 @@ def test_configs3_full_size_vs_oracle():
     import parity as PAR
     why = _fullsize_oracle_skip_reason()
     if why is not None:
-        print(f"[parity] test_configs3_full_size_vs_oracle skipped: {why}")
-        pytest.skip(why)
+        _skip_or_fail_fullsize("test_configs3_full_size_vs_oracle", why)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     latent, n, k, layers = (64, 64, 32), 500000, 8, 10
     cfg = bench.model_config(latent, layers, k, 0.0, "cfg3")
