@@ -104,6 +104,11 @@ SIGNATURES = {
     "gaot_ffn_w13_swiglu": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "gaot_ffn_w2_bwd_swiglu": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "gaot_swiglu_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "gaot_ffn_packed_bytes": (_i64, [_i, _i]),
+    "gaot_ffn_pack": (_i, [_p, _p, _i, _p, _i, _p]),
+    "gaot_ffn_pack_multi": (_i, [_p, _i, _i, _i, _p]),
+    "gaot_ffn_fwd": (_i, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
+    "gaot_ffn_bwd_dag": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),
     "gaot_act_fwd": (_i, [_p, _p, _i64, _i, _p]),
     "gaot_axpy": (_i, [_p, _p, _f, _p, _i64, _i64, _p]),
@@ -140,7 +145,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gaot_abi_version() != 10:
+    if lib.gaot_abi_version() != 11:
         raise GaotError("libgaot3d_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -198,6 +198,13 @@ __device__ __forceinline__ f32v2 gelu_e2_grad2(f32v2 x) {   // the derivative al
     return sw + (f32v2)(0.5f);
 }
 
+// sigmoid for the bf16-mode SwiGLU (forward and backward, stand-alone passes and GEMM epilogues alike -- ONE form, so the fused and
+// the unfused kernels agree bit for bit): v_exp_f32 + v_rcp_f32 (1 ulp each; the result is rounded to bf16 right after) instead of
+// the IEEE division's ten instructions
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

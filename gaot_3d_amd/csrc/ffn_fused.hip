@@ -1,0 +1,756 @@
+// The SwiGLU FFN of a latent Transformer block as ONE kernel per direction over 64-row blocks (reference attn.py:146-157:
+// w2(silu(w1 x) * w3 x), and :226-229 for the residual that follows it), d_model = 256, bf16 operands, fp32 accumulation.
+//
+// Why a row-block kernel and what it is bound by.  Unfused, the forward is two launches (w1|w3 + SwiGLU epilogue, then w2 + residual)
+// that move the [S, F] product u through HBM in between and each pay their own fill / drain; the backward is four (cast of dy, du = dy W2,
+// SwiGLU', dx = dag W13) that move du ([S, F]) and re-read a | g.  A workgroup here owns 64 rows and walks F in chunks of 128 columns:
+//     forward :  a|g chunk = h W13c^T (K = 256)  ->  u chunk = silu(a) g (registers -> LDS, 16 KB)  ->  y += u chunk W2c^T (K = 128)
+// so u never returns from HBM.  What a row block cannot share with its neighbours is the WEIGHTS: every workgroup streams all of W13
+// and W2 (1.5 MB of bf16 at F = 1024) from its XCD's L2.  The operands of a wave are its OWN 64 weight rows of every step, nothing a
+// second wave reads, so they skip LDS: the weights are PRE-PACKED IN MFMA FRAGMENT ORDER (k_ffn_pack: one 1-KB block per
+// wave-instruction, lane l's 16 bytes at block + 16 l) and loaded global -> VGPR with fully coalesced 1-KB requests, two steps ahead
+// of their use (register ring of three).  LDS holds only the activation tile (32 KB, LDS-DMA, source-side XOR swizzle as in
+// gemm_k256.hip) and two u chunks.  Arithmetic and summation order are those of the unfused kernels (k_gemm_k256<OUT_SWIGLU>,
+// k_gemm_tn_n256): a | g, u and y are BIT-IDENTICAL to the two-launch path, so the backward and every test bound are unchanged.
+// Per 64-row block and chunk a wave issues 96 MFMAs (3 072 matrix-pipe cycles); HBM: a | g and u are still written once for the
+// backward (96 MB per layer at S = 16 384), which is this kernel's floor (~16 us at the measured copy rate) -- see DESIGN.md §3.4.
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// lab only (tools/lab/ffn_fwd_lab.hip): ablation bits -- 1: the weight ring is loaded once and never refilled; 4: u = a (no SwiGLU
+// arithmetic); 8: the activation / u fragments are read from LDS once per chunk phase; 16: no barrier in the chunk loop
+#ifndef GAOT_FFN_ABL
+#define GAOT_FFN_ABL 0
+#endif
+#ifdef GAOT_FFN_TIMING      // lab only: s_memtime stamps of workgroup 0 / wave 0 at the phase boundaries
+__device__ unsigned long long g_ffn_t[64];
+#define FFN_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ffn_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FFN_STAMP(i) do { } while (0)
+#endif
+constexpr int D = 256, RB = 64, FC = 128;          // d_model, rows per workgroup, F columns per chunk
+constexpr int H_BYTES = RB * D * 2;                // activation tile: 64 rows x 512 B
+constexpr int U_BYTES = RB * FC * 2;               // one u chunk: 64 rows x 256 B
+constexpr int AG_BYTES = RB * 2 * FC * 2;          // one a | g chunk on its way to HBM: 64 rows x 512 B (SAVE only)
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    return (unsigned)__builtin_bit_cast(bf16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(bf16_t, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float rbf(float v) { return __uint_as_float((unsigned)__builtin_bit_cast(bf16_t, (__bf16)v) << 16); }
+
+// ---- weight packing ---------------------------------------------------------------------------------------------------------------
+// Fragment block = what one wave-instruction loads: 64 lanes x 8 bf16; lane (l31, hf) holds W[row0 + l31][k0 + 8 hf + 0..7] -- the A
+// operand of v_mfma_f32_32x32x16_bf16 in the transposed product (weight rows on the tile rows).
+//   forward  W13p: block (((c*4 + w)*2 + jt)*16 + s): row = jt*F + c*128 + w*32 + l31 of [w1; w3] ([2F][256]), k = 16 s + 8 hf + e
+//            W2p : block (((c*4 + w)*2 + jt)* 8 + s): row = w*64 + jt*32 + l31 of w2 ([256][F]),         k = c*128 + 16 s + 8 hf + e
+//   backward W2tp: du = dy W2, fragment rows = F columns: block (((c*4 + w)*16 + s): "row" f = c*128 + w*32 + l31, k = 16 s + 8 hf + e
+//                  of W2^T, i.e. element w2[k][f]
+//            W13tp: dx = dag W13, fragment rows = d columns: block ((((c*4 + w)*2 + jt)*16 + s): "row" j = w*64 + jt*32 + l31,
+//                  k-index kk = 16 s + 8 hf + e over the chunk's 256 dag columns (kk < 128: a column c*128 + kk, else g column
+//                  c*128 + kk - 128), i.e. element w13[(kk < 128 ? 0 : F) + c*128 + (kk & 127)][j]
+__device__ __forceinline__ void ffn_pack_body(const float* __restrict__ w13, const float* __restrict__ w2, int F, bf16_t* __restrict__ w13p,
+                                              bf16_t* __restrict__ w2p, bf16_t* __restrict__ w2tp, bf16_t* __restrict__ w13tp) {
+    const int NC = F / FC;
+    const int64_t n13 = (int64_t)NC * 4 * 2 * 16 * 64, n2 = (int64_t)NC * 4 * 2 * 8 * 64, n2t = (int64_t)NC * 4 * 16 * 64;
+    const int64_t total = n13 + n2 + (w2tp ? n2t + n13 : 0);
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = id;
+        const float* src;
+        int64_t stride;      // element stride between consecutive e
+        bf16_t* dst;
+        if (t < n13) {
+            const int lane = t & 63, s = (t >> 6) & 15, jt = (t >> 10) & 1, w = (t >> 11) & 3, c = (int)(t >> 13);
+            const int row = jt * F + c * FC + w * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+            src = w13 + (int64_t)row * D + k; stride = 1; dst = w13p + t * 8;
+        } else if ((t -= n13) < n2) {
+            const int lane = t & 63, s = (t >> 6) & 7, jt = (t >> 9) & 1, w = (t >> 10) & 3, c = (int)(t >> 12);
+            const int row = w * 64 + jt * 32 + (lane & 31), k = c * FC + 16 * s + 8 * (lane >> 5);
+            src = w2 + (int64_t)row * F + k; stride = 1; dst = w2p + t * 8;
+        } else if ((t -= n2) < n2t) {
+            const int lane = t & 63, s = (t >> 6) & 15, w = (t >> 10) & 3, c = (int)(t >> 12);
+            const int f = c * FC + w * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+            src = w2 + (int64_t)k * F + f; stride = F; dst = w2tp + t * 8;
+        } else {
+            t -= n2t;
+            const int lane = t & 63, s = (t >> 6) & 15, jt = (t >> 10) & 1, w = (t >> 11) & 3, c = (int)(t >> 13);
+            const int j = w * 64 + jt * 32 + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+            const int row = (kk < FC ? 0 : F) + c * FC + (kk & (FC - 1));
+            src = w13 + (int64_t)row * D + j; stride = D; dst = w13tp + t * 8;
+        }
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2(src[(2 * e) * stride], src[(2 * e + 1) * stride]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+constexpr int PACK_MAX = 16;
+struct PackTable {
+    const float* w13[PACK_MAX];
+    const float* w2[PACK_MAX];
+    bf16_t* packed[PACK_MAX];
+};
+// blockIdx.y = the FFN: all blocks of a Transformer in one launch
+__global__ void k_ffn_pack(PackTable t, int F, int with_backward) {
+    bf16_t* p = t.packed[blockIdx.y];
+    bf16_t* w2p = p + (int64_t)2 * F * D;
+    bf16_t* w2tp = with_backward ? w2p + (int64_t)D * F : nullptr;
+    ffn_pack_body(t.w13[blockIdx.y], t.w2[blockIdx.y], F, p, w2p, w2tp, with_backward ? w2tp + (int64_t)D * F : nullptr);
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------------------
+// X [M][256] bf16 (the normalised h RMSNorm wrote), R [M][ldr] fp32 residual or null, Y [M][256] fp32, AG [M][2F] bf16 (a | g),
+// U [M][F] bf16.  SAVE = false: a | g and u are not written (inference / a backward that recomputes them).
+template <bool SAVE, int RD>
+__global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X, const u32x4* __restrict__ W13p,
+                                                     const u32x4* __restrict__ W2p, const float* __restrict__ R, float* __restrict__ Y,
+                                                     bf16_t* __restrict__ AG, bf16_t* __restrict__ U, int M, int F, int ldr) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous range of row blocks (the a | g / u / y rows one
+    // XCD's L2 write-combines are then neighbours)
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB, NC = F / FC;
+    FFN_STAMP(0);
+    constexpr int LA = RD - 1;
+    static_assert(6 % RD == 0, "the ring is indexed by the position within the loop body");
+
+    const int64_t xbytes = (int64_t)M * D * 2, agbytes = (int64_t)M * F * 4, ubytes = (int64_t)M * F * 2, ybytes = (int64_t)M * D * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t agrs = __builtin_amdgcn_make_buffer_rsrc((void*)(SAVE ? AG : nullptr), 0, SAVE ? (int)(agbytes > 0x7fffffff ? 0x7fffffff : agbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)(SAVE ? U : nullptr), 0, SAVE ? (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)(ybytes > 0x7fffffff ? 0x7fffffff : ybytes), 0x00020000);
+
+    // the residual rows of this lane's outputs: requested at the top of the LAST chunk's iteration (below) -- at the kernel's end the
+    // workgroup would finish on an exposed HBM round trip, at its start all 256 workgroups would wait for 16 MB more before their first MFMA
+    f32x4 rres[2][2][4];
+    const int64_t rbytes = (int64_t)M * ldr * 4;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, R ? (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes) : 0, 0x00020000);
+    // A STEP = 8 fragment blocks (8 KB per wave) and 16 MFMAs.  Steps of chunk c: st 0..3 = the four 64-deep k-slices of h W13c^T (tiles
+    // a, g), st 4, 5 = the two 64-deep k-slices of u W2c^T (tiles: output columns 64 w .. +31, +32 .. +63).  Chunks past the last one read
+    // as zeros (buffer range check): the loop below runs one a | g product too many instead of carrying a second copy of its body.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t w13rs = __builtin_amdgcn_make_buffer_rsrc((void*)W13p, 0, 2 * F * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)W2p, 0, D * F * 2, 0x00020000);
+    bool wfirst = true;
+    auto wload = [&](u32x4 (&dst)[8], int c, int st) {
+        if ((GAOT_FFN_ABL & 1) && !wfirst) return;
+        if (st < 4) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    dst[jt * 4 + s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w13rs, lane * 16, ((((c * 4 + wv) * 2 + jt) * 16) + 4 * st + s) * 1024, 0));
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    dst[jt * 4 + s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane * 16, ((((c * 4 + wv) * 2 + jt) * 8) + 4 * (st - 4) + s) * 1024, 0));
+        }
+    };
+    // The wave's timeline of steps: positions 0..3 = a | g product of chunk 0 (prologue); then per loop iteration c six positions:
+    // b = 0..3 the a | g product of chunk c + 1, b = 4, 5 the y accumulation of chunk c.  Ring slot of a position = position % RD
+    // (6 % RD == 0: static); LA = RD - 1 steps (8 KB per wave each) are in flight.  The XCD's L2 hands a CU ~75 GB/s when all 32
+    // stream (16 channels x 64 B/clk): the 1.5 MB of weights per row block cost ~20 us of that pipe.
+    u32x4 wr[RD][8];
+    auto prefetch_body = [&](int c, int tpos) {     // tpos = position in the body of iteration c, may run into iteration c + 1
+        const int cc = tpos < 6 ? c : c + 1, b = tpos < 6 ? tpos : tpos - 6;
+        wload(wr[(4 + tpos) % RD], b < 4 ? cc + 1 : cc, b);
+    };
+#pragma unroll
+    for (int p = 0; p < LA; ++p) {
+        if (p < 4) wload(wr[p % RD], 0, p);
+        else prefetch_body(0, p - 4);
+    }
+    if (GAOT_FFN_ABL & 1) { wload(wr[LA % RD], 0, 0); wfirst = false; }
+
+    // the activation tile by LDS-DMA: piece q = wave*8 + i fills tile rows 2q, 2q+1; slot s of row r holds source chunk s ^ (r & 15)
+    {
+        const int lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = 2 * i + lh;
+            const int voff = (m0 + wave * 16 + x) * D * 2 + (((lane & 31) ^ x) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lds + (wave * 8 + i) * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FFN_STAMP(1);
+
+    f32x16 y[2][2], agc[2][2], agn[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { y[jt][i][r] = 0.f; agc[jt][i][r] = 0.f; }
+
+    const int sw = l31 & 15;
+    const char* hb = lds + l31 * 512;                       // activation rows l31 (i = 0) and 32 + l31 (+ 32 * 512)
+    bf16x8 hn0, hn1;
+    // one 16-deep k-step (ks = 0..15) of the a | g product into acc, with the NEXT k-step's activation fragments requested first
+    auto ag_kstep = [&](f32x16 (&acc)[2][2], const u32x4 (&w)[8], int ks) {
+        const bf16x8 h0 = hn0, h1 = hn1;
+        if (!(GAOT_FFN_ABL & 8) || ks == 15) {
+            const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+            hn0 = *reinterpret_cast<const bf16x8*>(hb + slot);
+            hn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + slot);
+        }
+        const bf16x8 wa = __builtin_bit_cast(bf16x8, w[ks & 3]), wg = __builtin_bit_cast(bf16x8, w[4 + (ks & 3)]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h0, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h1, acc[1][1], 0, 0, 0);
+    };
+    hn0 = *reinterpret_cast<const bf16x8*>(hb + ((hf ^ sw) << 4));
+    hn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + ((hf ^ sw) << 4));
+    // ---- prologue: a | g of chunk 0 ----
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st + LA < 4) wload(wr[(st + LA) % RD], 0, st + LA);
+        else prefetch_body(0, st + LA - 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ag_kstep(agc, wr[st % RD], 4 * st + s);
+    }
+
+    FFN_STAMP(2);
+    for (int c = 0; c < NC; ++c) {
+        char* ub = lds + H_BYTES + (c & 1) * U_BYTES;
+        char* agb = lds + H_BYTES + 2 * U_BYTES + (c & 1) * AG_BYTES;
+        if (c == NC - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = m0 + 32 * i + l31;
+                const unsigned roff = (m < M && R) ? (unsigned)m * (unsigned)ldr * 4u : 0x80000000u;     // out of range -> zeros
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        rres[i][jt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0));
+            }
+        }
+        // ---- a | g of chunk c + 1 (MFMAs) with the epilogue of chunk c (vector instructions) between its k-steps ----
+        // epilogue of chunk c: a | g rounded to bf16 (-> HBM), u = silu(a) g from the ROUNDED values (-> HBM, -> LDS).
+        // agc[jt][i][r]: column c*128 + 32 wave + mfma32_row(r, hf) of a (jt 0) / g (jt 1), row m0 + 32 i + l31.  Work unit (i, q) = the
+        // lane's four columns 8q + 4hf .. + 3 of row tile i; the units (i, q) and (i, q + 2) leave together (half-wave pairing: 16 bytes
+        // per lane).  16 k-steps: even k-step 2j runs unit j (order: (0,0) (0,2) (0,1) (0,3) (1,0) ...), odd k-steps 4j' + 3 pair and store.
+        unsigned pa[2][2][2], pg[2][2][2], pu[2][2][2];      // [slot of the pair][unit within the pair][2 words]
+        const int ncol = c * FC + wave * 32;
+        auto half_unit = [&](int i, int q, int ps, int pw, int h) {       // elements 2h, 2h + 1 of unit (i, q)
+            float av[2], gv[2];
+            pa[ps][pw][h] = pack2(agc[0][i][4 * q + 2 * h], agc[0][i][4 * q + 2 * h + 1]);
+            pg[ps][pw][h] = pack2(agc[1][i][4 * q + 2 * h], agc[1][i][4 * q + 2 * h + 1]);
+            // the rounded values back as fp32: low / high half of the packed word
+            av[0] = __uint_as_float(pa[ps][pw][h] << 16); av[1] = __uint_as_float(pa[ps][pw][h] & 0xffff0000u);
+            gv[0] = __uint_as_float(pg[ps][pw][h] << 16); gv[1] = __uint_as_float(pg[ps][pw][h] & 0xffff0000u);
+            // breadth first: no instruction reads its predecessor's result (a dependent v_exp_f32 / v_rcp_f32 chain stalls the wave's
+            // one issue port for the latency of each link, and with it the MFMAs queued behind)
+            float o[2], t[2];
+            if (GAOT_FFN_ABL & 4) {
+                o[0] = av[0]; o[1] = av[1];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) t[e] = -1.4426950408889634f * av[e];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) t[e] = 1.0f + t[e];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_rcpf(t[e]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) o[e] = av[e] * t[e];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) o[e] = o[e] * gv[e];
+            }
+            pu[ps][pw][h] = pack2(o[0], o[1]);
+        };
+        auto finish = [&](int i, int q, int ps) {       // units (i, q) [pw 0] and (i, q + 2) [pw 1]
+            const int ml = 32 * i + l31, m = m0 + ml;
+            if constexpr (SAVE) {
+                // a | g leave through LDS (row ml: 512 B = 16 chunks of a, 16 of g; chunk stored at chunk ^ (row & 31)) and are written to
+                // HBM as whole 256-byte row segments during the y phase: stored from this layout (16 bytes per lane, two lanes per row) a
+                // wave-instruction touches 32 different 128-byte lines with 32 bytes each, and the 24 such stores per wave and chunk cost
+                // the CU's address path as much as the weight stream itself (merged phase 4 460 -> 6 500 cycles)
+                {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pa[ps][0][0], pa[ps][1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pa[ps][0][1], pa[ps][1][1], false, false);
+                    const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    *reinterpret_cast<u32x4*>(agb + ml * 512 + (((4 * wave + q + 2 * hf) ^ (ml & 31)) << 4)) = v;
+                }
+                {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pg[ps][0][0], pg[ps][1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pg[ps][0][1], pg[ps][1][1], false, false);
+                    const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    *reinterpret_cast<u32x4*>(agb + ml * 512 + (((16 + 4 * wave + q + 2 * hf) ^ (ml & 31)) << 4)) = v;
+                }
+            }
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pu[ps][0][0], pu[ps][1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pu[ps][0][1], pu[ps][1][1], false, false);
+            const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            // LDS: row ml (256 B), 16-byte chunk 4 wave + q + 2 hf, stored at chunk ^ (row & 15)
+            *reinterpret_cast<u32x4*>(ub + ml * 256 + (((4 * wave + q + 2 * hf) ^ (ml & 15)) << 4)) = v;
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) agn[jt][i][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            prefetch_body(c, st + LA);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ks = 4 * st + s;
+                __builtin_amdgcn_sched_barrier(0);      // a k-step's MFMAs, fragment reads and its share of the epilogue stay together
+                ag_kstep(agn, wr[(4 + st) % RD], ks);
+                {
+                    const int j = ks >> 1, i = j >> 2, jj = j & 3;       // jj: 0 -> q 0, 1 -> q 2, 2 -> q 1, 3 -> q 3
+                    half_unit(i, (jj >> 1) + 2 * (jj & 1), jj >> 1, jj & 1, ks & 1);
+                    if ((ks & 3) == 3) finish(i, jj >> 1, jj >> 1);
+                }
+                // the region's order: fragment reads first, then every MFMA followed by its share of the vector work
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_STAMP(3 + 3 * c);
+        if (!(GAOT_FFN_ABL & 16)) __builtin_amdgcn_s_barrier();
+        FFN_STAMP(4 + 3 * c);     // the chunk's u is complete; the other buffer's readers (chunk c - 1) are all past their reads
+        // ---- y += u chunk W2c^T: two 64-deep steps ----
+        bf16x8 un0 = *reinterpret_cast<const bf16x8*>(ub + l31 * 256 + ((hf ^ sw) << 4)), un1 = *reinterpret_cast<const bf16x8*>(ub + (32 + l31) * 256 + ((hf ^ sw) << 4));
+#pragma unroll
+        for (int st = 4; st < 6; ++st) {
+            prefetch_body(c, st + LA);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 u0 = un0, u1 = un1;
+                if (4 * (st - 4) + s + 1 < 8 && !(GAOT_FFN_ABL & 8)) {
+                    const int slot = ((2 * (4 * (st - 4) + s + 1) + hf) ^ sw) << 4;
+                    un0 = *reinterpret_cast<const bf16x8*>(ub + l31 * 256 + slot);
+                    un1 = *reinterpret_cast<const bf16x8*>(ub + (32 + l31) * 256 + slot);
+                }
+                if constexpr (SAVE) {
+                    // this wave's share of the chunk's a | g (rows 16 wave .. + 15, two rows per instruction) and u (four rows per
+                    // instruction) from LDS to HBM: one piece of a | g per k-step, one of u every other k-step
+                    const int kk = 4 * (st - 4) + s;
+                    {
+                        const int row = 16 * wave + 2 * kk + hf, ch = l31, m = m0 + row;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(agb + row * 512 + ((ch ^ (row & 31)) << 4));
+                        const unsigned off = m < M ? (unsigned)m * (unsigned)F * 4u + (unsigned)(((ch < 16 ? 0 : F) + c * FC + (ch & 15) * 8) * 2) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, agrs, off, 0, 0);
+                    }
+                    if ((kk & 1) == 0) {
+                        const int row = 16 * wave + 2 * kk + (lane >> 4), ch = lane & 15, m = m0 + row;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(ub + row * 256 + ((ch ^ (row & 15)) << 4));
+                        const unsigned off = m < M ? (unsigned)m * (unsigned)F * 2u + (unsigned)((c * FC + ch * 8) * 2) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, urs, off, 0, 0);
+                    }
+                }
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wr[(4 + st) % RD][s]), w1 = __builtin_bit_cast(bf16x8, wr[(4 + st) % RD][4 + s]);
+                y[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, u0, y[0][0], 0, 0, 0);
+                y[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, u0, y[1][0], 0, 0, 0);
+                y[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, u1, y[0][1], 0, 0, 0);
+                y[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, u1, y[1][1], 0, 0, 0);
+                // the NEXT k-step's fragment reads stay in front of this k-step's MFMAs (left alone, the scheduler sinks them behind
+                // the MFMAs to save two registers and every k-step then starts with an exposed LDS round trip: 2 016 -> 1 1xx cycles)
+                __builtin_amdgcn_sched_group_barrier(0x100, SAVE ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) agc[jt][i] = agn[jt][i];
+        FFN_STAMP(5 + 3 * c);
+    }
+    // ---- y (+ residual): column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31 ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const unsigned rowoff = m < M ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {y[jt][i][4 * q], y[jt][i][4 * q + 1], y[jt][i][4 * q + 2], y[jt][i][4 * q + 3]};
+                v += rres[i][jt][q];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, rowoff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0);
+            }
+    }
+    FFN_STAMP(40);
+}
+
+constexpr int FWD_LDS = H_BYTES + 2 * U_BYTES, FWD_LDS_SAVE = FWD_LDS + 2 * AG_BYTES;
+#ifndef GAOT_FFN_FWD_RING
+#define GAOT_FFN_FWD_RING 3
+#endif
+constexpr int FWD_RING = GAOT_FFN_FWD_RING;
+
+template <bool SAVE>
+int launch_ffn_fwd(const void* x, const void* w13p, const void* w2p, const float* r, float* y, void* ag, void* u, int M, int F, int ldr,
+                   hipStream_t st) {
+    auto kern = k_ffn_fwd<SAVE, FWD_RING>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SAVE ? FWD_LDS_SAVE : FWD_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("ffn_fwd: cannot set dynamic LDS %d: %s", SAVE ? FWD_LDS_SAVE : FWD_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), SAVE ? FWD_LDS_SAVE : FWD_LDS, st, (const bf16_t*)x, (const u32x4*)w13p, (const u32x4*)w2p, r, y,
+                 (bf16_t*)ag, (bf16_t*)u, M, F, ldr);
+    return GAOT_OK;
+}
+
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------------------
+// The backward's first half as one launch: a | g RECOMPUTED from the saved normalised input (the forward then writes neither a | g nor
+// u: 96 MB per layer at S = 16 384 that never cross HBM in the forward and are not read back here), du = dy W2, the SwiGLU derivative on
+// the rounded a, g, du (the arithmetic of k_swiglu_bwd_bf16), and
+//     dag = d(a) | d(g)  (bf16 [M][2F]: the operand of the dx and dW13 GEMMs),   u = silu(a) g  (bf16 [M][F]: the operand of dW2),
+//     dyb = bf16(dy)     ([M][256]: the operand of dW2)
+// written once.  X [M][256] bf16, DY [M][256] fp32, W13p as in the forward, W2tp = fragments of W2^T (layout table above).
+// Per chunk of 128 columns a wave issues 64 (a | g) + 32 (du) MFMAs; the derivative of chunk c sits between the MFMAs of chunk c + 1.
+// No barrier in the chunk loop: a wave stages and stores its own 32 columns.
+constexpr int STG_ROW = 208;              // a staged row: 32 da | 32 dg | 32 u bf16 = 192 B, + 16 B so that 16 consecutive rows start in 16 different bank groups
+constexpr int BWD_STG = 64 * STG_ROW;     // a wave's staging
+constexpr int BWD_LDS = 2 * H_BYTES + 4 * BWD_STG;
+
+template <int RD>
+__global__ __launch_bounds__(256, 1) void k_ffn_bwd(const bf16_t* __restrict__ X, const float* __restrict__ DY, const u32x4* __restrict__ W13p,
+                                                     const u32x4* __restrict__ W2tp, bf16_t* __restrict__ DAG, bf16_t* __restrict__ U,
+                                                     bf16_t* __restrict__ DYB, int M, int F) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB, NC = F / FC;
+    constexpr int LA = RD - 1;
+    static_assert(6 % RD == 0, "the ring is indexed by the step within a chunk");
+
+    const int64_t xbytes = (int64_t)M * D * 2, dagbytes = (int64_t)M * F * 4, ubytes = (int64_t)M * F * 2, dybytes = (int64_t)M * D * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, (int)(dybytes > 0x7fffffff ? 0x7fffffff : dybytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dagrs = __builtin_amdgcn_make_buffer_rsrc((void*)DAG, 0, (int)(dagbytes > 0x7fffffff ? 0x7fffffff : dagbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dybrs = __builtin_amdgcn_make_buffer_rsrc((void*)DYB, 0, DYB ? (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes) : 0, 0x00020000);
+
+    // steps of chunk c: st 0..3 = the four 64-deep k-slices of h W13c^T (8 blocks: a, g x 4 k-steps), st 4, 5 = the two 128-deep k-slices
+    // of dy W2tc^T (8 blocks: 8 k-steps of the one 32-column tile); 16 MFMAs per step either way
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t w13rs = __builtin_amdgcn_make_buffer_rsrc((void*)W13p, 0, 2 * F * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2trs = __builtin_amdgcn_make_buffer_rsrc((void*)W2tp, 0, D * F * 2, 0x00020000);
+    auto wload = [&](u32x4 (&dst)[8], int c, int st) {
+        if (st < 4) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    dst[jt * 4 + s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w13rs, lane * 16, ((((c * 4 + wv) * 2 + jt) * 16) + 4 * st + s) * 1024, 0));
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2trs, lane * 16, (((c * 4 + wv) * 16) + 8 * (st - 4) + s) * 1024, 0));
+        }
+    };
+    u32x4 wr[RD][8];
+    auto prefetch = [&](int c, int tpos) {     // tpos = step of chunk c, may run into chunk c + 1
+        wload(wr[tpos % RD], tpos < 6 ? c : c + 1, tpos < 6 ? tpos : tpos - 6);
+    };
+#pragma unroll
+    for (int p = 0; p < LA; ++p) prefetch(0, p);
+
+    // tiles: h (bf16 as stored) by LDS-DMA; dy fp32 -> bf16 through registers; both 64 rows x 512 B, slot s of row r = chunk s ^ (r & 15)
+    {
+        const int lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = 2 * i + lh;
+            const int voff = (m0 + wave * 16 + x) * D * 2 + (((lane & 31) ^ x) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lds + (wave * 8 + i) * 1024), 16, voff, 0, 0, 0);
+        }
+        f32x4 d0[8], d1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {       // row 8 i + (tid >> 5), 16-byte bf16 chunk tid & 31 = 8 floats
+            const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+            const unsigned off = m < M ? (unsigned)m * (unsigned)D * 4u + (unsigned)(threadIdx.x & 31) * 32u : 0x80000000u;
+            d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, off, 0, 0));
+            d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, off, 16, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31, m = m0 + row;
+            const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+            *reinterpret_cast<u32x4*>(lds + H_BYTES + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+            if (DYB) __builtin_amdgcn_raw_buffer_store_b128(v, dybrs, m < M ? (unsigned)m * (unsigned)D * 2u + (unsigned)ch * 16u : 0x80000000u, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 agc[2][2], agn[2][2], duc[2], dun[2];
+    const int sw = l31 & 15;
+    const char* hb = lds + l31 * 512;                       // h rows l31 (i = 0) and 32 + l31 (+ 32 * 512)
+    const char* yb = lds + H_BYTES + l31 * 512;             // dy rows, same layout
+    char* stg = lds + 2 * H_BYTES + wave * BWD_STG;         // this wave's staging: row r at r * STG_ROW: da 64 B | dg 64 B | u 64 B
+    bf16x8 fn0, fn1;
+    // k-step ks (0..15) of the a | g product (fragments of h), or of the du product (fragments of dy), with the NEXT k-step's two
+    // activation fragments requested first; `nxt` = base of the tile the next k-step reads (h or dy)
+    auto ag_kstep = [&](f32x16 (&acc)[2][2], const u32x4 (&w)[8], int ks, const char* nxt) {
+        const bf16x8 h0 = fn0, h1 = fn1;
+        const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+        fn0 = *reinterpret_cast<const bf16x8*>(nxt + slot);
+        fn1 = *reinterpret_cast<const bf16x8*>(nxt + 32 * 512 + slot);
+        const bf16x8 wa = __builtin_bit_cast(bf16x8, w[ks & 3]), wg = __builtin_bit_cast(bf16x8, w[4 + (ks & 3)]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h0, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h1, acc[1][1], 0, 0, 0);
+    };
+    auto du_kstep = [&](f32x16 (&acc)[2], const u32x4 (&w)[8], int ks, const char* nxt) {
+        const bf16x8 y0 = fn0, y1 = fn1;
+        const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+        fn0 = *reinterpret_cast<const bf16x8*>(nxt + slot);
+        fn1 = *reinterpret_cast<const bf16x8*>(nxt + 32 * 512 + slot);
+        const bf16x8 wt = __builtin_bit_cast(bf16x8, w[ks & 7]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt, y0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt, y1, acc[1], 0, 0, 0);
+    };
+    auto zero = [&](f32x16 (&a)[2][2], f32x16 (&d)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a[0][i][r] = 0.f; a[1][i][r] = 0.f; d[i][r] = 0.f; }
+    };
+    fn0 = *reinterpret_cast<const bf16x8*>(hb + ((hf ^ sw) << 4));
+    fn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + ((hf ^ sw) << 4));
+    // ---- prologue: a | g and du of chunk 0 ----
+    zero(agc, duc);
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        prefetch(0, st + LA);
+        if (st < 4) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ag_kstep(agc, wr[st % RD], 4 * st + s, (4 * st + s == 15) ? yb : hb);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) du_kstep(duc, wr[st % RD], 8 * (st - 4) + s, (8 * (st - 4) + s == 15) ? hb : yb);
+        }
+    }
+
+    for (int c = 0; c < NC; ++c) {
+        // the derivative of chunk c: agc[jt][i][r] / duc[i][r]: column c*128 + 32 wave + mfma32_row(r, hf), row m0 + 32 i + l31.  Unit (i, q)
+        // = the lane's four columns 8q + 4hf .. + 3 of row tile i; the units (i, q) and (i, q + 2) leave together (16 bytes per lane).
+        unsigned pa[2][2][2], pg[2][2][2], pu[2][2][2];      // [slot of the pair][unit within the pair][2 words]
+        auto half_unit = [&](int i, int q, int ps, int pw, int h) {       // elements 2h, 2h + 1 of unit (i, q)
+            const unsigned wa = pack2(agc[0][i][4 * q + 2 * h], agc[0][i][4 * q + 2 * h + 1]);
+            const unsigned wg = pack2(agc[1][i][4 * q + 2 * h], agc[1][i][4 * q + 2 * h + 1]);
+            const unsigned wd = pack2(duc[i][4 * q + 2 * h], duc[i][4 * q + 2 * h + 1]);
+            float av[2], gv[2], dv[2], sg[2], t[2], da[2], dg[2], o[2];
+            av[0] = __uint_as_float(wa << 16); av[1] = __uint_as_float(wa & 0xffff0000u);
+            gv[0] = __uint_as_float(wg << 16); gv[1] = __uint_as_float(wg & 0xffff0000u);
+            dv[0] = __uint_as_float(wd << 16); dv[1] = __uint_as_float(wd & 0xffff0000u);
+            // breadth first (see the forward); the arithmetic of k_swiglu_bwd_bf16 / k_swiglu_fwd_bf16 on the rounded a, g, du
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t[e] = -1.4426950408889634f * av[e];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t[e] = 1.0f + t[e];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) sg[e] = __builtin_amdgcn_rcpf(t[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                da[e] = dv[e] * gv[e] * sg[e] * (1.f + av[e] * (1.f - sg[e]));
+                dg[e] = dv[e] * av[e] * sg[e];
+                o[e] = av[e] * sg[e] * gv[e];
+            }
+            pa[ps][pw][h] = pack2(da[0], da[1]);
+            pg[ps][pw][h] = pack2(dg[0], dg[1]);
+            pu[ps][pw][h] = pack2(o[0], o[1]);
+        };
+        auto finish = [&](int i, int q, int ps) {       // units (i, q) [pw 0] and (i, q + 2) [pw 1] -> 16 bytes per lane: columns 8q + 16hf .. + 7
+            const int ml = 32 * i + l31, chunk = q + 2 * hf;      // 16-byte chunk 0..3 of the wave's 64-byte row segment
+            char* row = stg + ml * STG_ROW + (chunk << 4);
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pa[ps][0][0], pa[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pa[ps][0][1], pa[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(row) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pg[ps][0][0], pg[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pg[ps][0][1], pg[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(row + 64) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pu[ps][0][0], pu[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pu[ps][0][1], pu[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(row + 128) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+        };
+        // the wave's staged chunk to HBM: 16 rows x 64 B per instruction and matrix (lane: row lane >> 2, chunk lane & 3)
+        auto copy_out = [&](int piece) {       // piece 0..11: rows 16 (piece & 3) .., matrix piece >> 2 (da, dg, u)
+            const int rowl = 16 * (piece & 3) + (lane >> 2), ch = lane & 3, mat = piece >> 2, m = m0 + rowl;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + rowl * STG_ROW + mat * 64 + (ch << 4));
+            const int col = c * FC + wave * 32 + ch * 8;
+            if (mat < 2) __builtin_amdgcn_raw_buffer_store_b128(v, dagrs, m < M ? (unsigned)m * (unsigned)F * 4u + (unsigned)((mat * F + col) * 2) : 0x80000000u, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, urs, m < M ? (unsigned)m * (unsigned)F * 2u + (unsigned)(col * 2) : 0x80000000u, 0, 0);
+        };
+        zero(agn, dun);
+        // 24 groups of four MFMAs (16 a | g k-steps, 8 pairs of du k-steps) of chunk c + 1; group g carries half-unit g (g < 16), the
+        // pairings at g = 3, 7, 11, 15, the copy-out in groups 16..23 -- after the wave's own LDS writes, no barrier
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            prefetch(c + 1, st + LA);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int g = 4 * st + s;
+                if (st < 4) {
+                    ag_kstep(agn, wr[st % RD], g, g == 15 ? yb : hb);
+                    const int j = g >> 1, i = j >> 2, jj = j & 3;       // jj: 0 -> q 0, 1 -> q 2, 2 -> q 1, 3 -> q 3
+                    half_unit(i, (jj >> 1) + 2 * (jj & 1), jj >> 1, jj & 1, g & 1);
+                    if ((g & 3) == 3) finish(i, jj >> 1, jj >> 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                    }
+                } else {
+                    const int ks = 2 * (g - 16);
+                    du_kstep(dun, wr[st % RD], ks, yb);
+                    du_kstep(dun, wr[st % RD], ks + 1, ks + 1 == 15 ? hb : yb);
+                    if (g - 16 < 6) { copy_out(2 * (g - 16)); copy_out(2 * (g - 16) + 1); }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            agc[0][i] = agn[0][i]; agc[1][i] = agn[1][i]; duc[i] = dun[i];
+        }
+    }
+}
+
+template <int RD>
+int launch_ffn_bwd(const void* x, const float* dy, const void* w13p, const void* w2tp, void* dag, void* u, void* dyb, int M, int F, hipStream_t st) {
+    auto kern = k_ffn_bwd<RD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("ffn_bwd: cannot set dynamic LDS %d: %s", BWD_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), BWD_LDS, st, (const bf16_t*)x, dy, (const u32x4*)w13p, (const u32x4*)w2tp, (bf16_t*)dag,
+                 (bf16_t*)u, (bf16_t*)dyb, M, F);
+    return GAOT_OK;
+}
+
+}  // namespace
+
+// bytes of the four packed images of one FFN's weights (forward: w13p, w2p; backward: w2tp, w13tp), each 16-byte aligned:
+// offsets 0, 2F*256*2, +256*F*2, +256*F*2; total 2 * (2F*256 + 256*F) * 2 bytes
+extern "C" int64_t gaot_ffn_packed_bytes(int F, int with_backward) {
+    const int64_t fwd = ((int64_t)2 * F * D + (int64_t)D * F) * 2;
+    return with_backward ? 2 * fwd : fwd;
+}
+
+// Pack the FFN's fp32 weights (w13 = the co-located [w1; w3], [2F][256]; w2 [256][F]) into the fragment-ordered bf16 images the fused
+// kernels stream (see the layout table above).  packed: gaot_ffn_packed_bytes(F, with_backward) bytes.  One launch per FFN per step
+// (the weights change with every optimizer step); stands in for the bf16 casts / transposes of the unfused path.
+extern "C" int gaot_ffn_pack_multi(const gaot_ffn_pack_t* items, int num, int F, int with_backward, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(items && num > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    const int64_t frags = ((int64_t)2 * F * D + (int64_t)D * F) / 8 * (with_backward ? 2 : 1);
+    for (int i0 = 0; i0 < num; i0 += PACK_MAX) {
+        PackTable t{};
+        const int n = std::min(PACK_MAX, num - i0);
+        for (int i = 0; i < n; ++i) {
+            const gaot_ffn_pack_t& it = items[i0 + i];
+            GAOT_CHECK_ARG(it.w13 && it.w2 && it.packed && ((uintptr_t)it.packed % 16) == 0, "null or misaligned pointer in the table");
+            t.w13[i] = it.w13; t.w2[i] = it.w2; t.packed[i] = (bf16_t*)it.packed;
+        }
+        GAOT_KLAUNCH(k_ffn_pack, dim3((unsigned)std::min<int64_t>(ceil_div(frags, 256), 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, F,
+                     with_backward);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_ffn_pack(const float* w13, const float* w2, int F, void* packed, int with_backward, gaot_stream_t stream) {
+    const gaot_ffn_pack_t it{w13, w2, packed};
+    return gaot_ffn_pack_multi(&it, 1, F, with_backward, stream);
+}
+
+// y = w2(silu(w1 x) * w3 x) + residual in one launch: x [rows][256] bf16, packed = gaot_ffn_pack's image, residual fp32 [rows][ldr] or
+// NULL, y fp32 [rows][256]; ag (bf16 [rows][2F] = w1 x | w3 x) and u (bf16 [rows][F] = silu(a) g) are written for the backward when
+// both are non-NULL (both NULL: neither is written).  Values: bit-identical to gaot_ffn_w13_swiglu + gaot_gemm_ex(u, w2, residual).
+extern "C" int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float* residual, int64_t ldr, float* y, void* ag, void* u,
+                            int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(x_bf16 && packed && y && rows > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG((ag == nullptr) == (u == nullptr), "ag and u: both or neither");
+    GAOT_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)ag % 16) == 0 &&
+                   ((uintptr_t)u % 16) == 0 && ((uintptr_t)residual % 16) == 0 && (!residual || ldr % 4 == 0), "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff || (residual && rows * ldr * 4 >= 0x7fffffff)) {
+        gaot_set_error("gaot_ffn_fwd: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const void* w13p = p;
+    const void* w2p = p + (int64_t)2 * F * D;
+    const int rc = ag ? launch_ffn_fwd<true>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, (hipStream_t)stream)
+                      : launch_ffn_fwd<false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, (hipStream_t)stream);
+    if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// The first half of the FFN's backward in one launch, for a forward that saved nothing (gaot_ffn_fwd with ag = u = NULL): x [rows][256]
+// bf16 (the forward's input), dy fp32 [rows][256], packed = gaot_ffn_pack's image WITH the backward images ->
+// dag = d(a) | d(g) (bf16 [rows][2F]), u = silu(a) g (bf16 [rows][F]), dyb = bf16(dy) ([rows][256], optional).  Values: those of
+// gaot_ffn_w13_swiglu + gaot_gemm_ex (du, bf16) + gaot_swiglu_bwd_bf16 + gaot_cast_bf16.  Reference: autograd of attn.py:155-157.
+extern "C" int gaot_ffn_bwd_dag(const void* x_bf16, const float* dy, const void* packed, void* dag, void* u, void* dyb, int64_t rows, int F,
+                                gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(x_bf16 && dy && packed && dag && u && rows > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dag % 16) == 0 &&
+                   ((uintptr_t)u % 16) == 0 && ((uintptr_t)dyb % 16) == 0, "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_ffn_bwd_dag: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const void* w13p = p;
+    const void* w2tp = p + (int64_t)2 * F * D + (int64_t)D * F;
+    const int rc = launch_ffn_bwd<3>(x_bf16, dy, w13p, w2tp, dag, u, dyb, (int)rows, F, (hipStream_t)stream);
+    if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                                 const float a = __uint_as_float((e & 1) ? (aw & 0xffff0000u) : (aw << 16));
                                 const float g = __uint_as_float((e & 1) ? (gw & 0xffff0000u) : (gw << 16));
                                 const float d = rb(acc[jt][i][4 * q + e]);
-                                const float sg = 1.f / (1.f + __expf(-a));
+                                const float sg = sigmoid_fast(a);
                                 da[e] = d * g * sg * (1.f + a * (1.f - sg));
                                 dg[e] = d * a * sg;
                             }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float av = rb(acc[0][i][4 * q + e]), gv = rb(acc[1][i][4 * q + e]);
-                        o[e] = av * (1.0f / (1.0f + __expf(-av))) * gv;
+                        o[e] = av * sigmoid_fast(av) * gv;
                     }
                     pu[q][0] = pack2(o[0], o[1]);
                     pu[q][1] = pack2(o[2], o[3]);

@@ -355,7 +355,7 @@ __global__ void k_swiglu_fwd_bf16(const unsigned short* __restrict__ ag, unsigne
     unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F)[c], a);
     unpack8(reinterpret_cast<const uint4*>(ag + r * 2 * F + F)[c], g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = a[j] * sigmoid_f(a[j]) * g[j];
+    for (int j = 0; j < 8; ++j) o[j] = a[j] * sigmoid_fast(a[j]) * g[j];
     reinterpret_cast<uint4*>(u + r * F)[c] = pack8(o);
 }
 
@@ -372,7 +372,7 @@ __global__ void k_swiglu_bwd_bf16(const unsigned short* __restrict__ ag, const u
     unpack8(reinterpret_cast<const uint4*>(du + r * F)[c], d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float s = sigmoid_f(a[j]);
+        const float s = sigmoid_fast(a[j]);
         da[j] = d[j] * g[j] * s * (1.f + a[j] * (1.f - s));
         dg[j] = d[j] * a[j] * s;
     }

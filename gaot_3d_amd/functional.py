@@ -58,9 +58,36 @@ def precast_weights(mats, transposed=()) -> None:
             _WBT_CACHE[(m.data_ptr(), tuple(m.shape))] = c
 
 
+# fragment-ordered images of FFN weights for the fused FFN kernels (csrc/ffn_fused.hip), made by ONE launch for all blocks of a
+# Transformer (prepack_ffn) and valid until release_precast(): keyed by (address, shape) of the co-located fp32 [w1; w3]
+_FFN_PACK_CACHE: dict = {}
+_FFN_FUSED = os.environ.get("GAOT_FFN_FUSED", "1") != "0"
+
+
+def _ffn_fusable(w13: Tensor, w2: Tensor) -> bool:
+    f2, d = w13.shape
+    return bool(_FFN_FUSED and ops.get_precision() == "bf16" and w13.is_cuda and d == 256 and f2 % 256 == 0 and tuple(w2.shape) == (256, f2 // 2)
+                and w13.dtype == torch.float32 and w2.dtype == torch.float32 and w13.is_contiguous() and w2.is_contiguous())
+
+
+def prepack_ffn(pairs, with_backward: bool) -> None:
+    """``pairs``: (co-located [w1; w3] view, w2) of every FFN about to run; those the fused kernels take (d_model 256, F % 128 == 0,
+    bf16 mode) are packed by one launch per distinct F; ``with_backward``: the images the fused backward reads as well"""
+    _FFN_PACK_CACHE.clear()
+    by_f: dict = {}
+    for w13, w2 in pairs:
+        w13, w2 = _w2d(w13), _w2d(w2)
+        if _ffn_fusable(w13, w2):
+            by_f.setdefault(w13.shape[0] // 2, []).append((w13, w2))
+    for f, items in by_f.items():
+        for (w13, _w2), packed in zip(items, ops.ffn_pack_multi(items, f, with_backward)):
+            _FFN_PACK_CACHE[(w13.data_ptr(), tuple(w13.shape))] = (packed, bool(with_backward))
+
+
 def release_precast() -> None:
     _WB_CACHE.clear()
     _WBT_CACHE.clear()
+    _FFN_PACK_CACHE.clear()
 
 
 def _wbt(w: Tensor) -> Optional[Tensor]:
@@ -522,11 +549,6 @@ class FFNFn(Function):
         wcat_t, w2t = _wbt(wcat32), _wbt(_w2d(w2))   # bf16 transposes from the per-forward cast pass, or None
         xb = bf16_copy_of(x, (m, d))
         xa = xb if xb is not None else x2          # bf16 image written by the producing RMSNorm
-        if xa.dtype == torch.bfloat16 and wcat.dtype == torch.bfloat16 and d == 256 and f % 32 == 0:
-            ag, u = ops.ffn_w13_swiglu(xa, wcat, f)     # projection + SwiGLU in one launch (csrc/gemm_k256.hip, OUT_SWIGLU)
-        else:
-            ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
-            u = ops.swiglu_fwd_bf16(ag, f)
         res = None
         if res_is_x:
             res = x2
@@ -534,9 +556,34 @@ class FFNFn(Function):
             res = residual.reshape(m, d)
             if not res.is_contiguous():
                 res = res.contiguous()
-        y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
+        w2f = _w2d(w2)
+        if xa.dtype == torch.bfloat16 and _ffn_fusable(wcat32, w2f) and (res is None or res.dtype == torch.float32):
+            # the whole FFN in ONE launch over 64-row blocks (csrc/ffn_fused.hip): u never returns from HBM; a | g and u are still
+            # written for the backward below; bit-identical to the two launches of the other branch
+            # Nothing is saved for the backward but the (bf16) input: FFNFn.backward recomputes a | g inside gaot_ffn_bwd_dag -- the 96 MB
+            # of a | g and u per layer at S = 16 384 cross HBM once (backward) instead of three times.  Bit-identical to the other branch.
+            need_bwd = any(ctx.needs_input_grad[:4])
+            packed, has_bwd = _FFN_PACK_CACHE.get((wcat32.data_ptr(), tuple(wcat32.shape)), (None, False))
+            if packed is None or (need_bwd and not has_bwd):
+                packed = ops.ffn_pack(wcat32, w2f, f, need_bwd)
+            y, _ag, _u = ops.ffn_fwd(xa, packed, f, res, save=False)
+            empty = w2c.new_empty(0)
+            ctx.save_for_backward(xa, wcat, w2c, packed, empty, wcat_t if wcat_t is not None else empty, w2t if w2t is not None else empty)
+            ctx.fused = True
+            ctx.res_is_x = res_is_x
+            ctx.wparams = (w1, w3, w2)
+            ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
+            return y.view(*x.shape[:-1], d)
+        else:
+            if xa.dtype == torch.bfloat16 and wcat.dtype == torch.bfloat16 and d == 256 and f % 32 == 0:
+                ag, u = ops.ffn_w13_swiglu(xa, wcat, f)     # projection + SwiGLU in one launch (csrc/gemm_k256.hip, OUT_SWIGLU)
+            else:
+                ag = ops.gemm(xa, wcat, m, 2 * f, d, d, d, False, True, precision=1, out_dtype=torch.bfloat16)
+                u = ops.swiglu_fwd_bf16(ag, f)
+            y = ops.gemm(u, w2c, m, d, f, f, f, False, True, residual=res, ldr=d, precision=1)
         empty = w2c.new_empty(0)
         ctx.save_for_backward(xa, wcat, w2c, ag, u, wcat_t if wcat_t is not None else empty, w2t if w2t is not None else empty)
+        ctx.fused = False
         ctx.res_is_x = res_is_x
         ctx.wparams = (w1, w3, w2)
         ctx.meta = (f, d, x.shape, residual.shape if (residual is not None and not res_is_x) else None, w1.shape, w2.shape)
@@ -550,7 +597,13 @@ class FFNFn(Function):
         dy2 = dy.reshape(m, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        if d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:
+        if ctx.fused:
+            # (x2, wcat, w2c, packed, -, wcat_t, w2t): a | g recomputed, du = dy W2, the SwiGLU derivative and the bf16 copy of dy in ONE
+            # launch (csrc/ffn_fused.hip: k_ffn_bwd); the three products that follow read its outputs
+            packed = ag
+            dag, u, dyb = ops.ffn_bwd_dag(x2, dy2, packed, f)
+            dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
+        elif d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:
             # dy W2 as x W^T with both operands bf16 in memory and K = 256 -> the weights-in-registers kernel
             # (csrc/gemm_k256.hip: 41 -> 18 us at configs[1]) for one rounding pass over dy and a 0.5 MB weight transpose;
             # the weight-gradient GEMM reads the same bf16 rows (half the A traffic)

@@ -293,7 +293,10 @@ class Transformer(nn.Module):
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None):
         if x.is_cuda:    # bf16 mode: ONE launch rounds all weight matrices of the blocks (46 separate casts otherwise)
             mats = self._matrices()   # co-locates w1|w3 first
-            GF.precast_weights(mats, self._ffn_matrices() if self.training else ())
+            ffn = self._ffn_matrices()
+            GF.precast_weights(mats, ffn if self.training else ())
+            # fragment-ordered images for the fused FFN kernels, one launch (with the backward's images when it will run)
+            GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled())
         try:
             return self._forward(x, condition, relative_positions)
         finally:

@@ -801,6 +801,77 @@ def ffn_w13_swiglu(xb: Tensor, w13b: Tensor, f: int):
     return ag, u
 
 
+def ffn_pack(w13: Tensor, w2: Tensor, f: int, with_backward: bool) -> Tensor:
+    """the fp32 co-located [w1; w3] ([2F, 256]) and w2 ([256, F]) as the fragment-ordered bf16 images the fused FFN kernels stream
+    (include/gaot3d_hip.h: gaot_ffn_pack); one uint8 buffer"""
+    lib = _lib.load()
+    if w13.dtype != torch.float32 or w2.dtype != torch.float32 or not (w13.is_contiguous() and w2.is_contiguous()):
+        raise GaotError("ffn_pack: contiguous fp32 weights expected")
+    if tuple(w13.shape) != (2 * f, 256) or tuple(w2.shape) != (256, f):
+        raise GaotError(f"ffn_pack: expected [2F, 256] and [256, F] with F = {f}, got {tuple(w13.shape)} and {tuple(w2.shape)}")
+    packed = torch.empty(lib.gaot_ffn_packed_bytes(int(f), int(with_backward)), dtype=torch.uint8, device=w13.device)
+    check(lib.gaot_ffn_pack(_ptr(w13), _ptr(w2), int(f), _ptr(packed), int(with_backward), _stream()), "gaot_ffn_pack")
+    return packed
+
+
+class _FfnPackItem(C.Structure):   # gaot_ffn_pack_t
+    _fields_ = [("w13", C.c_void_p), ("w2", C.c_void_p), ("packed", C.c_void_p)]
+
+
+def ffn_pack_multi(pairs, f: int, with_backward: bool) -> List[Tensor]:
+    """ffn_pack for every (w13, w2) pair of a Transformer in ONE launch; the images are slices of one buffer"""
+    lib = _lib.load()
+    pairs = list(pairs)
+    if not pairs:
+        return []
+    nb = int(lib.gaot_ffn_packed_bytes(int(f), int(with_backward)))
+    buf = torch.empty(len(pairs) * nb, dtype=torch.uint8, device=pairs[0][0].device)
+    outs = [buf[i * nb:(i + 1) * nb] for i in range(len(pairs))]
+    items = (_FfnPackItem * len(pairs))()
+    for i, ((w13, w2), o) in enumerate(zip(pairs, outs)):
+        if w13.dtype != torch.float32 or w2.dtype != torch.float32 or not (w13.is_contiguous() and w2.is_contiguous()) \
+                or tuple(w13.shape) != (2 * f, 256) or tuple(w2.shape) != (256, f):
+            raise GaotError("ffn_pack_multi: contiguous fp32 [2F, 256] / [256, F] weights expected")
+        items[i] = _FfnPackItem(w13.data_ptr(), w2.data_ptr(), o.data_ptr())
+    check(lib.gaot_ffn_pack_multi(items, len(pairs), int(f), int(with_backward), _stream()), "gaot_ffn_pack_multi")
+    return outs
+
+
+def ffn_fwd(xb: Tensor, packed: Tensor, f: int, residual: Optional[Tensor] = None, save: bool = True):
+    """y = w2(silu(w1 x) * w3 x) + residual in one launch (include/gaot3d_hip.h: gaot_ffn_fwd): x [rows, 256] bf16, ``packed`` from
+    ffn_pack -> (y fp32 [rows, 256], a | g bf16 [rows, 2F] or None, u bf16 [rows, F] or None)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or not xb.is_contiguous() or xb.shape[1] != 256:
+        raise GaotError("ffn_fwd: contiguous bf16 [rows, 256] input expected")
+    rows = xb.shape[0]
+    if residual is not None and (residual.dtype != torch.float32 or residual.stride(-1) != 1 or tuple(residual.shape) != (rows, 256)):
+        raise GaotError("ffn_fwd: fp32 [rows, 256] residual expected")
+    y = torch.empty(rows, 256, dtype=torch.float32, device=xb.device)
+    ag = torch.empty(rows, 2 * f, dtype=torch.bfloat16, device=xb.device) if save else None
+    u = torch.empty(rows, f, dtype=torch.bfloat16, device=xb.device) if save else None
+    with _timed("ffn_fwd"):
+        check(lib.gaot_ffn_fwd(_ptr(xb), _ptr(packed), _ptr(residual), residual.stride(0) if residual is not None else 0, _ptr(y),
+                               _ptr(ag), _ptr(u), rows, int(f), _stream()), "gaot_ffn_fwd")
+    return y, ag, u
+
+
+def ffn_bwd_dag(xb: Tensor, dy: Tensor, packed: Tensor, f: int, want_dyb: bool = True):
+    """the first half of the FFN backward for a forward that saved nothing (include/gaot3d_hip.h: gaot_ffn_bwd_dag): x [rows, 256] bf16,
+    dy fp32 [rows, 256], ``packed`` from ffn_pack(..., with_backward=True) -> (dag bf16 [rows, 2F], u bf16 [rows, F], dyb bf16 or None)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or not xb.is_contiguous() or xb.shape[1] != 256:
+        raise GaotError("ffn_bwd_dag: contiguous bf16 [rows, 256] input expected")
+    rows = xb.shape[0]
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (rows, 256):
+        raise GaotError("ffn_bwd_dag: contiguous fp32 [rows, 256] gradient expected")
+    dag = torch.empty(rows, 2 * f, dtype=torch.bfloat16, device=xb.device)
+    u = torch.empty(rows, f, dtype=torch.bfloat16, device=xb.device)
+    dyb = torch.empty(rows, 256, dtype=torch.bfloat16, device=xb.device) if want_dyb else None
+    with _timed("ffn_bwd_dag"):
+        check(lib.gaot_ffn_bwd_dag(_ptr(xb), _ptr(dy), _ptr(packed), _ptr(dag), _ptr(u), _ptr(dyb), rows, int(f), _stream()), "gaot_ffn_bwd_dag")
+    return dag, u, dyb
+
+
 def ffn_w2_bwd_swiglu(dyb: Tensor, w2t: Tensor, ag: Tensor, f: int) -> Tensor:
     """dy [rows, 256] bf16, W2^T [F, 256] bf16, a | g bf16 [rows, 2F] -> d(a) | d(g) bf16 [rows, 2F]: the du = dy W2 product with the
     SwiGLU backward in its epilogue (include/gaot3d_hip.h: gaot_ffn_w2_bwd_swiglu)"""

@@ -24,7 +24,7 @@ extern "C" {
 #define GAOT_ERR_LAUNCH 2
 #define GAOT_ERR_UNSUPPORTED 3
 
-#define GAOT_ABI_VERSION 10
+#define GAOT_ABI_VERSION 11
 #define GAOT_MAX_MLP_LAYERS 5
 
 typedef void* gaot_stream_t; /* hipStream_t */
@@ -293,6 +293,31 @@ int gaot_swiglu_bwd_bf16(const void* ag, const void* du, void* dag, int64_t rows
  * values as gaot_gemm_ex (du = dy W2, bf16 result) followed by gaot_swiglu_bwd_bf16, du never written.  F % 64 == 0 */
 int gaot_ffn_w2_bwd_swiglu(const void* dy_bf16, const void* w2t_bf16, const void* ag, void* dag, int64_t rows, int64_t lda,
                            int64_t ldw, int F, gaot_stream_t stream);
+/* ---- the SwiGLU FFN as ONE launch per direction over 64-row blocks (ABI 11; csrc/ffn_fused.hip; reference
+ * src/model/layers/attn.py:146-157 FFN.forward and :226-229 the residual around it; d_model = 256, F % 128 == 0) ----
+ * The weights are streamed from L2 in MFMA fragment order: gaot_ffn_pack turns the fp32 co-located [w1; w3] ([2F][256]) and w2
+ * ([256][F]) into the packed bf16 images (gaot_ffn_packed_bytes(F, with_backward) bytes, 16-byte aligned; with_backward adds the
+ * images the backward kernel reads) -- one launch per FFN per optimizer step, in place of the bf16 casts / transposes. */
+int64_t gaot_ffn_packed_bytes(int F, int with_backward);
+int gaot_ffn_pack(const float* w13, const float* w2, int F, void* packed, int with_backward, gaot_stream_t stream);
+/* the same for every FFN of a Transformer in ONE launch (all of width F) */
+typedef struct {
+    const float* w13; /* [2F][256] */
+    const float* w2;  /* [256][F] */
+    void* packed;     /* gaot_ffn_packed_bytes(F, with_backward) bytes, 16-byte aligned */
+} gaot_ffn_pack_t;
+int gaot_ffn_pack_multi(const gaot_ffn_pack_t* items, int num, int F, int with_backward, gaot_stream_t stream);
+/* y = w2(silu(w1 x) * w3 x) + residual: x [rows][256] bf16, residual fp32 [rows][ldr] or NULL, y fp32 [rows][256]; ag (bf16
+ * [rows][2F] = w1 x | w3 x) and u (bf16 [rows][F]) are written for the backward when non-NULL (both or neither).  Bit-identical to
+ * gaot_ffn_w13_swiglu followed by gaot_gemm_ex(u, w2, residual). */
+int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float* residual, int64_t ldr, float* y, void* ag, void* u, int64_t rows,
+                 int F, gaot_stream_t stream);
+/* the first half of the backward for a forward that saved nothing (ag = u = NULL above): a | g recomputed from x, du = dy W2, the
+ * SwiGLU derivative -> dag = d(a) | d(g) (bf16 [rows][2F]), u = silu(a) g (bf16 [rows][F]), dyb = bf16(dy) ([rows][256], optional):
+ * the operands of the dx = dag W13, dW13 = dag^T x and dW2 = dyb^T u products.  packed: gaot_ffn_pack WITH the backward images.
+ * Values of gaot_ffn_w13_swiglu + gaot_gemm_ex (du, bf16 result) + gaot_swiglu_bwd_bf16 + gaot_cast_bf16. */
+int gaot_ffn_bwd_dag(const void* x_bf16, const float* dy, const void* packed, void* dag, void* u, void* dyb, int64_t rows, int F,
+                     gaot_stream_t stream);
 /* Activations outside the GEMM epilogue's none / gelu / relu / silu: the rest of the reference's `activation_fn(name)`
  * surface (src/model/layers/mlp.py:27-35: any F.<name>, torch's default parameters).  act ids: 0 none, 1 gelu (erf), 2 relu,
  * 3 silu, 4 tanh, 5 leaky_relu, 6 elu, 7 sigmoid, 8 softplus, 9 selu, 10 relu6, 11 hardswish, 12 mish, 13 gelu (tanh form).

@@ -1,0 +1,110 @@
+"""The SwiGLU FFN as one launch per direction (csrc/ffn_fused.hip, ABI 11; reference src/model/layers/attn.py:146-157 FFN.forward,
+:226-229 the residual around it).  The fused kernels keep the arithmetic and the summation order of the unfused launches
+(gaot_ffn_w13_swiglu + gaot_gemm_ex; gaot_gemm_ex + gaot_swiglu_bwd_bf16 + gaot_gemm_ex), so the checks here are BIT equality with
+that path -- which tests/test_ops_gpu.py and the whole-step tests pin against the oracle -- plus a direct fp64 check of the forward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _weights(f, seed=0):
+    torch.manual_seed(seed)
+    w13 = (torch.randn(2 * f, 256, device=DEV) * 0.06).contiguous()
+    w2 = (torch.randn(256, f, device=DEV) * 0.03).contiguous()
+    return w13, w2
+
+
+def test_pack_layouts():
+    """every packed image against its index formula (csrc/ffn_fused.hip, layout table)"""
+    from gaot_3d_amd import ops
+    f = 256
+    w13, w2 = _weights(f)
+    packed = ops.ffn_pack(w13, w2, f, True).view(torch.bfloat16).cpu()
+    w13b, w2b = w13.bfloat16().cpu(), w2.bfloat16().cpu()
+    n13, n2 = 2 * f * 256, 256 * f
+    w13p, w2p, w2tp, w13tp = packed[:n13], packed[n13:n13 + n2], packed[n13 + n2:n13 + 2 * n2], packed[n13 + 2 * n2:]
+    assert w13tp.numel() == n13
+    nc = f // 128
+    lane = torch.arange(64)
+    l31, hf = lane & 31, lane >> 5
+    e = torch.arange(8)
+    for c in range(nc):
+        for w in range(4):
+            for jt in range(2):
+                for s in range(16):
+                    blk = (((c * 4 + w) * 2 + jt) * 16 + s) * 512
+                    rows = jt * f + c * 128 + w * 32 + l31
+                    ks = (16 * s + 8 * hf)[:, None] + e[None, :]
+                    assert torch.equal(w13p[blk:blk + 512].view(64, 8), w13b[rows[:, None], ks]), ("w13p", c, w, jt, s)
+                    j = w * 64 + jt * 32 + l31
+                    kk = ks
+                    src_rows = torch.where(kk < 128, 0, f) + c * 128 + (kk & 127)
+                    assert torch.equal(w13tp[blk:blk + 512].view(64, 8), w13b[src_rows, j[:, None]]), ("w13tp", c, w, jt, s)
+                for s in range(8):
+                    blk = (((c * 4 + w) * 2 + jt) * 8 + s) * 512
+                    rows = w * 64 + jt * 32 + l31
+                    ks = (c * 128 + 16 * s + 8 * hf)[:, None] + e[None, :]
+                    assert torch.equal(w2p[blk:blk + 512].view(64, 8), w2b[rows[:, None], ks]), ("w2p", c, w, jt, s)
+            for s in range(16):
+                blk = ((c * 4 + w) * 16 + s) * 512
+                fcol = c * 128 + w * 32 + l31
+                ks = (16 * s + 8 * hf)[:, None] + e[None, :]
+                assert torch.equal(w2tp[blk:blk + 512].view(64, 8), w2b[ks, fcol[:, None]]), ("w2tp", c, w, s)
+
+
+@pytest.mark.parametrize("rows,f,res", [(16384, 1024, "x"), (4096, 1024, "other"), (1000, 256, None), (70, 128, "x"), (64, 512, None)])
+def test_fused_forward_equals_the_two_launch_path(rows, f, res):
+    from gaot_3d_amd import ops
+    w13, w2 = _weights(f)
+    torch.manual_seed(1)
+    x = torch.randn(rows, 256, device=DEV)
+    xb = x.bfloat16()
+    r = x if res == "x" else (torch.randn(rows, 256, device=DEV) if res == "other" else None)
+    ag0, u0 = ops.ffn_w13_swiglu(xb, w13.bfloat16(), f)
+    y0 = ops.gemm(u0, w2.bfloat16(), rows, 256, f, f, f, False, True, residual=r, ldr=256, precision=1)
+    packed = ops.ffn_pack(w13, w2, f, False)
+    y1, ag1, u1 = ops.ffn_fwd(xb, packed, f, r)
+    y2, ag2, u2 = ops.ffn_fwd(xb, packed, f, r, save=False)
+    torch.cuda.synchronize()
+    assert ag2 is None and u2 is None
+    assert torch.equal(ag0, ag1), f"a | g differ: {(ag0.float() - ag1.float()).abs().max().item():.3e}"
+    assert torch.equal(u0, u1), f"u differs: {(u0.float() - u1.float()).abs().max().item():.3e}"
+    assert torch.equal(y0, y1), f"y differs: {(y0 - y1).abs().max().item():.3e}"
+    assert torch.equal(y1, y2)
+    # and against fp64 on the bf16-rounded operands (the intermediates a, g, u are rounded to bf16 by design)
+    xd, w13d, w2d = xb.double(), w13.bfloat16().double(), w2.bfloat16().double()
+    a, g = (xd @ w13d[:f].t()).bfloat16().double(), (xd @ w13d[f:].t()).bfloat16().double()
+    ud = (torch.nn.functional.silu(a) * g).bfloat16().double()
+    ref = ud @ w2d.t() + (r.double() if r is not None else 0.0)
+    err = (y1.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[parity] ffn_fwd_fused rows={rows} F={f}: max err / peak vs fp64 {err:.3e}")
+    assert err < 2e-3
+
+
+@pytest.mark.parametrize("rows,f", [(16384, 1024), (1000, 256), (70, 128)])
+def test_fused_backward_first_half_equals_the_unfused_chain(rows, f):
+    """gaot_ffn_bwd_dag (a | g recomputed, du, SwiGLU derivative) against gaot_ffn_w13_swiglu + gaot_cast_bf16 + gaot_gemm_ex (du, bf16)
+    + gaot_swiglu_bwd_bf16: u and dyb bit for bit; dag bit for bit or within one bf16 rounding where the compiler contracts differently"""
+    from gaot_3d_amd import ops
+    w13, w2 = _weights(f)
+    torch.manual_seed(2)
+    xb = torch.randn(rows, 256, device=DEV).bfloat16()
+    dy = torch.randn(rows, 256, device=DEV) * 0.1
+    ag0, u0 = ops.ffn_w13_swiglu(xb, w13.bfloat16(), f)
+    dyb0 = ops.cast_bf16(dy)
+    w2t = w2.bfloat16().t().contiguous()
+    du0 = ops.gemm(dyb0, w2t, rows, f, 256, 256, 256, False, True, precision=1, out_dtype=torch.bfloat16)
+    dag0 = ops.swiglu_bwd_bf16(ag0, du0, f)
+    packed = ops.ffn_pack(w13, w2, f, True)
+    dag1, u1, dyb1 = ops.ffn_bwd_dag(xb, dy, packed, f)
+    torch.cuda.synchronize()
+    assert torch.equal(dyb0, dyb1)
+    assert torch.equal(u0, u1), f"u differs: {(u0.float() - u1.float()).abs().max().item():.3e}"
+    a, b = dag0.float(), dag1.float()
+    nbad = int((a != b).sum())
+    rel = ((a - b).abs() / (a.abs().clamp_min(1e-6))).max().item()
+    print(f"[parity] ffn_bwd_dag rows={rows} F={f}: {nbad} of {a.numel()} dag elements differ from the unfused chain, max rel {rel:.3e}")
+    assert rel <= 2 ** -7      # at most one bf16 ulp
+    assert nbad <= 1e-3 * a.numel()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported by libgaot3d_hip.so"
     assert declared == set(_lib.SIGNATURES.keys()), declared ^ set(_lib.SIGNATURES.keys())
-    assert lib.gaot_abi_version() == 10
+    assert lib.gaot_abi_version() == 11
 
 
 
