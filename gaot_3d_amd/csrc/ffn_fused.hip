@@ -654,6 +654,315 @@ __global__ __launch_bounds__(256, 1) void k_ffn_bwd(const bf16_t* __restrict__ X
     }
 }
 
+// The same pass WITH the input gradient: dx = dag W13 (+ dy when the block's residual is the FFN's own input, attn.py:229) accumulated
+// chunk by chunk from the dag chunk in LDS -- the dag tensor is written for the dW13 product but not read back for dx, and the
+// stand-alone dx GEMM (K = 2F) is gone.  Per chunk a wave issues 64 (a | g) + 32 (du) + 64 (dx) MFMAs; ten steps, ring of five.
+// The dag chunk is shared by the four waves (row = 512 B: 16 chunks da | 16 chunks dg, chunk stored at chunk ^ (row & 15)), double
+// buffered, one barrier per chunk; u stays in the wave's private staging.
+constexpr int UST_ROW = 80;                // a wave's staged u row: 64 B + 16 B (16 rows -> 16 bank groups)
+constexpr int BWDX_LDS = 2 * H_BYTES + 2 * AG_BYTES + 4 * 64 * UST_ROW;
+
+__global__ __launch_bounds__(256, 1) void k_ffn_bwd_dx(const bf16_t* __restrict__ X, const float* __restrict__ DY, const u32x4* __restrict__ W13p,
+                                                        const u32x4* __restrict__ W2tp, const u32x4* __restrict__ W13tp, bf16_t* __restrict__ DAG,
+                                                        bf16_t* __restrict__ U, bf16_t* __restrict__ DYB, float* __restrict__ DX, int M, int F,
+                                                        int add_dy) {
+    constexpr int RD = 5, LA = 3;      // five static slots, four live at a time (three steps in flight + the one in use)
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB, NC = F / FC;
+
+    const int64_t xbytes = (int64_t)M * D * 2, dagbytes = (int64_t)M * F * 4, ubytes = (int64_t)M * F * 2, dybytes = (int64_t)M * D * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, (int)(dybytes > 0x7fffffff ? 0x7fffffff : dybytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dagrs = __builtin_amdgcn_make_buffer_rsrc((void*)DAG, 0, (int)(dagbytes > 0x7fffffff ? 0x7fffffff : dagbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, (int)(ubytes > 0x7fffffff ? 0x7fffffff : ubytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dybrs = __builtin_amdgcn_make_buffer_rsrc((void*)DYB, 0, DYB ? (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dxrs = __builtin_amdgcn_make_buffer_rsrc((void*)DX, 0, (int)(dybytes > 0x7fffffff ? 0x7fffffff : dybytes), 0x00020000);
+
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t w13rs = __builtin_amdgcn_make_buffer_rsrc((void*)W13p, 0, 2 * F * D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2trs = __builtin_amdgcn_make_buffer_rsrc((void*)W2tp, 0, D * F * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w13trs = __builtin_amdgcn_make_buffer_rsrc((void*)W13tp, 0, 2 * F * D * 2, 0x00020000);
+    // kinds of step (8 fragment blocks, 16 MFMAs each): A(st 0..3) = k-slice st of h W13c^T; B(st 0, 1) = k-slice of dy W2tc^T;
+    // C(st 0..3) = k-slice of dag_c W13c (fragments of W13^T: output columns 64 w + 32 jt .., k over the chunk's 256 dag columns)
+    auto wloadA = [&](u32x4 (&dst)[8], int c, int st) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                dst[jt * 4 + s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w13rs, lane * 16, ((((c * 4 + wv) * 2 + jt) * 16) + 4 * st + s) * 1024, 0));
+    };
+    auto wloadB = [&](u32x4 (&dst)[8], int c, int st) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            dst[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2trs, lane * 16, (((c * 4 + wv) * 16) + 8 * st + s) * 1024, 0));
+    };
+    auto wloadC = [&](u32x4 (&dst)[8], int c, int st) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                dst[jt * 4 + s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w13trs, lane * 16, ((((c * 4 + wv) * 2 + jt) * 16) + 4 * st + s) * 1024, 0));
+    };
+    // the wave's timeline: positions 0..5 = steps A0..A3, B0, B1 of chunk 0 (prologue); iteration c of the loop = ten positions
+    // b = 0..3: A0..A3 of chunk c + 1 (beside the derivative of chunk c), b = 4..7: C0..C3 of chunk c, b = 8, 9: B0, B1 of chunk c + 1
+    // (into the du accumulators the derivative has just finished with: no second set).  Ring slot = position % 5 (10 % 5 == 0: static).
+    u32x4 wr[RD][8];
+    auto load_chunk_step = [&](u32x4 (&dst)[8], int c, int st) {     // st 0..5 of the A / B sequence of chunk c
+        if (st < 4) wloadA(dst, c, st);
+        else wloadB(dst, c, st - 4);
+    };
+    auto prefetch_body = [&](int c, int tpos) {     // tpos = body position of iteration c, may run into iteration c + 1
+        const int cc = tpos < 10 ? c : c + 1, b = tpos < 10 ? tpos : tpos - 10;
+        if (b < 4) wloadA(wr[(6 + tpos) % RD], cc + 1, b);
+        else if (b < 8) wloadC(wr[(6 + tpos) % RD], cc, b - 4);
+        else wloadB(wr[(6 + tpos) % RD], cc + 1, b - 8);
+    };
+#pragma unroll
+    for (int p = 0; p < LA; ++p) load_chunk_step(wr[p % RD], 0, p);
+
+    // tiles: h (bf16 as stored) by LDS-DMA; dy fp32 -> bf16 through registers; both 64 rows x 512 B, slot s of row r = chunk s ^ (r & 15)
+    {
+        const int lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = 2 * i + lh;
+            const int voff = (m0 + wave * 16 + x) * D * 2 + (((lane & 31) ^ x) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lds + (wave * 8 + i) * 1024), 16, voff, 0, 0, 0);
+        }
+        f32x4 d0[8], d1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+            const unsigned off = m < M ? (unsigned)m * (unsigned)D * 4u + (unsigned)(threadIdx.x & 31) * 32u : 0x80000000u;
+            d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, off, 0, 0));
+            d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, off, 16, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31, m = m0 + row;
+            const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+            *reinterpret_cast<u32x4*>(lds + H_BYTES + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+            if (DYB) __builtin_amdgcn_raw_buffer_store_b128(v, dybrs, m < M ? (unsigned)m * (unsigned)D * 2u + (unsigned)ch * 16u : 0x80000000u, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 agc[2][2], agn[2][2], duc[2], dx[2][2];
+    const int sw = l31 & 15;
+    const char* hb = lds + l31 * 512;
+    const char* yb = lds + H_BYTES + l31 * 512;
+    char* ust = lds + 2 * H_BYTES + 2 * AG_BYTES + wave * 64 * UST_ROW;      // this wave's staged u: row r at r * UST_ROW
+    bf16x8 fn0, fn1;
+    auto ag_kstep = [&](f32x16 (&acc)[2][2], const u32x4 (&w)[8], int ks, const char* nxt) {
+        const bf16x8 h0 = fn0, h1 = fn1;
+        const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+        fn0 = *reinterpret_cast<const bf16x8*>(nxt + slot);
+        fn1 = *reinterpret_cast<const bf16x8*>(nxt + 32 * 512 + slot);
+        const bf16x8 wa = __builtin_bit_cast(bf16x8, w[ks & 3]), wg = __builtin_bit_cast(bf16x8, w[4 + (ks & 3)]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h0, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, h1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, h1, acc[1][1], 0, 0, 0);
+    };
+    auto du_kstep = [&](f32x16 (&acc)[2], const u32x4 (&w)[8], int ks, const char* nxt) {
+        const bf16x8 y0 = fn0, y1 = fn1;
+        const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+        fn0 = *reinterpret_cast<const bf16x8*>(nxt + slot);
+        fn1 = *reinterpret_cast<const bf16x8*>(nxt + 32 * 512 + slot);
+        const bf16x8 wt = __builtin_bit_cast(bf16x8, w[ks & 7]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt, y0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt, y1, acc[1], 0, 0, 0);
+    };
+    auto zero = [&](f32x16 (&a)[2][2], f32x16 (&d)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a[0][i][r] = 0.f; a[1][i][r] = 0.f; d[i][r] = 0.f; }
+    };
+    // dx starts as dy (the gradient through the block's residual) or as zero: the accumulators themselves hold the fp32 dy rows of this
+    // lane's outputs -- column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31 -- no second set of registers for the residual
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const unsigned roff = (m < M && add_dy) ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;     // out of range -> zeros
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyrs, roff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0));
+                dx[jt][i][4 * q] = v[0]; dx[jt][i][4 * q + 1] = v[1]; dx[jt][i][4 * q + 2] = v[2]; dx[jt][i][4 * q + 3] = v[3];
+            }
+    }
+    fn0 = *reinterpret_cast<const bf16x8*>(hb + ((hf ^ sw) << 4));
+    fn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + ((hf ^ sw) << 4));
+    // ---- prologue: a | g and du of chunk 0 ----
+    zero(agc, duc);
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        if (st + LA < 6) load_chunk_step(wr[(st + LA) % RD], 0, st + LA);
+        else prefetch_body(0, st + LA - 6);
+        if (st < 4) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ag_kstep(agc, wr[st % RD], 4 * st + s, (4 * st + s == 15) ? yb : hb);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) du_kstep(duc, wr[st % RD], 8 * (st - 4) + s, (8 * (st - 4) + s == 15) ? hb : yb);
+        }
+    }
+
+    for (int c = 0; c < NC; ++c) {
+        char* dagb = lds + 2 * H_BYTES + (c & 1) * AG_BYTES;
+        unsigned pa[2][2][2], pg[2][2][2], pu[2][2][2];
+        auto half_unit = [&](int i, int q, int ps, int pw, int h) {
+            const unsigned wa = pack2(agc[0][i][4 * q + 2 * h], agc[0][i][4 * q + 2 * h + 1]);
+            const unsigned wg = pack2(agc[1][i][4 * q + 2 * h], agc[1][i][4 * q + 2 * h + 1]);
+            const unsigned wd = pack2(duc[i][4 * q + 2 * h], duc[i][4 * q + 2 * h + 1]);
+            float av[2], gv[2], dv[2], sg[2], t2[2], da[2], dg[2], o[2];
+            av[0] = __uint_as_float(wa << 16); av[1] = __uint_as_float(wa & 0xffff0000u);
+            gv[0] = __uint_as_float(wg << 16); gv[1] = __uint_as_float(wg & 0xffff0000u);
+            dv[0] = __uint_as_float(wd << 16); dv[1] = __uint_as_float(wd & 0xffff0000u);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t2[e] = -1.4426950408889634f * av[e];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t2[e] = __builtin_amdgcn_exp2f(t2[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) t2[e] = 1.0f + t2[e];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) sg[e] = __builtin_amdgcn_rcpf(t2[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                da[e] = dv[e] * gv[e] * sg[e] * (1.f + av[e] * (1.f - sg[e]));
+                dg[e] = dv[e] * av[e] * sg[e];
+                o[e] = av[e] * sg[e] * gv[e];
+            }
+            pa[ps][pw][h] = pack2(da[0], da[1]);
+            pg[ps][pw][h] = pack2(dg[0], dg[1]);
+            pu[ps][pw][h] = pack2(o[0], o[1]);
+        };
+        auto finish = [&](int i, int q, int ps) {
+            const int ml = 32 * i + l31;
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pa[ps][0][0], pa[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pa[ps][0][1], pa[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(dagb + ml * 512 + (((4 * wave + q + 2 * hf) ^ (ml & 15)) << 4)) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pg[ps][0][0], pg[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pg[ps][0][1], pg[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(dagb + ml * 512 + (((16 + 4 * wave + q + 2 * hf) ^ (ml & 15)) << 4)) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pu[ps][0][0], pu[ps][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pu[ps][0][1], pu[ps][1][1], false, false);
+                *reinterpret_cast<u32x4*>(ust + ml * UST_ROW + ((q + 2 * hf) << 4)) = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { agn[0][i][r] = 0.f; agn[1][i][r] = 0.f; }
+        // ---- a | g of chunk c + 1 (16 k-steps of four MFMAs) with the derivative of chunk c between them ----
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            prefetch_body(c, st + LA);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int g = 4 * st + s;
+                ag_kstep(agn, wr[(6 + st) % RD], g, hb);        // (its request at k-step 15 wraps to h's first fragments: unused)
+                const int j = g >> 1, i = j >> 2, jj = j & 3;
+                half_unit(i, (jj >> 1) + 2 * (jj & 1), jj >> 1, jj & 1, g & 1);
+                if ((g & 3) == 3) finish(i, jj >> 1, jj >> 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();        // the chunk's dag is complete; the other buffer's readers (chunk c - 1) are all past their reads
+        // ---- dx += dag_c W13c: four 64-deep steps over the chunk's 256 dag columns; the chunk's dag and u rows to HBM between them ----
+        const char* gb = dagb + l31 * 512;
+        fn0 = *reinterpret_cast<const bf16x8*>(gb + ((hf ^ sw) << 4));
+        fn1 = *reinterpret_cast<const bf16x8*>(gb + 32 * 512 + ((hf ^ sw) << 4));
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            prefetch_body(c, 4 + st + LA);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ks = 4 * st + s;
+                const bf16x8 g0 = fn0, g1 = fn1;
+                {       // the next k-step's fragments: dag, or (last k-step) the first dy fragments of the du product that follows
+                    const char* nb = ks + 1 < 16 ? gb : yb;
+                    const int slot = ((2 * ((ks + 1) & 15) + hf) ^ sw) << 4;
+                    fn0 = *reinterpret_cast<const bf16x8*>(nb + slot);
+                    fn1 = *reinterpret_cast<const bf16x8*>(nb + 32 * 512 + slot);
+                }
+                if ((ks & 1) == 0) {       // this wave's share of the chunk's dag rows (16 wave .. + 15, two rows per instruction) to HBM
+                    const int kk = ks >> 1, row = 16 * wave + 2 * kk + hf, ch = l31, m = m0 + row;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(dagb + row * 512 + ((ch ^ (row & 15)) << 4));
+                    const unsigned off = m < M ? (unsigned)m * (unsigned)F * 4u + (unsigned)(((ch < 16 ? 0 : F) + c * FC + (ch & 15) * 8) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, dagrs, off, 0, 0);
+                } else if ((ks & 3) == 1) {      // and its own u chunk: 16 rows x 64 B per instruction
+                    const int rowl = 16 * (ks >> 2) + (lane >> 2), ch = lane & 3, m = m0 + rowl;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ust + rowl * UST_ROW + (ch << 4));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, urs, m < M ? (unsigned)m * (unsigned)F * 2u + (unsigned)((c * FC + wave * 32 + ch * 8) * 2) : 0x80000000u, 0, 0);
+                }
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wr[(10 + st) % RD][s]), w1 = __builtin_bit_cast(bf16x8, wr[(10 + st) % RD][4 + s]);
+                dx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, g0, dx[0][0], 0, 0, 0);
+                dx[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, g0, dx[1][0], 0, 0, 0);
+                dx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, g1, dx[0][1], 0, 0, 0);
+                dx[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, g1, dx[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- du of chunk c + 1 (the derivative of chunk c is done with these accumulators) ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) duc[i][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            prefetch_body(c, 8 + st + LA);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                du_kstep(duc, wr[(14 + st) % RD], 8 * st + s, (8 * st + s == 15) ? hb : yb);
+                if (s & 1) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            agc[0][i] = agn[0][i]; agc[1][i] = agn[1][i];
+        }
+    }
+    // ---- dx (+ dy): column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31 ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const unsigned rowoff = m < M ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {dx[jt][i][4 * q], dx[jt][i][4 * q + 1], dx[jt][i][4 * q + 2], dx[jt][i][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dxrs, rowoff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0);
+            }
+    }
+}
+
 template <int RD>
 int launch_ffn_bwd(const void* x, const float* dy, const void* w13p, const void* w2tp, void* dag, void* u, void* dyb, int M, int F, hipStream_t st) {
     auto kern = k_ffn_bwd<RD>;
@@ -751,6 +1060,37 @@ extern "C" int gaot_ffn_bwd_dag(const void* x_bf16, const float* dy, const void*
     const void* w2tp = p + (int64_t)2 * F * D + (int64_t)D * F;
     const int rc = launch_ffn_bwd<3>(x_bf16, dy, w13p, w2tp, dag, u, dyb, (int)rows, F, (hipStream_t)stream);
     if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// The same with the input gradient computed in the launch: dx fp32 [rows][256] = dag W13 (+ dy when add_dy: the block's residual is the
+// FFN's own input, reference attn.py:229).  Stands in for gaot_ffn_bwd_dag followed by gaot_gemm_ex(dag, W13^T, residual = dy).
+extern "C" int gaot_ffn_bwd(const void* x_bf16, const float* dy, const void* packed, void* dag, void* u, void* dyb, float* dx, int add_dy,
+                            int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(x_bf16 && dy && packed && dag && u && dx && rows > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dag % 16) == 0 &&
+                   ((uintptr_t)u % 16) == 0 && ((uintptr_t)dyb % 16) == 0 && ((uintptr_t)dx % 16) == 0, "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_ffn_bwd: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_bwd_dx, hipFuncAttributeMaxDynamicSharedMemorySize, BWDX_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("ffn_bwd: cannot set dynamic LDS %d: %s", BWDX_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const bf16_t* w2tp = p + (int64_t)2 * F * D + (int64_t)D * F;
+    const bf16_t* w13tp = w2tp + (int64_t)D * F;
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_ffn_bwd_dx, dim3((unsigned)(8 * per)), dim3(256), BWDX_LDS, (hipStream_t)stream, (const bf16_t*)x_bf16, dy, (const u32x4*)p,
+                 (const u32x4*)w2tp, (const u32x4*)w13tp, (bf16_t*)dag, (bf16_t*)u, (bf16_t*)dyb, dx, (int)rows, F, add_dy);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -62,6 +62,7 @@ def precast_weights(mats, transposed=()) -> None:
 # Transformer (prepack_ffn) and valid until release_precast(): keyed by (address, shape) of the co-located fp32 [w1; w3]
 _FFN_PACK_CACHE: dict = {}
 _FFN_FUSED = os.environ.get("GAOT_FFN_FUSED", "1") != "0"
+_FFN_BWD_DX = os.environ.get("GAOT_FFN_BWD_DX", "1") != "0"      # the input gradient inside the fused backward launch (A/B switch)
 
 
 def _ffn_fusable(w13: Tensor, w2: Tensor) -> bool:
@@ -601,6 +602,13 @@ class FFNFn(Function):
             # (x2, wcat, w2c, packed, -, wcat_t, w2t): a | g recomputed, du = dy W2, the SwiGLU derivative and the bf16 copy of dy in ONE
             # launch (csrc/ffn_fused.hip: k_ffn_bwd); the three products that follow read its outputs
             packed = ag
+            if ctx.needs_input_grad[0] and _FFN_BWD_DX:
+                # ... and the input gradient dag W13 (+ dy) as well: the dag chunk is consumed on chip, the stand-alone K = 2F product is gone
+                dx, dag, u, dyb = ops.ffn_bwd(x2, dy2, packed, f, ctx.res_is_x)
+                dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
+                dwcat = _dw_gemm(dag, x2, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
+                dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
+                return dx.view(xshape), dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None
             dag, u, dyb = ops.ffn_bwd_dag(x2, dy2, packed, f)
             dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         elif d == 256 and w2c.dtype == torch.bfloat16 and f % 64 == 0:

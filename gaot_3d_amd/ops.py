@@ -872,6 +872,25 @@ def ffn_bwd_dag(xb: Tensor, dy: Tensor, packed: Tensor, f: int, want_dyb: bool =
     return dag, u, dyb
 
 
+def ffn_bwd(xb: Tensor, dy: Tensor, packed: Tensor, f: int, add_dy: bool, want_dyb: bool = True):
+    """ffn_bwd_dag with the input gradient in the same launch (include/gaot3d_hip.h: gaot_ffn_bwd) ->
+    (dx fp32 [rows, 256] = dag W13 (+ dy), dag, u, dyb)"""
+    lib = _lib.load()
+    if xb.dtype != torch.bfloat16 or not xb.is_contiguous() or xb.shape[1] != 256:
+        raise GaotError("ffn_bwd: contiguous bf16 [rows, 256] input expected")
+    rows = xb.shape[0]
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (rows, 256):
+        raise GaotError("ffn_bwd: contiguous fp32 [rows, 256] gradient expected")
+    dag = torch.empty(rows, 2 * f, dtype=torch.bfloat16, device=xb.device)
+    u = torch.empty(rows, f, dtype=torch.bfloat16, device=xb.device)
+    dyb = torch.empty(rows, 256, dtype=torch.bfloat16, device=xb.device) if want_dyb else None
+    dx = torch.empty(rows, 256, dtype=torch.float32, device=xb.device)
+    with _timed("ffn_bwd"):
+        check(lib.gaot_ffn_bwd(_ptr(xb), _ptr(dy), _ptr(packed), _ptr(dag), _ptr(u), _ptr(dyb), _ptr(dx), int(add_dy), rows, int(f), _stream()),
+              "gaot_ffn_bwd")
+    return dx, dag, u, dyb
+
+
 def ffn_w2_bwd_swiglu(dyb: Tensor, w2t: Tensor, ag: Tensor, f: int) -> Tensor:
     """dy [rows, 256] bf16, W2^T [F, 256] bf16, a | g bf16 [rows, 2F] -> d(a) | d(g) bf16 [rows, 2F]: the du = dy W2 product with the
     SwiGLU backward in its epilogue (include/gaot3d_hip.h: gaot_ffn_w2_bwd_swiglu)"""

@@ -318,6 +318,11 @@ int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float* residual, 
  * Values of gaot_ffn_w13_swiglu + gaot_gemm_ex (du, bf16 result) + gaot_swiglu_bwd_bf16 + gaot_cast_bf16. */
 int gaot_ffn_bwd_dag(const void* x_bf16, const float* dy, const void* packed, void* dag, void* u, void* dyb, int64_t rows, int F,
                      gaot_stream_t stream);
+/* the same with the input gradient in the launch: dx fp32 [rows][256] = dag W13 (+ dy when add_dy: the block's residual is the FFN's
+ * own input, attn.py:229), accumulated chunk by chunk from the dag chunk on chip -- stands in for gaot_ffn_bwd_dag followed by
+ * gaot_gemm_ex(dag, W13^T, residual = dy); dag and u are still written (the dW13 / dW2 products read them) */
+int gaot_ffn_bwd(const void* x_bf16, const float* dy, const void* packed, void* dag, void* u, void* dyb, float* dx, int add_dy,
+                 int64_t rows, int F, gaot_stream_t stream);
 /* Activations outside the GEMM epilogue's none / gelu / relu / silu: the rest of the reference's `activation_fn(name)`
  * surface (src/model/layers/mlp.py:27-35: any F.<name>, torch's default parameters).  act ids: 0 none, 1 gelu (erf), 2 relu,
  * 3 silu, 4 tanh, 5 leaky_relu, 6 elu, 7 sigmoid, 8 softplus, 9 selu, 10 relu6, 11 hardswish, 12 mish, 13 gelu (tanh form).

@@ -108,3 +108,28 @@ def test_fused_backward_first_half_equals_the_unfused_chain(rows, f):
     print(f"[parity] ffn_bwd_dag rows={rows} F={f}: {nbad} of {a.numel()} dag elements differ from the unfused chain, max rel {rel:.3e}")
     assert rel <= 2 ** -7      # at most one bf16 ulp
     assert nbad <= 1e-3 * a.numel()
+
+
+@pytest.mark.parametrize("rows,f,add_dy", [(16384, 1024, True), (4096, 1024, False), (1000, 256, True), (70, 128, True)])
+def test_fused_backward_with_input_gradient(rows, f, add_dy):
+    """gaot_ffn_bwd: dag, u, dyb bit for bit those of gaot_ffn_bwd_dag; dx against the stand-alone product of that dag (fp32 accumulation
+    in another order: 1e-5 of peak) and against fp64"""
+    from gaot_3d_amd import ops
+    w13, w2 = _weights(f)
+    torch.manual_seed(3)
+    xb = torch.randn(rows, 256, device=DEV).bfloat16()
+    dy = torch.randn(rows, 256, device=DEV) * 0.1
+    packed = ops.ffn_pack(w13, w2, f, True)
+    dag0, u0, dyb0 = ops.ffn_bwd_dag(xb, dy, packed, f)
+    w13t = w13.bfloat16().t().contiguous()
+    dx0 = ops.gemm(dag0, w13t, rows, 256, 2 * f, 2 * f, 2 * f, False, True, residual=dy if add_dy else None, ldr=256, precision=1)
+    dx1, dag1, u1, dyb1 = ops.ffn_bwd(xb, dy, packed, f, add_dy)
+    dx2, _, _, _ = ops.ffn_bwd(xb, dy, packed, f, add_dy)
+    torch.cuda.synchronize()
+    assert torch.equal(dag0, dag1) and torch.equal(u0, u1) and torch.equal(dyb0, dyb1)
+    assert torch.equal(dx1, dx2), "rerun differs"
+    ref = dag0.double() @ w13.bfloat16().double() + (dy.double() if add_dy else 0.0)
+    peak = ref.abs().max().item()
+    e_gemm, e_ref, e_gemm_ref = (dx1 - dx0).abs().max().item() / peak, (dx1.double() - ref).abs().max().item() / peak, (dx0.double() - ref).abs().max().item() / peak
+    print(f"[parity] ffn_bwd dx rows={rows} F={f} add_dy={add_dy}: vs stand-alone GEMM {e_gemm:.2e}, vs fp64 {e_ref:.2e} (stand-alone GEMM vs fp64 {e_gemm_ref:.2e}) of peak")
+    assert e_gemm < 1e-5 and e_ref < 1e-5

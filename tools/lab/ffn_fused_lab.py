@@ -50,3 +50,7 @@ du = ops.gemm(dyb, w2t, rows, f, 256, 256, 256, False, True, precision=1, out_dt
 tb += timeit(lambda: ops.swiglu_bwd_bf16(ag, du, f), "swiglu_bwd_bf16")
 print(f"three launches: {tb:.1f} us")
 timeit(lambda: ops.ffn_bwd_dag(xb, dy, packed, f), "ffn_bwd_dag fused (recompute + du + SwiGLU')")
+dag = ops.swiglu_bwd_bf16(ag, du, f)
+w13t = w13b.t().contiguous()
+timeit(lambda: ops.gemm(dag, w13t, rows, 256, 2 * f, 2 * f, 2 * f, False, True, residual=dy, ldr=256, precision=1), "dx gemm (k_gemm_tn_n256, K = 2F)")
+timeit(lambda: ops.ffn_bwd(xb, dy, packed, f, True), "ffn_bwd fused (recompute + du + SwiGLU' + dx)")
