@@ -43,19 +43,26 @@ __device__ __forceinline__ bf16x8 frag_of(const f32x4& lo, const f32x4& hi) {
 }
 // the same words as 8-byte pieces of the [16 e][64 f] LDS tile (two half tiles of [16][32], tile32 layout): lane (edge n,
 // group g) holds features 16 mb + 4 g + 0..3 of block mb
+// The [16 e][32 f] half tiles of h_l / dz_l are WRITTEN with 8-byte stores (ds_write_b64: groups of 16 consecutive lanes = the 16 edge
+// rows of one group g, banks taken modulo 32 dwords) and READ only through ds_read_b64_tr_b16.  In the plain tile32 layout a row is
+// 64 B = 16 dwords, so rows n and n + 2 of a group land on the same banks: every such store ran 2-way conflicted (round 5 counters:
+// SQ_LDS_BANK_CONFLICT 26 M / 34 M of 47.7 M / 67.7 M LDS cycles for NH = 2 / 3; ~26 stores of ~4 extra cycles per tile).  Here the
+// 8-byte half of a chunk is swapped for rows with bit 1 set -- 16 rows x 8 B cover all 32 banks -- and the transposed read applies
+// the same swap (a bijection of the half-wave's addresses: still conflict free under its modulo-64 banking).
+__device__ __forceinline__ int tile_off8(int row, int chunk, int half) { return tile_off(row, chunk) + 8 * (half ^ ((row >> 1) & 1)); }
 __device__ __forceinline__ void store_frag_rows(char* tile, const bf16x8& f, int s, int n, int g) {
     const uint4 w = __builtin_bit_cast(uint4, f);
     char* half = tile + s * 1024;   // blocks 2s, 2s+1 = features 32 s .. 32 s + 31 = half tile s
-    *reinterpret_cast<uint2*>(half + tile_off(n, (g >> 1)) + 8 * (g & 1)) = make_uint2(w.x, w.y);
-    *reinterpret_cast<uint2*>(half + tile_off(n, 2 + (g >> 1)) + 8 * (g & 1)) = make_uint2(w.z, w.w);
+    *reinterpret_cast<uint2*>(half + tile_off8(n, (g >> 1), g & 1)) = make_uint2(w.x, w.y);
+    *reinterpret_cast<uint2*>(half + tile_off8(n, 2 + (g >> 1), g & 1)) = make_uint2(w.z, w.w);
 }
 // contract over tile ROWS (edges 0..15), lane = column: element i <-> row 8 hf + i  (the natural k order of a row read)
 __device__ __forceinline__ bf16x8 frag_cols16(const char* tile, int lane) {
     const int i = lane & 15, grp = (lane >> 4) & 1, hf = lane >> 5;
     const int col = 16 * grp + 4 * (i & 3);
     const int r0 = 8 * hf + (i >> 2), r1 = r0 + 4;
-    const char* p0 = tile + tile_off(r0, col >> 3) + ((col & 7) << 1);
-    const char* p1 = tile + tile_off(r1, col >> 3) + ((col & 7) << 1);
+    const char* p0 = tile + tile_off8(r0, col >> 3, (col & 7) >> 2);      // tiles written by store_frag_rows
+    const char* p1 = tile + tile_off8(r1, col >> 3, (col & 7) >> 2);
     const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p0));
     const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p1));
     bf16x8 o;
@@ -93,8 +100,11 @@ struct Lds3 {
     // four hidden layers: 56 KB of images + eight waves' tiles (8 x 18.5 KB) do not fit 160 KB -- the fragments are then read
     // from the image buffer in global memory (1 KB per wave instruction, coalesced, L2 resident) instead of LDS
     static constexpr bool GIMG = NH >= 4;
-    static constexpr int w0t = GIMG ? 0 : img_bytes;             // float [8][64] (rows 6, 7 zero)
-    static constexpr int bias = w0t + 8 * H * 4;                // float NH*64 + 32
+    // float [8][W0S] (rows 6, 7 zero); row stride 80, not 64: a lane group of the layer-0 operand read (ds_read_b32, groups of 32
+    // lanes, banks modulo 32) holds rows g and g + 1 -- 64 apart they share every bank (2-way), 80 apart none
+    static constexpr int W0S = 80;
+    static constexpr int w0t = GIMG ? 0 : img_bytes;
+    static constexpr int bias = w0t + 8 * W0S * 4;              // float NH*64 + 32
     static constexpr int tiles = (bias + (NH * H + C) * 4 + 15) & ~15;
     static constexpr int h(int l) { return l * 2048; }          // per-wave offsets: [16 e][64 f] bf16
     static constexpr int dz(int l) { return NH * 2048 + l * 2048; }
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
         for (int i = threadIdx.x; i < L::img_bytes / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = images[i];
     {
         float* w0 = reinterpret_cast<float*>(lds + L::w0t);
-        for (int i = threadIdx.x; i < 8 * H; i += 512) w0[i] = (i < IN0 * H) ? w0t_g[i] : 0.f;
+        for (int i = threadIdx.x; i < 8 * H; i += 512) w0[(i >> 6) * L::W0S + (i & 63)] = (i < IN0 * H) ? w0t_g[i] : 0.f;
         float* bl = reinterpret_cast<float*>(lds + L::bias);
 #pragma unroll
         for (int l = 0; l < NH; ++l)
@@ -317,8 +327,8 @@ __global__ __launch_bounds__(512, 1) void k_gno_bwd3_bf16(
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 z[mb] = *reinterpret_cast<const f32x4*>(bias_l + 16 * mb + 4 * g);
-                z[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[g * H + 16 * mb + n], bin0, z[mb], 0, 0, 0);
-                z[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[(4 + g) * H + 16 * mb + n], bin1, z[mb], 0, 0, 0);
+                z[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[g * L::W0S + 16 * mb + n], bin0, z[mb], 0, 0, 0);
+                z[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[(4 + g) * L::W0S + 16 * mb + n], bin1, z[mb], 0, 0, 0);
             }
             activate(0, z);
         }
