@@ -70,6 +70,7 @@ SIGNATURES = {
     "gaot_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
     "gaot_rmsnorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "gaot_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
+    "gaot_rmsnorm_bwd2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gaot_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "gaot_colsum": (_i, [_p, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "gaot_gemm_ex_partials": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _p, _sz, _p, _p, _p]),

@@ -48,8 +48,8 @@ __global__ void k_rmsnorm_fwd(const float* __restrict__ x, const float* __restri
 // dx = r*w*dy - x*r^3*mean(x*w*dy);  dw partial per block = sum_rows dy*x*r
 constexpr int RN_ROWS_PER_WAVE = 8;
 __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                              const float* __restrict__ rstd, const float* __restrict__ dx_add, float* __restrict__ dx,
-                              float* __restrict__ dw_part, int64_t rows, int d) {
+                              const float* __restrict__ rstd, const float* __restrict__ dx_add, const float* __restrict__ dx_add2,
+                              float* __restrict__ dx, float* __restrict__ dw_part, int64_t rows, int d) {
     extern __shared__ float sm[];  // [4][d]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = d / 4;
@@ -82,7 +82,12 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
             if (i < nv) {
                 const float4 v = xr[i], g = gr[i], ww = wr[i];
                 // dx_add: the gradient that reaches x through its other consumer (the block's residual), added here
-                const float4 e = dx_add ? reinterpret_cast<const float4*>(dx_add + row * d)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 e = dx_add ? reinterpret_cast<const float4*>(dx_add + row * d)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dx_add2) {      // a third consumer of x (the U-ViT skip tap): (dx + dx_add) + dx_add2, the order of two accumulation passes
+                    const float4 e2 = reinterpret_cast<const float4*>(dx_add2 + row * d)[i];
+                    dxr[i] = make_float4((r * ww.x * g.x - v.x * c + e.x) + e2.x, (r * ww.y * g.y - v.y * c + e.y) + e2.y,
+                                         (r * ww.z * g.z - v.z * c + e.z) + e2.z, (r * ww.w * g.w - v.w * c + e.w) + e2.w);
+                } else
                 dxr[i] = make_float4(r * ww.x * g.x - v.x * c + e.x, r * ww.y * g.y - v.y * c + e.y,
                                      r * ww.z * g.z - v.z * c + e.z, r * ww.w * g.w - v.w * c + e.w);
                 dwacc[j].x += g.x * v.x * r;
@@ -108,8 +113,8 @@ __global__ void k_rmsnorm_bwd(const float* __restrict__ x, const float* __restri
 // bound at 3.9 TB/s).  Same arithmetic, same summation order, same partial layout.
 __global__ __launch_bounds__(256) void k_rmsnorm_bwd_d256(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, const float* __restrict__ rstd,
-                                                          const float* __restrict__ dx_add, float* __restrict__ dx,
-                                                          float* __restrict__ dw_part, int64_t rows) {
+                                                          const float* __restrict__ dx_add, const float* __restrict__ dx_add2,
+                                                          float* __restrict__ dx, float* __restrict__ dw_part, int64_t rows) {
     constexpr int d = 256, R = RN_ROWS_PER_WAVE;
     __shared__ float sm[4 * d];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -138,9 +143,13 @@ __global__ __launch_bounds__(256) void k_rmsnorm_bwd_d256(const float* __restric
     for (int rr = 0; rr < R; ++rr) {
         if (row0 + rr >= rows) break;
         const float rs = r[rr], c = dot[rr] * rs * rs * rs / (float)d;
-        reinterpret_cast<float4*>(dx + (row0 + rr) * d)[lane] =
-            make_float4(rs * ww.x * g[rr].x - v[rr].x * c + e[rr].x, rs * ww.y * g[rr].y - v[rr].y * c + e[rr].y,
-                        rs * ww.z * g[rr].z - v[rr].z * c + e[rr].z, rs * ww.w * g[rr].w - v[rr].w * c + e[rr].w);
+        float4 o = make_float4(rs * ww.x * g[rr].x - v[rr].x * c + e[rr].x, rs * ww.y * g[rr].y - v[rr].y * c + e[rr].y,
+                               rs * ww.z * g[rr].z - v[rr].z * c + e[rr].z, rs * ww.w * g[rr].w - v[rr].w * c + e[rr].w);
+        if (dx_add2) {      // a third consumer of x (the U-ViT skip tap), added last: the order of two accumulation passes
+            const float4 e2 = reinterpret_cast<const float4*>(dx_add2 + (row0 + rr) * d)[lane];
+            o = make_float4(o.x + e2.x, o.y + e2.y, o.z + e2.z, o.w + e2.w);
+        }
+        reinterpret_cast<float4*>(dx + (row0 + rr) * d)[lane] = o;
         dwacc.x += g[rr].x * v[rr].x * rs;
         dwacc.y += g[rr].y * v[rr].y * rs;
         dwacc.z += g[rr].z * v[rr].z * rs;
@@ -533,10 +542,9 @@ extern "C" size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim) {
     return sizeof(float) * (size_t)(ceil_div(rows, 4 * RN_ROWS_PER_WAVE) * dim) + 64;
 }
 
-extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd,
-                                const float* dx_add, float* dx, float* dweight, int64_t rows, int dim, void* workspace,
-                                size_t workspace_bytes, gaot_stream_t stream) {
-    GAOT_ENTER();
+static int rmsnorm_bwd_impl(const float* x, const float* weight, const float* dy, const float* rstd, const float* dx_add,
+                            const float* dx_add2, float* dx, float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
+                            gaot_stream_t stream) {
     GAOT_CHECK_ARG(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 1024, "dim must be a multiple of 4, <= 1024");
     GAOT_CHECK_ARG(workspace_bytes >= gaot_rmsnorm_bwd_workspace_bytes(rows, dim), "workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -547,15 +555,31 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float
     GAOT_CHECK_ARG(x && weight && dy && rstd && dx && workspace, "null pointer");
     const int64_t nblk = ceil_div(rows, 4 * RN_ROWS_PER_WAVE);
     float* part = (float*)workspace;
-    if (dim == 256 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)weight) & 15) == 0)
-        GAOT_KLAUNCH(k_rmsnorm_bwd_d256, dim3((unsigned)nblk), dim3(256), 0, st, x, weight, dy, rstd, dx_add, dx, part, rows);
+    if (dim == 256 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)dx_add2 | (uintptr_t)weight) & 15) == 0)
+        GAOT_KLAUNCH(k_rmsnorm_bwd_d256, dim3((unsigned)nblk), dim3(256), 0, st, x, weight, dy, rstd, dx_add, dx_add2, dx, part, rows);
     else
         GAOT_KLAUNCH(k_rmsnorm_bwd, dim3((unsigned)nblk), dim3(256), sizeof(float) * 4 * dim, st, x, weight, dy, rstd,
-                           dx_add, dx, part, rows, dim);
+                           dx_add, dx_add2, dx, part, rows, dim);
     // dweight == NULL: the gaot_rmsnorm_bwd_parts(rows) partial rows stay in the workspace for gaot_reduce_multi (32 lanes)
     if (dweight) GAOT_KLAUNCH(k_reduce_parts, dim3(blocks_for(dim, RP_COLS)), dim3(256), 0, st, part, nblk, (int64_t)dim, dweight);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
+}
+
+extern "C" int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd,
+                                const float* dx_add, float* dx, float* dweight, int64_t rows, int dim, void* workspace,
+                                size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    return rmsnorm_bwd_impl(x, weight, dy, rstd, dx_add, nullptr, dx, dweight, rows, dim, workspace, workspace_bytes, stream);
+}
+// the same with a SECOND gradient that reaches x through a third consumer (the long-range skip of the U-ViT, reference attn.py:282-288:
+// an encoder block's output feeds the next block AND the mirrored decoder block): dx = (dx + dx_add) + dx_add2 in the same pass --
+// stands in for the accumulation pass the autograd engine would run on the two gradients
+extern "C" int gaot_rmsnorm_bwd2(const float* x, const float* weight, const float* dy, const float* rstd, const float* dx_add,
+                                 const float* dx_add2, float* dx, float* dweight, int64_t rows, int dim, void* workspace,
+                                 size_t workspace_bytes, gaot_stream_t stream) {
+    GAOT_ENTER();
+    return rmsnorm_bwd_impl(x, weight, dy, rstd, dx_add, dx_add2, dx, dweight, rows, dim, workspace, workspace_bytes, stream);
 }
 extern "C" int64_t gaot_rmsnorm_bwd_parts(int64_t rows) { return ceil_div(rows, 4 * RN_ROWS_PER_WAVE); }
 

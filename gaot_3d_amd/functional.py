@@ -294,23 +294,30 @@ class RMSNormResFn(Function):
     backward kernel itself instead of a separate accumulation pass over [B*S, d]."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, eps: float):
+    def forward(ctx, x: Tensor, weight: Tensor, eps: float, tap: bool = False):
+        """``tap`` (extension): a THIRD alias of x for the U-ViT's long-range skip (reference attn.py:282-288: an encoder block's output
+        feeds the next block and the mirrored decoder block) -- its gradient, too, is added by the backward kernel, so x keeps one
+        consumer and the autograd engine runs no accumulation pass for it"""
         xc = x if x.is_contiguous() else x.contiguous()
         y, rstd, yb = ops.rmsnorm_fwd(xc, weight, eps, _want_bf16_copy(xc))
         ctx.save_for_backward(xc, weight, rstd)
         yb = yb if yb is not None else torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(yb)
         ctx.set_materialize_grads(False)   # an unused output (the bf16 copy, the residual) gets None, not a zero fill
+        ctx.nargs = 4       # (apply is always called with the four arguments)
+        if tap:
+            return y, xc.detach(), yb, xc.detach()
         return y, xc.detach(), yb
 
     @staticmethod
-    def backward(ctx, dy: Tensor, dres: Optional[Tensor], _dyb=None):
+    def backward(ctx, dy: Tensor, dres: Optional[Tensor], _dyb=None, dtap: Optional[Tensor] = None):
         x, w, rstd = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(x)
         d = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, None if dres is None else dres.reshape(x.shape), defer=ops.defer_ok((w,)))
-        return dx, dw, None
+        dx, dw = ops.rmsnorm_bwd(x, w, d, rstd, None if dres is None else dres.reshape(x.shape), defer=ops.defer_ok((w,)),
+                                 dx_add2=None if dtap is None else dtap.reshape(x.shape))
+        return (dx, dw, None, None)[:ctx.nargs]
 
 
 class AttentionFn(Function):
@@ -851,6 +858,15 @@ def multi_linear(x: Tensor, weights, precision: Optional[int] = None, image_spec
     return MultiLinearFn.apply(x, precision, image_spec, *weights)
 
 
+def _same_view(a: Tensor, b: Tensor) -> bool:
+    """the same autograd tensor, or two identical views of one base (x.reshape(..) taken twice): gradients handed to either reach
+    the same elements of the same tensor"""
+    if a is b:
+        return True
+    ba, bb = (a._base if a._base is not None else a), (b._base if b._base is not None else b)
+    return ba is bb and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+
+
 class CatLinearFn(Function):
     """y = [x_0 | x_1 | ...] W^T + b without materialising the concatenation (reference: torch.cat then
     nn.Linear -- magno.py:494,571-575,771-775): one GEMM per input against the matching column block of
@@ -875,6 +891,8 @@ class CatLinearFn(Function):
             col += ki
         ctx.save_for_backward(w, *xs2)
         ctx.meta = (precision, weight.shape, bias is not None)
+        # were two of the inputs the same autograd tensor?  (then a None for the later one is "no further contribution")
+        ctx.dups = any(_same_view(xs[i], xs[j]) for i in range(len(xs)) for j in range(i))
         return y
 
     @staticmethod
@@ -887,10 +905,20 @@ class CatLinearFn(Function):
         dw = torch.empty(n, k, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[0] else None
         dxs = []
         col = 0
+        first = {}      # storage of an input -> index of its first occurrence
         for i, x in enumerate(xs):
             ki = x.shape[1]
-            dxs.append(ops.gemm(d, w[:, col:], m, ki, n, n, k, False, False, precision=precision)
-                       if ctx.needs_input_grad[3 + i] else None)
+            key = (x.data_ptr(), tuple(x.shape))
+            j = first.get(key)
+            if ctx.needs_input_grad[3 + i] and j is not None and dxs[j] is not None and ctx.dups:
+                # the SAME tensor twice (the first decoder block of the U-ViT gets the last encoder output as x AND as its skip,
+                # attn.py:282-288): its two gradients meet in this GEMM's epilogue and leave as ONE -- no accumulation pass by the engine
+                dxs[j] = ops.gemm(d, w[:, col:], m, ki, n, n, k, False, False, residual=dxs[j], ldr=ki, precision=precision)
+                dxs.append(None)
+            else:
+                dxs.append(ops.gemm(d, w[:, col:], m, ki, n, n, k, False, False, precision=precision)
+                           if ctx.needs_input_grad[3 + i] else None)
+                first.setdefault(key, i)
             if dw is not None:
                 ops.gemm(d, x, n, ki, m, n, ki, True, False, out=dw[:, col:], ldc=k, precision=precision)
             col += ki

@@ -116,7 +116,12 @@ class GAOT3D(nn.Module):
         if tokens_batch_idx is None:
             lat = tokens_pos.to(device)
             lat = lat if num_graphs == 1 else lat.repeat(num_graphs, 1)
-            lat_bidx = torch.arange(num_graphs, device=device).repeat_interleave(self.num_latent_tokens)
+            # a per-(batch size, device) constant: built once (arange + repeat_interleave are ATen launches on the replayed step otherwise)
+            cache = self.__dict__.setdefault("_lat_bidx_cache", {})
+            lat_bidx = cache.get((num_graphs, device))
+            if lat_bidx is None:
+                lat_bidx = torch.arange(num_graphs, device=device).repeat_interleave(self.num_latent_tokens)
+                cache[(num_graphs, device)] = lat_bidx
         else:
             assert tokens_pos.shape[0] == tokens_batch_idx.shape[0], "tokens_pos and tokens_batch_idx must have same length"
             lat, lat_bidx = tokens_pos.to(device), tokens_batch_idx.to(device)

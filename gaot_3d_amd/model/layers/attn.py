@@ -4,6 +4,7 @@
 RMSNorm row kernel, MFMA GEMMs (q|k|v and w1|w3 written into one fused buffer each), RoPE, flash
 attention fwd/bwd, SwiGLU.  Time-conditional norm (use_conditional_norm, reference mlp.py:74-128) rescales the input
 of attention / FFN per batch element (needs ``condition`` as a [batch, 1] tensor)."""
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -47,6 +48,9 @@ class TransformerConfig:
     use_long_range_skip: bool = True
     attn_config: AttentionConfig = field(default_factory=AttentionConfig)
     ffn_config: FFNConfig = field(default_factory=FFNConfig)
+
+
+SKIP_TAPS = {"on": os.environ.get("GAOT_SKIP_TAPS", "1") != "0"}      # A/B switch of Transformer._forward's skip taps (tests)
 
 
 class RotaryEmbedding(nn.Module):
@@ -200,12 +204,14 @@ class RMSNorm(nn.Module):
             y._gaot_bf16 = yb      # picked up by the GEMM that consumes y (functional.bf16_copy_of)
         return y
 
-    def forward_with_residual(self, x):
-        """(norm(x), x) with x routed through the same autograd node: see functional.RMSNormResFn"""
-        y, xres, yb = GF.RMSNormResFn.apply(x, self.weight, self.eps)
+    def forward_with_residual(self, x, tap: bool = False):
+        """(norm(x), x) with x routed through the same autograd node: see functional.RMSNormResFn; ``tap``: (norm(x), x, x) -- a
+        third alias of x for the U-ViT's long-range skip"""
+        out = GF.RMSNormResFn.apply(x, self.weight, self.eps, bool(tap))
+        y, xres, yb = out[:3]
         if yb.numel():
             y._gaot_bf16 = yb
-        return y, xres
+        return (y, xres, out[3]) if tap else (y, xres)
 
 
 class TransformerBlock(nn.Module):
@@ -224,19 +230,28 @@ class TransformerBlock(nn.Module):
             self.skip_proj = nn.Linear(input_size + output_size, input_size)
 
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
-                skip: Optional[torch.Tensor] = None):
+                skip: Optional[torch.Tensor] = None, want_input_tap: bool = False):
+        """``want_input_tap`` (extension, used by Transformer._forward): also return an alias of the block's INPUT whose gradient the
+        attention norm's backward kernel adds itself -- the caller hands it to the mirrored decoder block as its long-range skip
+        (reference attn.py:282-288) instead of the input tensor, which then keeps a single consumer.  None when the block cannot
+        provide one (no attention norm, or a skip projection in front of it)."""
+        tap, asked = None, want_input_tap
         if self.skip_connection and skip is not None:
             b, s, d = x.shape
             x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
                               self.skip_proj.bias).view(b, s, -1)
+            want_input_tap = False
         if self.attn_norm is None:
             h, xres = x, x
+        elif want_input_tap and x.is_cuda:
+            h, xres, tap = self.attn_norm.forward_with_residual(x, tap=True)
         else:
             h, xres = self.attn_norm.forward_with_residual(x)
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
         h = h if self.ffn_norm is None else self.ffn_norm(h)
         # NB: the second residual adds the *normalised* h (reference attn.py:226-229)
-        return self.ffn(h, condition=condition, residual=h)                                          # h + ffn(h)
+        out = self.ffn(h, condition=condition, residual=h)                                           # h + ffn(h)
+        return (out, tap) if asked else out
 
     @classmethod
     def from_config(cls, input_size: int, output_size: int, skip_connection: bool = False,
@@ -305,12 +320,26 @@ class Transformer(nn.Module):
     def _forward(self, x, condition, relative_positions):
         if isinstance(self.input_proj, nn.Linear):
             x = GF.linear(x, self.input_proj.weight, self.input_proj.bias)
+        # long-range skips: the output of encoder block i feeds block i + 1 AND decoder block n - 1 - i.  The skip handed to the decoder
+        # is an alias produced by the NEXT block's attention norm (RMSNormResFn tap): both gradients of x_i then meet inside that
+        # norm's backward kernel and the autograd engine runs no accumulation pass over [S, d] per skip (4 ATen adds per step at L = 10)
         skips = []
-        for layer in self.encoder_layers:
-            x = layer(x, condition=condition, relative_positions=relative_positions)
+        taps = self.use_long_range_skip and torch.is_grad_enabled() and SKIP_TAPS["on"]
+        for li, layer in enumerate(self.encoder_layers):
+            if taps and li > 0:
+                x, tap = layer(x, condition=condition, relative_positions=relative_positions, want_input_tap=True)
+                if tap is not None:
+                    skips[-1] = tap
+            else:
+                x = layer(x, condition=condition, relative_positions=relative_positions)
             skips.append(x)
         if self.middle_layer is not None:
-            x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
+            if taps and skips:
+                x, tap = self.middle_layer(x, condition=condition, relative_positions=relative_positions, want_input_tap=True)
+                if tap is not None:
+                    skips[-1] = tap
+            else:
+                x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
         for layer in self.decoder_layers:
             skip = skips.pop() if self.use_long_range_skip else None
             x = layer(x, condition=condition, relative_positions=relative_positions, skip=skip)

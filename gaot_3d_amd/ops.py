@@ -468,8 +468,10 @@ def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float, want_bf16: bool = False):
     return y, rstd, yb
 
 
-def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None, defer: bool = False):
-    """``defer``: the weight gradient's partial rows are summed by flush_deferred (see defer_ok)"""
+def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional[Tensor] = None, defer: bool = False,
+                dx_add2: Optional[Tensor] = None):
+    """``defer``: the weight gradient's partial rows are summed by flush_deferred (see defer_ok); ``dx_add`` / ``dx_add2``: gradients
+    that reach x through other consumers (the block's residual; the U-ViT skip tap), added by the same pass"""
     lib = _lib.load()
     d = x.shape[-1]
     rows = x.numel() // d
@@ -478,9 +480,17 @@ def rmsnorm_bwd(x: Tensor, w: Tensor, dy: Tensor, rstd: Tensor, dx_add: Optional
     ws = _ws(lib.gaot_rmsnorm_bwd_workspace_bytes(rows, d), x.device)
     if dx_add is not None:
         dx_add = _req(dx_add, torch.float32, "dx_add")
+    if dx_add2 is not None:
+        dx_add2 = _req(dx_add2, torch.float32, "dx_add2")
+        if dx_add is None:
+            dx_add, dx_add2 = dx_add2, None
     defer = defer and rows > 0
-    check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx), None if defer else _ptr(dw), rows, d,
-                               _ptr(ws), ws.numel(), _stream()), "gaot_rmsnorm_bwd")
+    if dx_add2 is not None:
+        check(lib.gaot_rmsnorm_bwd2(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx_add2), _ptr(dx), None if defer else _ptr(dw),
+                                    rows, d, _ptr(ws), ws.numel(), _stream()), "gaot_rmsnorm_bwd2")
+    else:
+        check(lib.gaot_rmsnorm_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx_add), _ptr(dx), None if defer else _ptr(dw), rows, d,
+                                   _ptr(ws), ws.numel(), _stream()), "gaot_rmsnorm_bwd")
     if defer:
         _defer(ws, dw, d, lib.gaot_rmsnorm_bwd_parts(rows), 32)
     return dx, dw
@@ -672,7 +682,9 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b:
 
 
 def _qscale(scale: float) -> float:
-    return float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
+    """fp32(scale) * fp32(log2 e), rounded once in fp32 (host arithmetic: numpy, not a torch op on the step's path)"""
+    import numpy as np
+    return float(np.float32(scale) * np.float32(1.4426950408889634))
 
 
 def qkv_image_packed(xb: Tensor, wcat: Tensor, rows: int, pos0: int, s_total: int, h: int, hkv: int, freqs: Optional[Tensor],

@@ -236,6 +236,11 @@ size_t gaot_rmsnorm_bwd_workspace_bytes(int64_t rows, int dim);
 int gaot_rmsnorm_bwd(const float* x, const float* weight, const float* dy, const float* rstd, const float* dx_add,
                      float* dx, float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
                      gaot_stream_t stream);
+/* the same with a SECOND gradient reaching x through a third consumer (ABI 11: the U-ViT long-range skip, reference attn.py:282-288:
+ * an encoder block's output feeds the next block and the mirrored decoder block): dx = (dx + dx_add) + dx_add2 */
+int gaot_rmsnorm_bwd2(const float* x, const float* weight, const float* dy, const float* rstd, const float* dx_add,
+                      const float* dx_add2, float* dx, float* dweight, int64_t rows, int dim, void* workspace, size_t workspace_bytes,
+                      gaot_stream_t stream);
 size_t gaot_colsum_workspace_bytes(int64_t M, int64_t N);
 int gaot_colsum(const float* x, int64_t M, int64_t N, int64_t ld, float* out, void* workspace, size_t workspace_bytes,
                 gaot_stream_t stream);

@@ -575,3 +575,36 @@ def test_training_loop_loss_decreases():
     print("[train] losses:", " ".join(f"{v:.4f}" for v in losses[::3]))
     assert all(torch.isfinite(q).all() for q in model.parameters())
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+
+
+def test_skip_taps_and_duplicate_skip_inputs_change_nothing():
+    """Transformer._forward hands the decoder blocks ALIASES of the encoder outputs (RMSNormResFn tap) so that the two gradients of an
+    encoder output meet inside the next block's norm backward kernel (gaot_rmsnorm_bwd2), and CatLinearFn folds the two gradients of a
+    tensor given twice into one GEMM epilogue: no autograd-engine accumulation passes.  a + b == b + a: every gradient must be bit-identical
+    to the plain sharing (reference attn.py:282-288)."""
+    import gaot_3d_amd
+    from gaot_3d_amd.model.layers import attn as A
+    cfg = A.TransformerConfig(num_layers=6, hidden_size=256, use_long_range_skip=True,
+                              attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0),
+                              ffn_config=A.FFNConfig(hidden_size=512))
+    torch.manual_seed(0)
+    net = A.Transformer(256, 256, cfg).to(DEV).train()
+    x = torch.randn(1, 1024, 256, device=DEV, requires_grad=True)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        gaot_3d_amd.set_precision(prec)
+        try:
+            for on in (False, True):
+                A.SKIP_TAPS["on"] = on
+                for p in net.parameters():
+                    p.grad = None
+                x.grad = None
+                y = net(x)
+                y.square().mean().backward()
+                torch.cuda.synchronize()
+                out[(prec, on)] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            A.SKIP_TAPS["on"] = True
+            gaot_3d_amd.set_precision("fp32")
+        for a, b in zip(out[(prec, False)], out[(prec, True)]):
+            assert torch.equal(a, b), f"{prec}: max diff {(a - b).abs().max().item():.3e}"

@@ -574,7 +574,7 @@ def test_rmsnorm_swiglu_rope_patchify_mse():
     try:
         x2 = x.to(DEV).requires_grad_(True)
         w2 = w.to(DEV).requires_grad_(True)
-        y2, xres, yb2 = GF.RMSNormResFn.apply(x2, w2, 1e-6)
+        y2, xres, yb2 = GF.RMSNormResFn.apply(x2, w2, 1e-6, False)
         assert torch.equal(yb2, y2.detach().bfloat16()) and torch.equal(xres, x2.detach())
         gres = gen(300, 256, seed=7).to(DEV)
         ((y2 * g.to(DEV)).sum() + (xres * gres).sum()).backward()
