@@ -296,8 +296,8 @@ def cpu_baseline(mode, layers, k, seed, atten_dropout, points, latent_full, cpu_
     else:
         n, latent = points // 8, (latent_full[0] // 2, latent_full[1] // 2, latent_full[2] // 2)
     # SURVEY 8d asks for the host's own cores.  MEASURED on the pool's 256-thread boxes: the full step on all 256 threads takes
-    # 253.8 s against 28.3 s on 64 (profiles/r5_j_bench_bf16_graph.json), the bounded step 214 s against 5.1 s on 16
-    # (profiles/r5_k_bench_default.json) -- the segmented reductions and the fp32 GEMMs of [16 384, 256] rows do not scale past a
+    # 253.8 s against 28.3 s on 64 (profiles/archive/r5_j_bench_bf16_graph.json), the bounded step 214 s against 5.1 s on 16
+    # (profiles/archive/r5_k_bench_default.json) -- the segmented reductions and the fp32 GEMMs of [16 384, 256] rows do not scale past a
     # socket's worth, oversubscribed they collapse.  So the full-sample step runs on min(os.cpu_count(), 64) threads, the host's
     # thread count and CPU model are named in the line, and --cpu-baseline-all-cores repeats the all-cores measurement on request
     ncpu = os.cpu_count() or 1
@@ -804,10 +804,30 @@ def main(argv=None):
             # the reference's own arithmetic is fp32 end to end: the same step on the exact-fp32 MFMA kernels
             try:
                 gaot_3d_amd.set_precision("fp32")
-                k3 = max(2, min(args.steps, 3))
+                k3 = max(2, min(args.steps, 10))
                 e3, g3, _, _ = measure(step, k3, 1, use_graph)
-                fp32_mode = dict(ms_per_step=e3 / k3 * 1e3, value=n_total / (e3 / k3), dtype="f32", steps=k3)
+                fp32_mode = dict(ms_per_step=e3 / k3 * 1e3, value=n_total / (e3 / k3), dtype="f32", steps=k3,
+                                 ms_per_step_median=round(statistics.median(last_step_ms), 3) if last_step_ms else None,
+                                 launch="hipGraph replay of one captured step" if g3 is not None else "eager")
                 del g3
+                # the reference's own arithmetic as a measured mode: HIP events around the instrumented launches of
+                # two eager fp32 steps -> the dominant kernel against the fp32 matrix peak (157.3 TF/s, MI355X_MICROARCH.md)
+                ops.timing_reset(True)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t32 = ops.timing_summary()
+                ops.timing_reset(False)
+                w32 = algorithmic_work(n_total // world, m_lat, edge_counts["enc"], edge_counts["dec"], s_tok, args.layers)
+                k32 = {nm: dict(avg_ms=round(tot / c, 4), calls_per_step=c / 2, total_ms_per_step=round(tot / 2, 4),
+                                tflops=round(w32[nm]["flops"] / (tot / c * 1e-3) / 1e12, 2)) for nm, (c, tot) in t32.items() if nm in w32 and c}
+                if k32:
+                    dom32 = max(k32, key=lambda nm: k32[nm]["total_ms_per_step"])
+                    fp32_mode["roofline_fp32"] = dict(kernel=dom32, bound="mfma", achieved=k32[dom32]["tflops"], peak=157.3, unit="TFLOP/s",
+                                                      frac=round(k32[dom32]["tflops"] / 157.3, 4), avg_ms=k32[dom32]["avg_ms"], traffic=None)
+                    fp32_mode["kernels"] = k32
+                    tr32 = step_roofline_ms(n_total // world, m_lat, edge_counts["enc"], edge_counts["dec"], s_tok, args.layers, "fp32", out=wl_out)
+                    fp32_mode["step_roofline"] = dict(t_roof_ms=round(tr32["t_roof_ms"], 3), frac=round(tr32["t_roof_ms"] / fp32_mode["ms_per_step"], 4))
             except Exception as ex:
                 fp32_mode = dict(error=f"{type(ex).__name__}: {ex}")
             finally:

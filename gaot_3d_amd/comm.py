@@ -218,7 +218,7 @@ class SegmentedGraph:
         # needed, and every rank skips the same closures (no rank waits for another).  Running it would enqueue RCCL work
         # while captures begin and end on this stream, and the process group's watchdog thread polls that work's events
         # from the side: about one recording in thirty then died with hipErrorCapturedEvent ("event last recorded in a
-        # capturing stream") raised in the watchdog (profiles/r3_o_rccl_watchdog_abort.txt).
+        # capturing stream") raised in the watchdog (profiles/archive/r3_o_rccl_watchdog_abort.txt).
         self._end(fn, keep, kind)
         self._begin()
 

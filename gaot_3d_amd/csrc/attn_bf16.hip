@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         }
     };
     // priority between the two waves of a SIMD: s_setprio flips around the S / dP MFMA cluster of every tile, both waves alike
-    // (measured and removed, profiles/r4_b / r4_e / r4_h: static priority for either half of the waves, priority for one half
+    // (measured and removed, profiles/archive/r4_b / r4_e / r4_h: static priority for either half of the waves, priority for one half
     // inside its MFMA clusters only, one half a level higher throughout, no priority at all: within +-1.5 % at compile time;
     // RUN-TIME-conditional s_setprio splits the basic blocks around the clusters and changed the dropout kernel's schedule by
     // +30 %: the flips around the S / dP cluster are unconditional)
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(64 * FB_WAVES, FB_WAVES == 8 ? 1 : (FB_KB >= 4 ? 1 
         bf16_t* part = fa.dqpart + (((int64_t)b * a.H + head) * fa.nslab + slab) * (int64_t)a.S * D;
         // the stage's Q / dO rows through buffer resources of this (batch, head): one 32-bit lane offset per load and a scalar row
         // offset instead of 64-bit lane addresses (they were spilled: the kernel then needs scratch, and a scratch kernel costs
-        // ~10 us of idle queue on either side of its launch -- profiles/r4_q_gaps.txt); rows past S read as zeros in hardware
+        // ~10 us of idle queue on either side of its launch -- profiles/archive/r4_q_gaps.txt); rows past S read as zeros in hardware
         const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((int64_t)a.S * a.ld * 2), 0x00020000);
         const __amdgpu_buffer_rsrc_t do_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dop, 0, (int)((int64_t)a.S * a.H * D * 2), 0x00020000);
         const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc((void*)lsep, 0, a.S * 4, 0x00020000);
@@ -2170,16 +2170,16 @@ extern "C" int gaot_attn_fwd_bf16(const float* qkv, const float* rope_freqs, voi
     // (dropout, S = 16 384, 8 heads: <3,4> 0.550 ms, <4,4> 0.66 ms with 144 B of scratch; before that path <4,4> 0.577 ms)
     // bound-based kernel (128 registers: 4 workgroups per CU), then the adaptive one for the workgroups it flagged
     // (schedule pins inside the forward's tile -- start of tile / after the exp stream / before the P V products -- were
-    // measured: +-0.5 %, profiles/r4_g_attn_lab.txt; the template parameter stays at 0)
+    // measured: +-0.5 %, profiles/archive/r4_g_attn_lab.txt; the template parameter stays at 0)
     // (a keep-bit image -- the forward also writing one 32-bit word of keep bits per (query, 32-key tile) for the backward to read
-    // through scalar loads -- measured as its two halves, profiles/r4_w_keep_bit_image_lab.txt: WRITING the words (8 and-or steps,
+    // through scalar loads -- measured as its two halves, profiles/archive/r4_w_keep_bit_image_lab.txt: WRITING the words (8 and-or steps,
     // one cross-half combine, one 128-byte store per wave and tile) costs the forward 0.516 -> 0.599 ms; the backward with its masks
     // for FREE (no xor, no compares, selects kept) gains 0.834 -> 0.810 ms at most.  Not built.)
     // (K / V stages by LDS-DMA into two stage buffers -- no register staging, no ds_write, ONE barrier per 128 keys, 103 instead
     // of 112 registers -- measured 0.538 / 0.431 ms against 0.524 / 0.424 with / without dropout: the staging is not what the
-    // forward waits on; profiles/r4_t_attn_fwd_dma_lab.txt; removed)
+    // forward waits on; profiles/archive/r4_t_attn_fwd_dma_lab.txt; removed)
     // row sums of the bound-based tile: with dropout one v_dot2c_f32_bf16 per pair of the packed p (-2 %: 0.524 -> 0.514 ms per layer,
-    // profiles/r5_l_attn_fwd_rowsum_lab.txt), without dropout the 16 fp32 adds (no difference measured there).
+    // profiles/archive/r5_l_attn_fwd_rowsum_lab.txt), without dropout the 16 fp32 adds (no difference measured there).
     // GAOT_ATTN_FWD_LAB = 1 / 8 forces the adds / the dot products for both (measurement only).
     static const int fwd_lab = [] { const char* e = getenv("GAOT_ATTN_FWD_LAB"); return e ? atoi(e) : 0; }();
     const bool dot2 = fwd_lab == 8 || (fwd_lab != 1 && a.drop.thr);
@@ -2285,7 +2285,7 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             static const int variant = [] { const char* e = getenv("GAOT_ATTN_BWD_VARIANT"); return e ? atoi(e) : 0; }();
             int rc;
             // k_attn_bwd_asm (one wave per SIMD, hand-scheduled tile loop, dS transposed on the matrix pipe with dropout / through LDS
-            // without) is the default for whole-sequence launches: same box, S = 16 384, H = 8 (profiles/r5_d_attn_bwd_asm_mfma_t2.txt):
+            // without) is the default for whole-sequence launches: same box, S = 16 384, H = 8 (profiles/archive/r5_d_attn_bwd_asm_mfma_t2.txt):
             // 0.798 against 0.836 ms with dropout (-4.5 %), 0.669 against 0.717 ms without (-6.7 %); dK / dV bit-identical to the compiled
             // kernel, dQ within 5e-5 of peak (four slots of four key blocks instead of eight of two).  Few heads per launch: query-range
             // parts as in the compiled kernel (ranges that are multiples of 128 queries; others keep the compiled kernel).  GAOT_ATTN_BWD_VARIANT=2 forces the asm kernel, =3 the compiled one.
@@ -2295,10 +2295,10 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
                 else if (lab == 3) rc = drop ? go(k_attn_bwd_asm<true, 3>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false, 3>, AsmLds<false>::TOTAL, 256);
                 else rc = drop ? go(k_attn_bwd_asm<true>, AsmLds<true>::TOTAL, 256) : go(k_attn_bwd_asm<false>, AsmLds<false>::TOTAL, 256);
             }
-            else if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/r4_b_attn_bwd_lab.txt)
+            else if (variant == 1)       // one wave per SIMD, compiler-managed 512 registers: 1.9 / 1.27 ms (profiles/archive/r4_b_attn_bwd_lab.txt)
                 rc = drop ? go(k_attn_bwd_fused<true, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256) : go(k_attn_bwd_fused<false, 4, 4, 2>, FusedLds<4, 4, 2>::TOTAL, 256);
             // (128-query stages with bf16 slots -- FB_NT = 4 -- measured 1.07 / 0.81 ms against 0.90 / 0.76: spills in the
-            // dropout variant, profiles/r4_g_attn_lab.txt; removed)
+            // dropout variant, profiles/archive/r4_g_attn_lab.txt; removed)
             else if (variant == 7 && drop)   // round-3 mask arithmetic (row words per query, xor + compare per element)
                 rc = go(k_attn_bwd_fused<true, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             else if (want_stamps && drop) {    // diagnostic build: cycles per phase of the PK kernel, printed to stderr
@@ -2327,14 +2327,14 @@ extern "C" int gaot_attn_bwd_bf16(const void* qkv_image, const float* o, const f
             else if (lab == 100)      // no schedule pins (the round-3 / r4_d schedule)
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 0>, FusedLds<8, 2, 2>::TOTAL, 512);
             // (compile-time priority variants on the pinned schedule -- waves >= W/2 one level higher, static priority without
-            // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/r4_h_attn_bwd_prio_stamps.txt)
+            // flips, no priority at all -- measured within +-1.5 % of the flips: profiles/archive/r4_h_attn_bwd_prio_stamps.txt)
             // (double-buffered stage tiles filled by the first half of the waves before the stage barrier -- to use their 17 % of
-            // barrier idle time -- measured 0.97 / 0.795 ms against 0.89 / 0.786: profiles/r4_i_attn_bwd_double_buffer_lab.txt; removed)
+            // barrier idle time -- measured 0.97 / 0.795 ms against 0.89 / 0.786: profiles/archive/r4_i_attn_bwd_double_buffer_lab.txt; removed)
             // (the mask stream of a register group -- 4 xor, 8 exp, 8 SDWA compares, 16 selects, 8 multiplies -- as ONE asm statement,
             // which removes the s_nop the compiler puts behind every asm boundary (60 per stage): 0.856 -> 0.969 ms, exp-first order or
-            // not; the nops are not what the stream waits on -- profiles/r4_o_attn_bwd_asm_group_lab.txt; removed)
+            // not; the nops are not what the stream waits on -- profiles/archive/r4_o_attn_bwd_asm_group_lab.txt; removed)
             // (all S products before the dP products, with and without a pin behind the cluster, and a pin after the dV / dK block:
-            // within +-1 % -- profiles/r4_k_attn_bwd_cluster_order_lab.txt)
+            // within +-1 % -- profiles/archive/r4_k_attn_bwd_cluster_order_lab.txt)
             else                      // shipped: schedule pinned at the top of a tile, after the exp / mask stream and after the dQ products
                 rc = drop ? go(k_attn_bwd_fused<true, 8, 2, 2, true, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512) : go(k_attn_bwd_fused<false, 8, 2, 2, false, 0, 26>, FusedLds<8, 2, 2>::TOTAL, 512);
             if (rc != GAOT_OK) return rc;

@@ -248,7 +248,7 @@ int csr_build_t(const IDX* edge_index, int64_t E, int sort_row, int64_t Q, int32
     int* tscan = table + tn + 1;            // [tn + 1]
     int* bsum = tscan + tn + 1;             // [nbt + 1]
     // (a kernel, not hipMemsetAsync: in a replayed hipGraph a memset node costs ~10 us of idle queue on either side of it --
-    // profiles/r4_q_graph_replay_gaps.txt)
+    // profiles/archive/r4_q_graph_replay_gaps.txt)
     GAOT_KLAUNCH(k_zero_flags, dim3(1), dim3(64), 0, st, flags, 4);
     if (E == 0) {
         (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(Q + 1), st);

@@ -444,7 +444,7 @@ int gaot_gemm_bf16_dispatch(const void* A, const void* B, void* C, float* preact
     if (!a_ks && !b_ks && dt == 3 && splits <= 1 && !bias && !preact && act == 0 &&
         gaot_gemm_tn_n256_applicable(A, B, C, residual, M, N, K, lda, ldb, ldc, ldr))
         return gaot_gemm_tn_n256_launch(A, B, (float*)C, residual, M, K, lda, ldb, ldc, ldr, st);
-    // (measured and removed, round 4, profiles/r4_p_wgrad_streamed_operand_lab.txt: a weight-gradient kernel with 128 x 128 tiles whose
+    // (measured and removed, round 4, profiles/archive/r4_p_wgrad_streamed_operand_lab.txt: a weight-gradient kernel with 128 x 128 tiles whose
     // token-major bf16 operands stream by LDS-DMA through a ring of 3-4 stage buffers (source-side XOR swizzle for the transposed
     // reads) -- 60 / 56 us against 52 us for the register-staged kernel below on w1|w3 with operands from HBM; its DMA alone
     // takes 38 us (2.3 TB/s: 64-96 KB in flight per CU is all an LDS ring can hold) and one wave per SIMD does not overlap

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k256(const bf16_t* __restrict__
                     const float sc = head < im.nq ? im.qscale : 1.0f;
                     const int mm = m < M ? m : M - 1;
                     // (a buffer resource + one 32-bit offset: the 64-bit row pointer cost the two registers this mode spilled, and a
-                    // kernel that needs scratch pays ~5 us of idle queue on either side of every launch -- profiles/r4_q_gaps.txt)
+                    // kernel that needs scratch pays ~5 us of idle queue on either side of every launch -- profiles/archive/r4_q_gaps.txt)
                     const int toff = (mm % im.S) * 128 + 16 * hf;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

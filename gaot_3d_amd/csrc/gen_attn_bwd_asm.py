@@ -18,7 +18,7 @@ it moved every MFMA result through AGPR copies and spilled) is done by hand here
   * every LDS read is issued a unit (or a tile) ahead of its use and waited for by COUNT (s_waitcnt lgkmcnt(n), computed here).
 The stage code around the tile loop (global loads, LDS staging, slot reduction, barriers) stays C++.
 
-Measured (MI355X, S = 16 384, H = 8, profiles/r5_b ... r5_e, r5_d_*mfma_t*): the loop runs at its instruction-issue time (562
+Measured (MI355X, S = 16 384, H = 8, profiles/archive/r5_b ... r5_e, r5_d_*mfma_t*): the loop runs at its instruction-issue time (562
 cycles per unit without its LDS instructions = 104 vector instructions + 10 MFMAs to the cycle; an LDS instruction costs ~13
 more on the same port), which is why the transpose moved to the matrix pipe under dropout.
 
@@ -37,10 +37,10 @@ TILE = 2048
 # (B operand of dQ^T): "mfma" = TWO MORE MFMAs against a permutation ("identity") fragment -- the accumulator as the A operand
 # [key][query] times I[query][query'] comes out with the query on the lane, exactly (products with 1.0 / 0.0), then 8 cvt_pk;
 # "lds" = through a wave-private LDS tile (4 ds_write_b64 + 4 ds_read_b64_tr_b16 per unit).  LDS instructions cost ~13 issue
-# cycles each on the port the vector stream needs (profiles/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
+# cycles each on the port the vector stream needs (profiles/archive/r5_e): the MFMA form trades 8 of a unit's 15 for 2 MFMAs + 8 packs.
 TR_DROP = os.environ.get("GEN_TR_DROP", "mfma")       # measured: 0.854 (mfma) against 0.896 ms for the compiled kernel on one box, lds 0.838 / 0.843
 ORDER = os.environ.get("GEN_ORDER", "depth")      # the unit's vector stream: "depth" (pair by pair; shipped) | "breadth" (two pairs at a time, kind by kind, in
-                                                   # place: measured 0.8166 / 0.8188 against 0.8185 / 0.8179 ms, profiles/r5_ag -- nothing; the forward's loop gained 4 % from it)
+                                                   # place: measured 0.8166 / 0.8188 against 0.8185 / 0.8179 ms, profiles/archive/r5_ag -- nothing; the forward's loop gained 4 % from it)
 DS_FORM = os.environ.get("GEN_DS", "fmac")           # dropout: dS = p (-delta') + (keep p) dP' (mul + fmac) | "select": p select(keep, dP' - delta', -delta') (measurement builds)
 TR_NODROP = os.environ.get("GEN_TR_NODROP", "lds")   # without dropout the unit is MFMA bound: 12 MFMAs cost more than the LDS round trip (0.726 against 0.684 ms)
 

@@ -30,7 +30,7 @@ MFMA = "v_mfma_f32_32x32x16_bf16"
 # row sums l[q] = sum_k p[q][k] of the (undropped, packed) p: "dot2" = 8 v_dot2c_f32_bf16 per unit into two chains per query tile (in / out
 # operands of the statement), "mfma" = two more MFMAs per unit against a fragment of ones into a second accumulator per query tile
 # (a96-a159: every row of it is the row sum) -- 16 issue cycles instead of 32-68 (the dot products pay 8.5 cycles beside an MFMA)
-LSUM = os.environ.get("GEN_FWD_LSUM", "dot2")   # measured (profiles/r5_aa): mfma 0.4277 ms against 0.4190 for dot2 (compiled kernel 0.507):
+LSUM = os.environ.get("GEN_FWD_LSUM", "dot2")   # measured (profiles/archive/r5_aa): mfma 0.4277 ms against 0.4190 for dot2 (compiled kernel 0.507):
                                                 # the two extra MFMAs cost more (clock) than the eight dot products they replace
 
 V0 = 48
@@ -123,7 +123,7 @@ def gen_stage(drop: bool):
     #   S(u+1) k-steps 0, 1 between the exponentials (64 cycles apart: the second accumulates into the first; the other score buffer's
     #   last reader was the previous unit's last pack; the result is read by the next unit's first v_exp_f32, >= 20 instructions on);
     #   PV(u-1) k-step 0 in front of the packs; k-step 1 (same accumulator: a dependent MFMA issued less than ~64 cycles behind its
-    #   predecessor stalls the wave -- the loop without vector instructions runs at 60 cycles per MFMA, profiles/r5_ac) BEHIND the
+    #   predecessor stalls the wave -- the loop without vector instructions runs at 60 cycles per MFMA, profiles/archive/r5_ac) BEHIND the
     #   row-sum block: v_dot2c_f32_bf16 costs 8.5 instead of 4 cycles while the matrix pipe runs (tools/lab/inst_cost.hip), so that
     #   block stays clear of the MFMAs' 32 cycles.
     if LSUM == "mfma":

@@ -302,7 +302,7 @@ template <int NH>
 int launch_fwd_b(const MlpPtrs& p, const float* y_pos, const float* x_pos, const float* f_y, const int* src_s,
                  const int* dst_s, const int* rowptr, int64_t E, float* out, float* part, hipStream_t st) {
     // Shipped: 12 waves per workgroup (one weight image per CU, THREE waves per SIMD; 127 KB of LDS at three hidden layers) with the
-    // id / coordinate loads pipelined.  Measured at E = 4 M (profiles/r5_w_gno_fwd_variants_lab.txt; nh = 3 / 2 / 4): round-4 form
+    // id / coordinate loads pipelined.  Measured at E = 4 M (profiles/archive/r5_w_gno_fwd_variants_lab.txt; nh = 3 / 2 / 4): round-4 form
     // 0.402 / 0.317 / 0.466 ms, 4 waves + full pipeline 0.390 / 0.300 / 0.435, 12 waves + id pipeline 0.377 / 0.277 / 0.421,
     // 12 waves alone 0.377 / 0.279 / 0.427.  GAOT_GNO_FWD_VARIANT (measurement only) = 0: 4 waves, no pipeline | 1: 4 waves, ids +
     // coordinates + f rows pipelined | 2: the shipped form | 3: 12 waves, no pipeline

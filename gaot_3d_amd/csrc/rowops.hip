@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const copy_f4* __restrict__
     }
 }
 
-static int stream_copy_variant = 9;    // the fastest measured on MI355X: 6.05-6.08 TB/s at 1 GiB (profiles/r5_b_stream_copy_lab.txt)
+static int stream_copy_variant = 9;    // the fastest measured on MI355X: 6.05-6.08 TB/s at 1 GiB (profiles/archive/r5_b_stream_copy_lab.txt)
 
 extern "C" int gaot_stream_copy_ex(const void* src, void* dst, int64_t bytes, int variant, gaot_stream_t stream) {
     GAOT_ENTER();

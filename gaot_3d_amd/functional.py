@@ -627,7 +627,7 @@ class FFNFn(Function):
                 # measurement only (GAOT_FFN_BWD_FUSED=1): the SwiGLU backward in that product's epilogue (gaot_ffn_w2_bwd_swiglu: du
                 # never reaches HBM).  Built, bit-compatible, and SLOWER: 54.9 us against 22.8 + 24.8 us at [16 384, 1024] -- a lane
                 # of the transposed product owns a row, so the epilogue's reads of a | g touch 32 rows per instruction where the
-                # stand-alone pass streams at 6.7 TB/s (profiles/r5_t_ffn_bwd_fusion_lab.txt); the step: 21.98 against 21.93 ms
+                # stand-alone pass streams at 6.7 TB/s (profiles/archive/r5_t_ffn_bwd_fusion_lab.txt); the step: 21.98 against 21.93 ms
                 dag = ops.ffn_w2_bwd_swiglu(dyb, w2t if w2t.numel() else w2c.t().contiguous(), ag, f)
             else:
                 du = ops.gemm(dyb, w2t if w2t.numel() else w2c.t().contiguous(), m, f, d, d, d, False, True, precision=1,

@@ -680,7 +680,7 @@ class ShardedStep:
         ``overlap_grads=False``: one flat all-reduce after backward instead of buckets launched from gradient hooks.
         ``overlap_dw=True``: the weight-gradient GEMMs (and the bucket copies / all-reduces that follow them) run on a side
         stream beside the backward chain and its exchange steps, joined once before the step returns (``comm.side_run``);
-        measured SLOWER on one GPU (no idle CUs beside the chain: profiles/r4_u), meant for N > 1 where the chain waits in
+        measured SLOWER on one GPU (no idle CUs beside the chain: profiles/archive/r4_u), meant for N > 1 where the chain waits in
         exchange steps -- ``bench.py --gpus N`` times both settings."""
         self.model = model
         self.group = group

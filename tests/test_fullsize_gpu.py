@@ -342,11 +342,11 @@ def test_configs2_sample_point_sharded_two_ranks_one_gpu(sample, tmp_path):
         assert k in got["norms"], k
         rel = abs(got["norms"][k] - float(ref.norm())) / (float(ref.norm()) + 1e-30)
         worst = max(worst, rel)
-        assert rel <= 2e-2, (k, got["norms"][k], float(ref.norm()))         # achieved 6.4e-3 without dropout (profiles/r3_c)
+        assert rel <= 2e-2, (k, got["norms"][k], float(ref.norm()))         # achieved 6.4e-3 without dropout (profiles/archive/r3_c)
         head = torch.tensor(got["grads"][k], dtype=torch.float64)
         hd = float((head - ref.flatten()[:64]).abs().max()) / (float(ref.abs().max()) + 1e-30)
         worst_head = max(worst_head, hd)
-        assert hd <= 1e-2, (k, hd)                                           # achieved 2.4e-3 (profiles/r5_a_parity.txt)
+        assert hd <= 1e-2, (k, hd)                                           # achieved 2.4e-3 (profiles/archive/r5_a_parity.txt)
         n += 1
     print(f"[parity] configs2_2rank (dropout 0.1): {n} gradient tensors, worst norm deviation {worst:.2e}, worst leading value {worst_head:.2e} of peak")
     assert n > 100

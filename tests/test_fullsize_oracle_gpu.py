@@ -13,7 +13,7 @@
 
 Tolerances: fp32 kernels rtol 1e-4 / atol 1e-5-of-peak on outputs, rtol 1e-3 on gradients; bf16 kernels
 max-abs <= 1e-2 of the reference's peak on outputs, cosine >= 0.999 and max-abs <= 1e-2 / 2e-2 of peak on gradients (<= 3 x the
-achieved errors of profiles/r4_ad_parity.txt: a 5 x regression fails)."""
+achieved errors of profiles/archive/r4_ad_parity.txt: a 5 x regression fails)."""
 import math
 import os
 import sys
@@ -460,7 +460,7 @@ def _fullsize_oracle_skip_reason():
     cores = os.cpu_count() or 1
     if ram < 110 or cores < 24:
         return (f"whole-step oracle needs >= 110 GB of free host memory and >= 24 cores, this host has {ram:.0f} GB / {cores}; "
-                f"recorded result: profiles/r2_l_parity_fullsize_model_vs_oracle.txt")
+                f"recorded result: profiles/archive/r2_l_parity_fullsize_model_vs_oracle.txt")
     return None
 
 
@@ -522,7 +522,7 @@ def test_model_full_size_vs_oracle():
             PAR.close("fullsize_vs_oracle_fp32/loss", loss, loss_r, 1e-5, 0.0)
             PAR.grads_cosine("fullsize_vs_oracle_fp32/grads", grads, grads_r, 0.99999, per_tensor=0.9999)
         else:
-            # achieved (profiles/r4_ad_parity.txt): pred 3.2e-3 of peak, rel_l2 1.4e-3, loss 2.3e-3, gradient cosine 0.999991
+            # achieved (profiles/archive/r4_ad_parity.txt): pred 3.2e-3 of peak, rel_l2 1.4e-3, loss 2.3e-3, gradient cosine 0.999991
             PAR.close_peak("fullsize_vs_oracle_bf16/pred", pred, pred_r, 1e-2, rel_l2=5e-3)
             PAR.close("fullsize_vs_oracle_bf16/loss", loss, loss_r, 7e-3, 0.0)
             PAR.grads_cosine("fullsize_vs_oracle_bf16/grads", grads, grads_r, 0.9999, per_tensor=0.99)
