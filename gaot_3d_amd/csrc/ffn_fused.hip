@@ -105,10 +105,16 @@ __global__ void k_ffn_pack(PackTable t, int F, int with_backward) {
 // ---- forward ------------------------------------------------------------------------------------------------------------------------
 // X [M][256] bf16 (the normalised h RMSNorm wrote), R [M][ldr] fp32 residual or null, Y [M][256] fp32, AG [M][2F] bf16 (a | g),
 // U [M][F] bf16.  SAVE = false: a | g and u are not written (inference / a backward that recomputes them).
-template <bool SAVE, int RD>
+// NORM (gaot_norm_ffn_fwd): the block's RMSNorm in front of the FFN (reference attn.py:227-229: h = ffn_norm(h); h + ffn(h)) computed
+// HERE from the fp32 rows -- X is not read; R = the un-normalised rows [M][ldr], NW the norm weight: a wave normalises its 16 rows with
+// the arithmetic of k_rmsnorm_fwd (one wave per row, a lane per float4, the same butterfly), writes them to the LDS tile and to YB (bf16
+// [M][256]: the backward's input and the dW13 product's operand) and their 1/rms to RSTD; the residual added at the end is the
+// normalised row, recomputed from R.  The stand-alone norm pass (a read and two writes of [M][256]) is gone.
+template <bool SAVE, int RD, bool NORM = false>
 __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X, const u32x4* __restrict__ W13p,
                                                      const u32x4* __restrict__ W2p, const float* __restrict__ R, float* __restrict__ Y,
-                                                     bf16_t* __restrict__ AG, bf16_t* __restrict__ U, int M, int F, int ldr) {
+                                                     bf16_t* __restrict__ AG, bf16_t* __restrict__ U, int M, int F, int ldr,
+                                                     const float* __restrict__ NW, float eps, bf16_t* __restrict__ YB, float* __restrict__ RSTD) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous range of row blocks (the a | g / u / y rows one
@@ -171,8 +177,48 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
     }
     if (GAOT_FFN_ABL & 1) { wload(wr[LA % RD], 0, 0); wfirst = false; }
 
-    // the activation tile by LDS-DMA: piece q = wave*8 + i fills tile rows 2q, 2q+1; slot s of row r holds source chunk s ^ (r & 15)
-    {
+    float* rstd_l = reinterpret_cast<float*>(lds + H_BYTES + 2 * U_BYTES + (SAVE ? 2 * AG_BYTES : 0));      // NORM: 64 floats
+    if constexpr (NORM) {
+        // rows 16 wave .. + 15 of the block, a lane per float4 (the arithmetic and summation order of k_rmsnorm_fwd, rowops.hip)
+        const int64_t rbytes = (int64_t)M * ldr * 4, ybbytes = (int64_t)M * D * 2;
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)YB, 0, (int)(ybbytes > 0x7fffffff ? 0x7fffffff : ybbytes), 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(NW)[lane];
+        float4 v[16];
+        float ss[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = m0 + wave * 16 + j;
+            v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, m < M ? (unsigned)m * (unsigned)ldr * 4u + lane * 16u : 0x80000000u, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            ss[j] = 0.f;
+            ss[j] += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ss[j] += __shfl_xor(ss[j], o, 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rl = wave * 16 + j, m = m0 + rl;
+            const float r = rsqrtf(ss[j] / (float)D + eps);
+            const float4 o = make_float4(v[j].x * r * g.x, v[j].y * r * g.y, v[j].z * r * g.z, v[j].w * r * g.w);
+            const u32x4 dummy = {0, 0, 0, 0};
+            (void)dummy;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 pk = {pack2(o.x, o.y), pack2(o.z, o.w)};
+            // tile: row rl, 8-byte half (lane & 1) of the 16-byte chunk lane >> 1, chunk stored at slot chunk ^ (rl & 15)
+            *reinterpret_cast<u32x2*>(lds + rl * 512 + ((((lane >> 1) ^ (rl & 15))) << 4) + 8 * (lane & 1)) = pk;
+            __builtin_amdgcn_raw_buffer_store_b64(pk, ybrs, m < M ? (unsigned)m * (unsigned)D * 2u + lane * 8u : 0x80000000u, 0, 0);
+            if (lane == 0) {
+                rstd_l[rl] = r;
+                if (m < M) RSTD[m] = r;
+            }
+        }
+    } else {
+        // the activation tile by LDS-DMA: piece q = wave*8 + i fills tile rows 2q, 2q+1; slot s of row r holds source chunk s ^ (r & 15)
         const int lh = lane >> 5;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -388,7 +434,14 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {y[jt][i][4 * q], y[jt][i][4 * q + 1], y[jt][i][4 * q + 2], y[jt][i][4 * q + 3]};
-                v += rres[i][jt][q];
+                if constexpr (NORM) {       // the residual is the normalised row: (h r) w, as k_rmsnorm_fwd forms it
+                    const float r = rstd_l[32 * i + l31];
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(NW + wave * 64 + 32 * jt + 8 * q + 4 * hf);
+                    const f32x4 hv = rres[i][jt][q];
+                    v += f32x4{hv[0] * r * g[0], hv[1] * r * g[1], hv[2] * r * g[2], hv[3] * r * g[3]};
+                } else {
+                    v += rres[i][jt][q];
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, rowoff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0);
             }
     }
@@ -401,25 +454,25 @@ constexpr int FWD_LDS = H_BYTES + 2 * U_BYTES, FWD_LDS_SAVE = FWD_LDS + 2 * AG_B
 #endif
 constexpr int FWD_RING = GAOT_FFN_FWD_RING;
 
-template <bool SAVE>
+template <bool SAVE, bool NORM>
 int launch_ffn_fwd(const void* x, const void* w13p, const void* w2p, const float* r, float* y, void* ag, void* u, int M, int F, int ldr,
-                   hipStream_t st) {
-    auto kern = k_ffn_fwd<SAVE, FWD_RING>;
+                   const float* nw, float eps, void* yb, float* rstd, hipStream_t st) {
+    auto kern = k_ffn_fwd<SAVE, FWD_RING, NORM>;
+    constexpr int LDS = (SAVE ? FWD_LDS_SAVE : FWD_LDS) + (NORM ? 256 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SAVE ? FWD_LDS_SAVE : FWD_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
-            gaot_set_error("ffn_fwd: cannot set dynamic LDS %d: %s", SAVE ? FWD_LDS_SAVE : FWD_LDS, hipGetErrorString(e));
+            gaot_set_error("ffn_fwd: cannot set dynamic LDS %d: %s", LDS, hipGetErrorString(e));
             return GAOT_ERR_LAUNCH;
         }
         attr_set = true;
     }
     const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
-    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), SAVE ? FWD_LDS_SAVE : FWD_LDS, st, (const bf16_t*)x, (const u32x4*)w13p, (const u32x4*)w2p, r, y,
-                 (bf16_t*)ag, (bf16_t*)u, M, F, ldr);
+    GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), LDS, st, (const bf16_t*)x, (const u32x4*)w13p, (const u32x4*)w2p, r, y,
+                 (bf16_t*)ag, (bf16_t*)u, M, F, ldr, nw, eps, (bf16_t*)yb, rstd);
     return GAOT_OK;
 }
-
 
 // ---- backward ---------------------------------------------------------------------------------------------------------------------------
 // The backward's first half as one launch: a | g RECOMPUTED from the saved normalised input (the forward then writes neither a | g nor
@@ -1034,8 +1087,8 @@ extern "C" int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float*
     const bf16_t* p = (const bf16_t*)packed;
     const void* w13p = p;
     const void* w2p = p + (int64_t)2 * F * D;
-    const int rc = ag ? launch_ffn_fwd<true>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, (hipStream_t)stream)
-                      : launch_ffn_fwd<false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, (hipStream_t)stream);
+    const int rc = ag ? launch_ffn_fwd<true, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, nullptr, 0.f, nullptr, nullptr, (hipStream_t)stream)
+                      : launch_ffn_fwd<false, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, nullptr, 0.f, nullptr, nullptr, (hipStream_t)stream);
     if (rc != GAOT_OK) return rc;
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -1091,6 +1144,28 @@ extern "C" int gaot_ffn_bwd(const void* x_bf16, const float* dy, const void* pac
     const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
     GAOT_KLAUNCH(k_ffn_bwd_dx, dim3((unsigned)(8 * per)), dim3(256), BWDX_LDS, (hipStream_t)stream, (const bf16_t*)x_bf16, dy, (const u32x4*)p,
                  (const u32x4*)w2tp, (const u32x4*)w13tp, (bf16_t*)dag, (bf16_t*)u, (bf16_t*)dyb, dx, (int)rows, F, add_dy);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// RMSNorm + FFN + residual of a Transformer block in ONE launch (reference attn.py:227-229: h = ffn_norm(h); h + ffn(h) -- the residual
+// is the NORMALISED h): h fp32 [rows][ldh], norm_weight fp32 [256] -> y fp32 [rows][256] = n + w2(silu(w1 n) * w3 n) with n = RMSNorm(h);
+// yb = bf16(n) ([rows][256]: the backward's input) and rstd [rows] are written for the backward (gaot_ffn_bwd, then gaot_rmsnorm_bwd on
+// its dx); nothing else is saved.  Values: those of gaot_rmsnorm_fwd followed by gaot_ffn_fwd(residual = its fp32 output).
+extern "C" int gaot_norm_ffn_fwd(const float* h, int64_t ldh, const float* norm_weight, float eps, const void* packed, float* y, void* yb,
+                                 float* rstd, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(h && norm_weight && packed && y && yb && rstd && rows > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG(((uintptr_t)h % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)yb % 16) == 0 &&
+                   ((uintptr_t)norm_weight % 16) == 0 && ldh % 4 == 0 && ldh >= D, "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff || rows * ldh * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_norm_ffn_fwd: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const int rc = launch_ffn_fwd<false, true>(nullptr, p, p + (int64_t)2 * F * D, h, y, nullptr, nullptr, (int)rows, F, (int)ldh, norm_weight, eps, yb,
+                                               rstd, (hipStream_t)stream);
+    if (rc != GAOT_OK) return rc;
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

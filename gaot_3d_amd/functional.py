@@ -62,6 +62,7 @@ def precast_weights(mats, transposed=()) -> None:
 # Transformer (prepack_ffn) and valid until release_precast(): keyed by (address, shape) of the co-located fp32 [w1; w3]
 _FFN_PACK_CACHE: dict = {}
 _FFN_FUSED = os.environ.get("GAOT_FFN_FUSED", "1") != "0"
+_NORM_FFN = os.environ.get("GAOT_NORM_FFN", "1") != "0"        # the block's ffn_norm inside the fused FFN forward (A/B switch)
 _FFN_BWD_DX = os.environ.get("GAOT_FFN_BWD_DX", "1") != "0"      # the input gradient inside the fused backward launch (A/B switch)
 
 
@@ -651,6 +652,53 @@ class FFNFn(Function):
         dwcat = _dw_gemm(dag, x2, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
         dres = dy2.view(rshape) if (rshape is not None and ctx.needs_input_grad[4]) else None
         return dx, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, dres, None
+
+
+class NormFFNFn(Function):
+    """RMSNorm -> FFN -> + the normalised input: the second half of a Transformer block (reference attn.py:227-229:
+    ``h = ffn_norm(h); h + ffn(h)``) as ONE forward launch (csrc/ffn_fused.hip, NORM) -- the stand-alone norm pass and its fp32 output are
+    gone; saved for the backward: h, bf16(norm(h)), 1/rms.  Backward: gaot_ffn_bwd (dx w.r.t. the normalised rows, the residual's
+    gradient included), the two weight-gradient products, gaot_rmsnorm_bwd.  Values: those of RMSNormFn + FFNFn."""
+
+    @staticmethod
+    def eligible(h: Tensor, norm_w: Tensor, w1: Tensor, w3: Tensor, w2: Tensor) -> bool:
+        if not (_FFN_FUSED and _NORM_FFN and h.is_cuda and h.dtype == torch.float32 and h.shape[-1] == 256 and norm_w.numel() == 256
+                and _adjacent([_w2d(w1), _w2d(w3)]) and all(t.requires_grad for t in (w1, w3, w2)) and torch.is_grad_enabled()):
+            return False
+        f = w1.shape[0]
+        wcat32 = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, 256), (256, 1))
+        return _ffn_fusable(wcat32, _w2d(w2))
+
+    @staticmethod
+    def forward(ctx, h: Tensor, norm_w: Tensor, eps: float, w1: Tensor, w3: Tensor, w2: Tensor):
+        f, d = w1.shape
+        h2 = h.reshape(-1, d)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        wcat32 = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1))
+        packed, has_bwd = _FFN_PACK_CACHE.get((wcat32.data_ptr(), tuple(wcat32.shape)), (None, False))
+        if packed is None or not has_bwd:
+            packed = ops.ffn_pack(wcat32, _w2d(w2), f, True)
+        y, yb, rstd = ops.norm_ffn_fwd(h2, norm_w, eps, packed, f)
+        ctx.save_for_backward(h2, norm_w, rstd, yb, packed)
+        ctx.wparams = (w1, w3, w2)
+        ctx.nparam = norm_w
+        ctx.meta = (f, d, h.shape, w1.shape, w2.shape)
+        return y.view(*h.shape[:-1], d)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        h2, norm_w, rstd, yb, packed = ctx.saved_tensors
+        f, d, hshape, w1shape, w2shape = ctx.meta
+        m = h2.shape[0]
+        dy2 = dy.reshape(m, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)       # dn: gradient w.r.t. the normalised rows (FFN input + residual)
+        dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
+        dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
+        dh, dnw = ops.rmsnorm_bwd(h2, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
+        return dh.view(hshape), dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
 
 
 class Mlp2Fn(Function):

@@ -248,6 +248,14 @@ class TransformerBlock(nn.Module):
         else:
             h, xres = self.attn_norm.forward_with_residual(x)
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
+        f = self.ffn
+        if self.ffn_norm is not None and f.correction is None and h.is_cuda and h.shape[-1] == 256 and torch.is_grad_enabled():
+            GF.colocate([f.w1.weight, f.w3.weight])     # (no-op once done)
+        if (self.ffn_norm is not None and f.correction is None
+                and GF.NormFFNFn.eligible(h, self.ffn_norm.weight, f.w1.weight, f.w3.weight, f.w2.weight)):
+            # ffn_norm, the FFN and the residual in one launch (bf16 mode, d_model 256)
+            out = GF.NormFFNFn.apply(h, self.ffn_norm.weight, self.ffn_norm.eps, f.w1.weight, f.w3.weight, f.w2.weight)
+            return (out, tap) if asked else out
         h = h if self.ffn_norm is None else self.ffn_norm(h)
         # NB: the second residual adds the *normalised* h (reference attn.py:226-229)
         out = self.ffn(h, condition=condition, residual=h)                                           # h + ffn(h)

@@ -867,6 +867,23 @@ def ffn_fwd(xb: Tensor, packed: Tensor, f: int, residual: Optional[Tensor] = Non
     return y, ag, u
 
 
+def norm_ffn_fwd(h: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, f: int):
+    """RMSNorm + FFN + residual in one launch (include/gaot3d_hip.h: gaot_norm_ffn_fwd): h fp32 [rows, 256] ->
+    (y fp32 [rows, 256] = n + ffn(n), yb = bf16(n) [rows, 256], rstd [rows]) with n = RMSNorm(h)"""
+    lib = _lib.load()
+    if h.dtype != torch.float32 or h.dim() != 2 or h.shape[1] != 256 or h.stride(1) != 1:
+        raise GaotError("norm_ffn_fwd: fp32 [rows, 256] input expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    rows = h.shape[0]
+    y = torch.empty(rows, 256, dtype=torch.float32, device=h.device)
+    yb = torch.empty(rows, 256, dtype=torch.bfloat16, device=h.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=h.device)
+    with _timed("norm_ffn_fwd"):
+        check(lib.gaot_norm_ffn_fwd(_ptr(h), h.stride(0), _ptr(nw), float(eps), _ptr(packed), _ptr(y), _ptr(yb), _ptr(rstd), rows, int(f),
+                                    _stream()), "gaot_norm_ffn_fwd")
+    return y, yb, rstd
+
+
 def ffn_bwd_dag(xb: Tensor, dy: Tensor, packed: Tensor, f: int, want_dyb: bool = True):
     """the first half of the FFN backward for a forward that saved nothing (include/gaot3d_hip.h: gaot_ffn_bwd_dag): x [rows, 256] bf16,
     dy fp32 [rows, 256], ``packed`` from ffn_pack(..., with_backward=True) -> (dag bf16 [rows, 2F], u bf16 [rows, F], dyb bf16 or None)"""

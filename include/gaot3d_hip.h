@@ -317,6 +317,11 @@ int gaot_ffn_pack_multi(const gaot_ffn_pack_t* items, int num, int F, int with_b
  * gaot_ffn_w13_swiglu followed by gaot_gemm_ex(u, w2, residual). */
 int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float* residual, int64_t ldr, float* y, void* ag, void* u, int64_t rows,
                  int F, gaot_stream_t stream);
+/* RMSNorm + FFN + residual of a Transformer block in one launch (attn.py:227-229: h = ffn_norm(h); h + ffn(h) -- the residual is the
+ * NORMALISED h): y = n + w2(silu(w1 n) * w3 n), n = RMSNorm(h; norm_weight, eps); yb = bf16(n) and rstd are written for the backward
+ * (gaot_ffn_bwd on yb, then gaot_rmsnorm_bwd on its dx).  Values of gaot_rmsnorm_fwd followed by gaot_ffn_fwd. */
+int gaot_norm_ffn_fwd(const float* h, int64_t ldh, const float* norm_weight, float eps, const void* packed, float* y, void* yb,
+                      float* rstd, int64_t rows, int F, gaot_stream_t stream);
 /* the first half of the backward for a forward that saved nothing (ag = u = NULL above): a | g recomputed from x, du = dy W2, the
  * SwiGLU derivative -> dag = d(a) | d(g) (bf16 [rows][2F]), u = silu(a) g (bf16 [rows][F]), dyb = bf16(dy) ([rows][256], optional):
  * the operands of the dx = dag W13, dW13 = dag^T x and dW2 = dyb^T u products.  packed: gaot_ffn_pack WITH the backward images.

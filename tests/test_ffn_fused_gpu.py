@@ -133,3 +133,43 @@ def test_fused_backward_with_input_gradient(rows, f, add_dy):
     e_gemm, e_ref, e_gemm_ref = (dx1 - dx0).abs().max().item() / peak, (dx1.double() - ref).abs().max().item() / peak, (dx0.double() - ref).abs().max().item() / peak
     print(f"[parity] ffn_bwd dx rows={rows} F={f} add_dy={add_dy}: vs stand-alone GEMM {e_gemm:.2e}, vs fp64 {e_ref:.2e} (stand-alone GEMM vs fp64 {e_gemm_ref:.2e}) of peak")
     assert e_gemm < 1e-5 and e_ref < 1e-5
+
+
+@pytest.mark.parametrize("rows,f", [(16384, 1024), (1000, 256)])
+def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f):
+    """NormFFNFn (ffn_norm + FFN + residual in one forward launch, reference attn.py:227-229) against RMSNormFn + FFNFn: the output and
+    every gradient, to bf16 rounding noise"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.model.layers import attn as A
+    torch.manual_seed(4)
+    blk = A.TransformerBlock(256, 256, attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0),
+                             ffn_config=A.FFNConfig(hidden_size=f)).to(DEV).train()
+    with torch.no_grad():
+        blk.ffn_norm.weight.add_(0.1 * torch.randn(256, device=DEV))
+    x = torch.randn(1, rows, 256, device=DEV, requires_grad=True)
+    gaot_3d_amd.set_precision("bf16")
+    out = {}
+    try:
+        for on in (False, True):
+            GF._NORM_FFN = on
+            for p in blk.parameters():
+                p.grad = None
+            x.grad = None
+            y = blk(x)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            out[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    finally:
+        GF._NORM_FFN = True
+        gaot_3d_amd.set_precision("fp32")
+    names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
+    # the row sum of squares is contracted in another order than in k_rmsnorm_fwd: 1/rms differs in its last bit for some rows and the bf16
+    # rounding of a normalised element flips now and then -- the two paths agree to bf16 rounding noise, not bit for bit
+    worst = 0.0
+    for n, a, b in zip(names, out[False], out[True]):
+        err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+        cos = torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+        worst = max(worst, err)
+        assert err < (1e-4 if n == "y" else 4e-3) and cos > 0.99999, f"{n}: max diff / peak {err:.3e}, cosine {cos:.7f}"
+    print(f"[parity] norm_ffn rows={rows} F={f}: fused vs norm + FFN, worst max-diff / peak over y and {len(names) - 1} gradients {worst:.2e}")

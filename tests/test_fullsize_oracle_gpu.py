@@ -261,7 +261,7 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
           f"max source degree {int(deg_src.max())}")
 
     # ---- forward: the oracle's IntegralTransform on the sub-graph of the sampled query rows --------------------------------
-    qs = _sample_rows(deg_dst, 1000, gen)
+    qs = _sample_rows(deg_dst, n_s, gen)
     local = torch.full((n_dst,), -1, dtype=torch.long)
     local[qs] = torch.arange(qs.numel())
     sel = local[dst] >= 0
@@ -322,8 +322,8 @@ def sample8m():
 def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
     """the fused GNO forward / backward on the 64 M-edge graphs of an 8 M-point sample (BASELINE configs[4]; VERDICT r4: that
     size was exercised only through properties and sharded == unsharded) against the oracle on SAMPLED rows: forward on the
-    sub-graph of >= 1 000 query rows; grad f_y on every edge of >= 1 000 source rows (full dout); weight / bias gradients
-    from a second backward whose dout is zero outside >= 4 000 sampled query rows -- the kernels still walk all 64 M edges
+    sub-graph of >= 1 000 (encoder: 400) query rows; grad f_y on every edge of >= 1 000 source rows (full dout); weight / bias gradients
+    from a second backward whose dout is zero outside >= 4 000 (encoder: 1 500) sampled query rows -- the kernels still walk all 64 M edges
     (row pointers and gathers beyond 2^31 bytes), the oracle needs the sampled rows' edges only (fp64)."""
     from gaot_3d_amd import ops
     batch, tokens = sample8m
@@ -347,7 +347,11 @@ def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
     src, dst = ei_c[0], ei_c[1]
     deg_dst = torch.bincount(dst, minlength=n_dst)
     deg_src = torch.bincount(src, minlength=n_src)
-    qw = _sample_rows(deg_dst, 4000, gen)                   # query rows that carry the masked dout
+    # sampled row counts by degree: the encoder's query rows (latent tokens) have ~490 edges each, the decoder's 8 -- the oracle's cost
+    # is the EDGES of the sampled rows (round 6: 49 s -> ~20 s per encoder case; same assertions)
+    heavy = float(deg_dst.float().mean()) > 64
+    n_w, n_s = (1500, 400) if heavy else (4000, 1000)
+    qw = _sample_rows(deg_dst, n_w, gen)                    # query rows that carry the masked dout
     dmask = torch.zeros_like(dout)
     dmask[qw] = dout[qw]
     _, gw, gb = ops.gno_backward(ws, bs, y_pos, x_pos, f_d, dmask.to(DEV), graph, precision=prec)
@@ -358,7 +362,7 @@ def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
           f"max source degree {int(deg_src.max())}")
     assert ei.shape[1] == 64_000_000
 
-    qs = _sample_rows(deg_dst, 1000, gen)
+    qs = _sample_rows(deg_dst, n_s, gen)
     local = torch.full((n_dst,), -1, dtype=torch.long)
     local[qs] = torch.arange(qs.numel())
     sel = local[dst] >= 0
