@@ -110,6 +110,9 @@ SIGNATURES = {
     "gaot_ffn_pack_multi": (_i, [_p, _i, _i, _i, _p]),
     "gaot_ffn_fwd": (_i, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i, _p]),
     "gaot_norm_ffn_fwd": (_i, [_p, _i64, _p, _f, _p, _p, _p, _p, _i64, _i, _p]),
+    "gaot_block_packed_bytes": (_i64, [_i]),
+    "gaot_block_pack_multi": (_i, [_p, _i, _i, _p]),
+    "gaot_block_tail_fwd": (_i, [_p, _i64, _p, _i64, _p, _f, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_ffn_bwd_dag": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_ffn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p]),
     "gaot_act_bwd": (_i, [_p, _p, _p, _i64, _i, _p]),

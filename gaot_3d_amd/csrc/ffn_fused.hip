@@ -92,6 +92,7 @@ constexpr int PACK_MAX = 16;
 struct PackTable {
     const float* w13[PACK_MAX];
     const float* w2[PACK_MAX];
+    const float* wo[PACK_MAX];      // o_proj.weight [256][256] or null: a fifth image behind the four (gaot_block_pack_multi)
     bf16_t* packed[PACK_MAX];
 };
 // blockIdx.y = the FFN: all blocks of a Transformer in one launch
@@ -100,6 +101,15 @@ __global__ void k_ffn_pack(PackTable t, int F, int with_backward) {
     bf16_t* w2p = p + (int64_t)2 * F * D;
     bf16_t* w2tp = with_backward ? w2p + (int64_t)D * F : nullptr;
     ffn_pack_body(t.w13[blockIdx.y], t.w2[blockIdx.y], F, p, w2p, w2tp, with_backward ? w2tp + (int64_t)D * F : nullptr);
+    if (const float* wo = t.wo[blockIdx.y]) {
+        // block ((w*2 + jt)*16 + s): row 64 w + 32 jt + l31 of o_proj.weight, k = 16 s + 8 hf + e
+        bf16_t* wop = p + ((int64_t)2 * F * D + (int64_t)D * F) * (with_backward ? 2 : 1);
+        for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < D * D / 8; id += gridDim.x * blockDim.x) {
+            const int lane = id & 63, s2 = (id >> 6) & 15, jt = (id >> 10) & 1, w = id >> 11;
+            const float* src = wo + (int64_t)(w * 64 + jt * 32 + (lane & 31)) * D + 16 * s2 + 8 * (lane >> 5);
+            *reinterpret_cast<u32x4*>(wop + (int64_t)id * 8) = u32x4{pack2(src[0], src[1]), pack2(src[2], src[3]), pack2(src[4], src[5]), pack2(src[6], src[7])};
+        }
+    }
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------------------
@@ -110,11 +120,24 @@ __global__ void k_ffn_pack(PackTable t, int F, int with_backward) {
 // the arithmetic of k_rmsnorm_fwd (one wave per row, a lane per float4, the same butterfly), writes them to the LDS tile and to YB (bf16
 // [M][256]: the backward's input and the dW13 product's operand) and their 1/rms to RSTD; the residual added at the end is the
 // normalised row, recomputed from R.  The stand-alone norm pass (a read and two writes of [M][256]) is gone.
-template <bool SAVE, int RD, bool NORM = false>
+// OPROJ (gaot_block_tail_fwd; with NORM): the attention's output projection and the block's first residual in front of that norm
+// (reference attn.py:127, 226: h = x + o_proj(attn)): O = the attention output fp32 [M][ldo], WOp = o_proj.weight as fragment blocks
+// ((w*2 + jt)*16 + s: row 64 w + 32 jt + l31, k = 16 s + 8 hf + e), R = x; the product's accumulators start as x, h is written to H
+// (fp32 [M][256]: the backward's norm input) and normalised from the registers -- the sum of squares of a row is the sum of the four
+// waves' 64-column partials (another order than k_rmsnorm_fwd: h itself is bit-identical to the stand-alone GEMM, 1/rms to rounding).
+struct TailArgs {
+    const float* NW; float eps; bf16_t* YB; float* RSTD;      // NORM
+    const float* O; int ldo; const u32x4* WOp; float* H;      // OPROJ
+};
+template <bool SAVE, int RD, bool NORM = false, bool OPROJ = false>
 __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X, const u32x4* __restrict__ W13p,
                                                      const u32x4* __restrict__ W2p, const float* __restrict__ R, float* __restrict__ Y,
-                                                     bf16_t* __restrict__ AG, bf16_t* __restrict__ U, int M, int F, int ldr,
-                                                     const float* __restrict__ NW, float eps, bf16_t* __restrict__ YB, float* __restrict__ RSTD) {
+                                                     bf16_t* __restrict__ AG, bf16_t* __restrict__ U, int M, int F, int ldr, TailArgs ta) {
+    static_assert(!OPROJ || NORM, "the output projection comes with the norm");
+    const float* __restrict__ NW = ta.NW;
+    const float eps = ta.eps;
+    bf16_t* __restrict__ YB = ta.YB;
+    float* __restrict__ RSTD = ta.RSTD;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     // consecutive workgroup ids sit on consecutive XCDs: give every XCD a contiguous range of row blocks (the a | g / u / y rows one
@@ -136,8 +159,10 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
     // the residual rows of this lane's outputs: requested at the top of the LAST chunk's iteration (below) -- at the kernel's end the
     // workgroup would finish on an exposed HBM round trip, at its start all 256 workgroups would wait for 16 MB more before their first MFMA
     f32x4 rres[2][2][4];
-    const int64_t rbytes = (int64_t)M * ldr * 4;
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, R ? (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes) : 0, 0x00020000);
+    const float* rsrc_p = OPROJ ? ta.H : R;          // the rows the final residual is (re)computed from
+    const int ldres = OPROJ ? D : ldr;
+    const int64_t rbytes = (int64_t)M * ldres * 4;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)rsrc_p, 0, rsrc_p ? (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes) : 0, 0x00020000);
     // A STEP = 8 fragment blocks (8 KB per wave) and 16 MFMAs.  Steps of chunk c: st 0..3 = the four 64-deep k-slices of h W13c^T (tiles
     // a, g), st 4, 5 = the two 64-deep k-slices of u W2c^T (tiles: output columns 64 w .. +31, +32 .. +63).  Chunks past the last one read
     // as zeros (buffer range check): the loop below runs one a | g product too many instead of carrying a second copy of its body.
@@ -177,8 +202,120 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
     }
     if (GAOT_FFN_ABL & 1) { wload(wr[LA % RD], 0, 0); wfirst = false; }
 
-    float* rstd_l = reinterpret_cast<float*>(lds + H_BYTES + 2 * U_BYTES + (SAVE ? 2 * AG_BYTES : 0));      // NORM: 64 floats
-    if constexpr (NORM) {
+    float* rstd_l = reinterpret_cast<float*>(lds + H_BYTES + 2 * U_BYTES + (SAVE ? 2 * AG_BYTES : 0));      // NORM: 64 floats (+ OPROJ: 4 x 64)
+    if constexpr (OPROJ) {
+        const int sw0 = l31 & 15;
+        const int64_t obytes = (int64_t)M * ta.ldo * 4, xb2 = (int64_t)M * ldr * 4, hbytes = (int64_t)M * D * 4, ybbytes = (int64_t)M * D * 2;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)ta.O, 0, (int)(obytes > 0x7fffffff ? 0x7fffffff : obytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, R ? (int)(xb2 > 0x7fffffff ? 0x7fffffff : xb2) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)ta.H, 0, (int)(hbytes > 0x7fffffff ? 0x7fffffff : hbytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)YB, 0, (int)(ybbytes > 0x7fffffff ? 0x7fffffff : ybbytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wors = __builtin_amdgcn_make_buffer_rsrc((void*)ta.WOp, 0, D * D * 2, 0x00020000);
+        // the attention output rows fp32 -> bf16 -> LDS tile (row 8 i + tid >> 5, 16-byte bf16 chunk tid & 31 = 8 floats)
+        {
+            f32x4 d0[8], d1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+                const unsigned off = m < M ? (unsigned)m * (unsigned)ta.ldo * 4u + (unsigned)(threadIdx.x & 31) * 32u : 0x80000000u;
+                d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, off, 0, 0));
+                d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, off, 16, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31;
+                const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+                *reinterpret_cast<u32x4*>(lds + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+            }
+        }
+        // h starts as x (the block's first residual): column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31
+        f32x16 hacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 32 * i + l31;
+            const unsigned roff = (m < M && R) ? (unsigned)m * (unsigned)ldr * 4u : 0x80000000u;     // out of range -> zeros
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs2, roff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0));
+                    hacc[jt][i][4 * q] = v[0]; hacc[jt][i][4 * q + 1] = v[1]; hacc[jt][i][4 * q + 2] = v[2]; hacc[jt][i][4 * q + 3] = v[3];
+                }
+        }
+        u32x4 wo[2][8];
+        auto woload = [&](u32x4 (&dst)[8], int st) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wors, lane * 16, (((wv * 2 + jt) * 16) + 4 * st + s2) * 1024, 0));
+        };
+        woload(wo[0], 0);
+        woload(wo[1], 1);
+        __builtin_amdgcn_s_barrier();       // the bf16 tile of the attention output is complete
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int slot = ((2 * (4 * st + s2) + hf) ^ sw0) << 4;
+                const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(lds + l31 * 512 + slot), o1 = *reinterpret_cast<const bf16x8*>(lds + (32 + l31) * 512 + slot);
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wo[st & 1][s2]), w1 = __builtin_bit_cast(bf16x8, wo[st & 1][4 + s2]);
+                hacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, o0, hacc[0][0], 0, 0, 0);
+                hacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, o0, hacc[1][0], 0, 0, 0);
+                hacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, o1, hacc[0][1], 0, 0, 0);
+                hacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, o1, hacc[1][1], 0, 0, 0);
+            }
+            if (st + 2 < 4) woload(wo[st & 1], st + 2);
+        }
+        // h to HBM (the backward's norm input) and the rows' sums of squares: this wave's 64 columns, then the four waves' partials
+        float* part = rstd_l + 64;       // [4 waves][64 rows]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 32 * i + l31;
+            const unsigned rowoff = m < M ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;
+            float ssl = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {hacc[jt][i][4 * q], hacc[jt][i][4 * q + 1], hacc[jt][i][4 * q + 2], hacc[jt][i][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), hrs, rowoff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0);
+                    ssl += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                }
+            ssl += __shfl_xor(ssl, 32, 64);
+            if (hf == 0) part[wave * 64 + 32 * i + l31] = ssl;
+        }
+        __builtin_amdgcn_s_barrier();       // partials complete; every wave is done reading the attention-output tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = 32 * i + l31, m = m0 + ml;
+            const float ssr = ((part[ml] + part[64 + ml]) + part[128 + ml]) + part[192 + ml];
+            const float r = rsqrtf(ssr / (float)D + eps);
+            if (wave == 0 && hf == 0) {
+                rstd_l[ml] = r;
+                if (m < M) RSTD[m] = r;
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(NW + wave * 64 + 32 * jt + 8 * q + 4 * hf);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 pk = {pack2(hacc[jt][i][4 * q] * r * g[0], hacc[jt][i][4 * q + 1] * r * g[1]),
+                                      pack2(hacc[jt][i][4 * q + 2] * r * g[2], hacc[jt][i][4 * q + 3] * r * g[3])};
+                    // tile: row ml, 16-byte chunk 8 wave + 4 jt + q, its 8-byte half hf
+                    *reinterpret_cast<u32x2*>(lds + ml * 512 + (((8 * wave + 4 * jt + q) ^ (ml & 15)) << 4) + 8 * hf) = pk;
+                }
+        }
+        __builtin_amdgcn_s_barrier();       // the normalised tile is complete
+        // bf16(norm(h)) to HBM, this wave's 16 rows, two rows per instruction
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = 16 * wave + 2 * k + hf, ch = l31, m = m0 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * 512 + ((ch ^ (row & 15)) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(v, ybrs, m < M ? (unsigned)m * (unsigned)D * 2u + (unsigned)ch * 16u : 0x80000000u, 0, 0);
+        }
+    } else if constexpr (NORM) {
         // rows 16 wave .. + 15 of the block, a lane per float4 (the arithmetic and summation order of k_rmsnorm_fwd, rowops.hip)
         const int64_t rbytes = (int64_t)M * ldr * 4, ybbytes = (int64_t)M * D * 2;
         const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, (int)(rbytes > 0x7fffffff ? 0x7fffffff : rbytes), 0x00020000);
@@ -226,8 +363,9 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
             const int voff = (m0 + wave * 16 + x) * D * 2 + (((lane & 31) ^ x) << 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lds + (wave * 8 + i) * 1024), 16, voff, 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA pieces have landed (the NORM forms write the tile with LDS stores: a
+                                                                // drain here would sit out the round trip of their h / yb stores to HBM)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FFN_STAMP(1);
 
@@ -275,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_fwd(const bf16_t* __restrict__ X
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int m = m0 + 32 * i + l31;
-                const unsigned roff = (m < M && R) ? (unsigned)m * (unsigned)ldr * 4u : 0x80000000u;     // out of range -> zeros
+                const unsigned roff = (m < M && rsrc_p) ? (unsigned)m * (unsigned)ldres * 4u : 0x80000000u;     // out of range -> zeros
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -454,11 +592,11 @@ constexpr int FWD_LDS = H_BYTES + 2 * U_BYTES, FWD_LDS_SAVE = FWD_LDS + 2 * AG_B
 #endif
 constexpr int FWD_RING = GAOT_FFN_FWD_RING;
 
-template <bool SAVE, bool NORM>
+template <bool SAVE, bool NORM, bool OPROJ = false>
 int launch_ffn_fwd(const void* x, const void* w13p, const void* w2p, const float* r, float* y, void* ag, void* u, int M, int F, int ldr,
-                   const float* nw, float eps, void* yb, float* rstd, hipStream_t st) {
-    auto kern = k_ffn_fwd<SAVE, FWD_RING, NORM>;
-    constexpr int LDS = (SAVE ? FWD_LDS_SAVE : FWD_LDS) + (NORM ? 256 : 0);
+                   const TailArgs& ta, hipStream_t st) {
+    auto kern = k_ffn_fwd<SAVE, FWD_RING, NORM, OPROJ>;
+    constexpr int LDS = (SAVE ? FWD_LDS_SAVE : FWD_LDS) + (NORM ? 256 : 0) + (OPROJ ? 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -470,7 +608,7 @@ int launch_ffn_fwd(const void* x, const void* w13p, const void* w2p, const float
     }
     const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
     GAOT_KLAUNCH(kern, dim3((unsigned)(8 * per)), dim3(256), LDS, st, (const bf16_t*)x, (const u32x4*)w13p, (const u32x4*)w2p, r, y,
-                 (bf16_t*)ag, (bf16_t*)u, M, F, ldr, nw, eps, (bf16_t*)yb, rstd);
+                 (bf16_t*)ag, (bf16_t*)u, M, F, ldr, ta);
     return GAOT_OK;
 }
 
@@ -1056,7 +1194,7 @@ extern "C" int gaot_ffn_pack_multi(const gaot_ffn_pack_t* items, int num, int F,
         for (int i = 0; i < n; ++i) {
             const gaot_ffn_pack_t& it = items[i0 + i];
             GAOT_CHECK_ARG(it.w13 && it.w2 && it.packed && ((uintptr_t)it.packed % 16) == 0, "null or misaligned pointer in the table");
-            t.w13[i] = it.w13; t.w2[i] = it.w2; t.packed[i] = (bf16_t*)it.packed;
+            t.w13[i] = it.w13; t.w2[i] = it.w2; t.wo[i] = nullptr; t.packed[i] = (bf16_t*)it.packed;
         }
         GAOT_KLAUNCH(k_ffn_pack, dim3((unsigned)std::min<int64_t>(ceil_div(frags, 256), 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, F,
                      with_backward);
@@ -1087,8 +1225,8 @@ extern "C" int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float*
     const bf16_t* p = (const bf16_t*)packed;
     const void* w13p = p;
     const void* w2p = p + (int64_t)2 * F * D;
-    const int rc = ag ? launch_ffn_fwd<true, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, nullptr, 0.f, nullptr, nullptr, (hipStream_t)stream)
-                      : launch_ffn_fwd<false, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, nullptr, 0.f, nullptr, nullptr, (hipStream_t)stream);
+    const int rc = ag ? launch_ffn_fwd<true, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, TailArgs{}, (hipStream_t)stream)
+                      : launch_ffn_fwd<false, false>(x_bf16, w13p, w2p, residual, y, ag, u, (int)rows, F, (int)ldr, TailArgs{}, (hipStream_t)stream);
     if (rc != GAOT_OK) return rc;
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
@@ -1163,8 +1301,55 @@ extern "C" int gaot_norm_ffn_fwd(const float* h, int64_t ldh, const float* norm_
         return GAOT_ERR_UNSUPPORTED;
     }
     const bf16_t* p = (const bf16_t*)packed;
-    const int rc = launch_ffn_fwd<false, true>(nullptr, p, p + (int64_t)2 * F * D, h, y, nullptr, nullptr, (int)rows, F, (int)ldh, norm_weight, eps, yb,
-                                               rstd, (hipStream_t)stream);
+    const TailArgs ta{norm_weight, eps, (bf16_t*)yb, rstd, nullptr, 0, nullptr, nullptr};
+    const int rc = launch_ffn_fwd<false, true>(nullptr, p, p + (int64_t)2 * F * D, h, y, nullptr, nullptr, (int)rows, F, (int)ldh, ta, (hipStream_t)stream);
+    if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// ---- the whole tail of a Transformer block in one launch (reference attn.py:127, 226-229): h = x + o_proj(attn_out); n = ffn_norm(h);
+// y = n + w2(silu(w1 n) * w3 n).  gaot_block_pack_multi: gaot_ffn_pack_multi WITH the backward images plus the fragment image of
+// o_proj.weight ([256][256]) behind them (gaot_block_packed_bytes(F) bytes per block).
+extern "C" int64_t gaot_block_packed_bytes(int F) { return gaot_ffn_packed_bytes(F, 1) + (int64_t)D * D * 2; }
+
+extern "C" int gaot_block_pack_multi(const gaot_block_pack_t* items, int num, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(items && num > 0 && F > 0 && F % FC == 0, "bad argument (F must be a multiple of 128)");
+    const int64_t frags = ((int64_t)2 * F * D + (int64_t)D * F) / 8 * 2;
+    for (int i0 = 0; i0 < num; i0 += PACK_MAX) {
+        PackTable t{};
+        const int n = std::min(PACK_MAX, num - i0);
+        for (int i = 0; i < n; ++i) {
+            const gaot_block_pack_t& it = items[i0 + i];
+            GAOT_CHECK_ARG(it.w13 && it.w2 && it.wo && it.packed && ((uintptr_t)it.packed % 16) == 0, "null or misaligned pointer in the table");
+            t.w13[i] = it.w13; t.w2[i] = it.w2; t.wo[i] = it.wo; t.packed[i] = (bf16_t*)it.packed;
+        }
+        GAOT_KLAUNCH(k_ffn_pack, dim3((unsigned)std::min<int64_t>(ceil_div(frags, 256), 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, F, 1);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// attn_out fp32 [rows][ldo] (the attention kernels' output, heads concatenated), x fp32 [rows][ldx] (the block's input: the first
+// residual), packed = one block image of gaot_block_pack_multi -> h fp32 [rows][256] (kept for the backward's norm), y fp32 [rows][256],
+// yb = bf16(ffn_norm(h)), rstd.  Values: gaot_gemm_ex(attn_out, Wo, residual = x) bit for bit, then gaot_norm_ffn_fwd to rounding.
+extern "C" int gaot_block_tail_fwd(const float* attn_out, int64_t ldo, const float* x, int64_t ldx, const float* norm_weight, float eps,
+                                   const void* packed, float* h, float* y, void* yb, float* rstd, int64_t rows, int F, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(attn_out && norm_weight && packed && h && y && yb && rstd && rows > 0 && F > 0 && F % FC == 0,
+                   "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG(((uintptr_t)attn_out % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
+                   ((uintptr_t)y % 16) == 0 && ((uintptr_t)yb % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 && ldo % 4 == 0 && ldo >= D &&
+                   (!x || (ldx % 4 == 0 && ldx >= D)), "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff || rows * ldo * 4 >= 0x7fffffff || (x && rows * ldx * 4 >= 0x7fffffff)) {
+        gaot_set_error("gaot_block_tail_fwd: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const bf16_t* wop = p + ((int64_t)2 * F * D + (int64_t)D * F) * 2;
+    const TailArgs ta{norm_weight, eps, (bf16_t*)yb, rstd, attn_out, (int)ldo, (const u32x4*)wop, h};
+    const int rc = launch_ffn_fwd<false, true, true>(nullptr, p, p + (int64_t)2 * F * D, x, y, nullptr, nullptr, (int)rows, F, (int)ldx, ta, (hipStream_t)stream);
     if (rc != GAOT_OK) return rc;
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;

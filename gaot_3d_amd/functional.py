@@ -61,7 +61,9 @@ def precast_weights(mats, transposed=()) -> None:
 # fragment-ordered images of FFN weights for the fused FFN kernels (csrc/ffn_fused.hip), made by ONE launch for all blocks of a
 # Transformer (prepack_ffn) and valid until release_precast(): keyed by (address, shape) of the co-located fp32 [w1; w3]
 _FFN_PACK_CACHE: dict = {}
+_WO_PACKED: dict = {}      # key of a block image that carries the o_proj fragment image -> address of that o_proj weight
 _FFN_FUSED = os.environ.get("GAOT_FFN_FUSED", "1") != "0"
+_BLOCK_TAIL = os.environ.get("GAOT_BLOCK_TAIL", "1") != "0"    # o_proj + residual + ffn_norm + FFN + residual in one forward launch (A/B switch)
 _NORM_FFN = os.environ.get("GAOT_NORM_FFN", "1") != "0"        # the block's ffn_norm inside the fused FFN forward (A/B switch)
 _FFN_BWD_DX = os.environ.get("GAOT_FFN_BWD_DX", "1") != "0"      # the input gradient inside the fused backward launch (A/B switch)
 
@@ -72,18 +74,32 @@ def _ffn_fusable(w13: Tensor, w2: Tensor) -> bool:
                 and w13.dtype == torch.float32 and w2.dtype == torch.float32 and w13.is_contiguous() and w2.is_contiguous())
 
 
-def prepack_ffn(pairs, with_backward: bool) -> None:
+def prepack_ffn(pairs, with_backward: bool, wos=None) -> None:
     """``pairs``: (co-located [w1; w3] view, w2) of every FFN about to run; those the fused kernels take (d_model 256, F % 128 == 0,
-    bf16 mode) are packed by one launch per distinct F; ``with_backward``: the images the fused backward reads as well"""
+    bf16 mode) are packed by one launch per distinct F; ``with_backward``: the images the fused backward reads as well; ``wos``
+    (with the backward images): the o_proj weight of each pair's block -- packed behind them for the block-tail kernel (BlockTailFn)"""
     _FFN_PACK_CACHE.clear()
+    _WO_PACKED.clear()
     by_f: dict = {}
-    for w13, w2 in pairs:
+    pairs = list(pairs)
+    wos = list(wos) if (wos is not None and with_backward and _BLOCK_TAIL) else [None] * len(pairs)
+    for (w13, w2), wo in zip(pairs, wos):
         w13, w2 = _w2d(w13), _w2d(w2)
         if _ffn_fusable(w13, w2):
-            by_f.setdefault(w13.shape[0] // 2, []).append((w13, w2))
-    for f, items in by_f.items():
-        for (w13, _w2), packed in zip(items, ops.ffn_pack_multi(items, f, with_backward)):
+            if wo is not None:
+                wo = _w2d(wo)
+                if tuple(wo.shape) != (256, 256) or wo.dtype != torch.float32 or not wo.is_contiguous():
+                    wo = None
+            by_f.setdefault((w13.shape[0] // 2, wo is not None), []).append((w13, w2, wo))
+    for (f, has_wo), items in by_f.items():
+        if has_wo:
+            outs = ops.block_pack_multi(items, f)
+        else:
+            outs = ops.ffn_pack_multi([(a, b) for a, b, _ in items], f, with_backward)
+        for (w13, _w2, wo), packed in zip(items, outs):
             _FFN_PACK_CACHE[(w13.data_ptr(), tuple(w13.shape))] = (packed, bool(with_backward))
+            if has_wo:
+                _WO_PACKED[(w13.data_ptr(), tuple(w13.shape))] = wo.data_ptr()
 
 
 def release_precast() -> None:
@@ -699,6 +715,55 @@ class NormFFNFn(Function):
         dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
         dh, dnw = ops.rmsnorm_bwd(h2, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         return dh.view(hshape), dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
+
+
+class BlockTailFn(Function):
+    """Everything of a Transformer block behind the attention kernels (reference attn.py:127, 226-229):
+    ``h = x + o_proj(attn_out); n = ffn_norm(h); out = n + ffn(n)`` as ONE forward launch (csrc/ffn_fused.hip, OPROJ + NORM).
+    Saved: attn_out, h, bf16(n), 1/rms.  Backward: gaot_ffn_bwd, the two FFN weight-gradient products, gaot_rmsnorm_bwd, then the o_proj
+    input- and weight-gradient products on dh; the gradient of x is dh."""
+
+    @staticmethod
+    def enabled() -> bool:
+        return _FFN_FUSED and _NORM_FFN and _BLOCK_TAIL and ops.get_precision() == "bf16"
+
+    @staticmethod
+    def eligible(x: Tensor, wo: Tensor, norm_w: Tensor, w1: Tensor, w3: Tensor, w2: Tensor) -> bool:
+        wo2 = _w2d(wo)
+        return (BlockTailFn.enabled() and tuple(wo2.shape) == (256, 256) and wo2.dtype == torch.float32 and wo.requires_grad
+                and NormFFNFn.eligible(x, norm_w, w1, w3, w2))
+
+    @staticmethod
+    def forward(ctx, o: Tensor, x: Tensor, wo: Tensor, norm_w: Tensor, eps: float, w1: Tensor, w3: Tensor, w2: Tensor):
+        f, d = w1.shape
+        o2 = o if o.is_contiguous() else o.contiguous()
+        x2 = x if x.is_contiguous() else x.contiguous()
+        wo2 = _w2d(wo)
+        wcat32 = w1.new_empty(0).set_(w1.untyped_storage(), w1.storage_offset(), (2 * f, d), (d, 1))
+        key = (wcat32.data_ptr(), tuple(wcat32.shape))
+        packed, _has_bwd = _FFN_PACK_CACHE.get(key, (None, False))
+        if packed is None or _WO_PACKED.get(key) != wo2.data_ptr():
+            packed = ops.block_pack_multi([(wcat32, _w2d(w2), wo2)], f)[0]
+        y, h, yb, rstd = ops.block_tail_fwd(o2, x2, norm_w, eps, packed, f)
+        ctx.save_for_backward(o2, _wb(wo2, 1), h, norm_w, rstd, yb, packed)
+        ctx.wparams = (w1, w3, w2)
+        ctx.nparam, ctx.oparam = norm_w, wo
+        ctx.meta = (f, d, w1.shape, w2.shape, wo.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        o2, wob, h, norm_w, rstd, yb, packed = ctx.saved_tensors
+        f, d, w1shape, w2shape, woshape = ctx.meta
+        m = h.shape[0]
+        dy2 = dy if dy.is_contiguous() else dy.contiguous()
+        dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)
+        dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
+        dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
+        dh, dnw = ops.rmsnorm_bwd(h, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
+        d_o = ops.gemm(dh, wob, m, d, d, d, d, False, False, precision=1) if ctx.needs_input_grad[0] else None
+        dwo = _dw_gemm(dh, o2, d, d, m, d, d, 1, (ctx.oparam,)).view(woshape)
+        return d_o, (dh if ctx.needs_input_grad[1] else None), dwo, dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
 
 
 class Mlp2Fn(Function):

@@ -87,8 +87,10 @@ class GroupQueryFlashAttention(nn.Module):
             self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
 
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None):
-        """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`)."""
+                residual: Optional[torch.Tensor] = None, project: bool = True):
+        """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`).
+        ``project=False`` (extension, TransformerBlock): return the heads' outputs [B*S, heads * head_dim] WITHOUT o_proj -- the caller
+        applies it (functional.BlockTailFn: o_proj, the residual, ffn_norm and the FFN in one launch)."""
         dp = float(self.atten_dropout) if self.training else 0.0     # reference attn.py:122-126
         if self.correction is not None:                               # attn.py:101-102
             x = self.correction(c=condition, x=x)
@@ -109,6 +111,8 @@ class GroupQueryFlashAttention(nn.Module):
                 assert b == 1, "sequence-parallel attention splits ONE sample"
                 o = SeqAttnFn.apply(x, seq_group, self.num_heads, self.num_kv_heads, freqs, dp, self.q_proj.weight,
                                     self.k_proj.weight, self.v_proj.weight)
+                if not project:
+                    return o.reshape(b * s, -1)
                 y = GF.linear(o.reshape(b * s, -1), self.o_proj.weight, None,
                               residual=None if residual is None else residual.reshape(b * s, -1))
                 return y.view(b, s, -1)
@@ -151,6 +155,8 @@ class GroupQueryFlashAttention(nn.Module):
         else:
             o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp,
                                      getattr(self, "_head_group", None))
+        if not project:
+            return o.reshape(b * s, -1)
         y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
 
@@ -247,8 +253,18 @@ class TransformerBlock(nn.Module):
             h, xres, tap = self.attn_norm.forward_with_residual(x, tap=True)
         else:
             h, xres = self.attn_norm.forward_with_residual(x)
-        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
         f = self.ffn
+        if (self.ffn_norm is not None and f.correction is None and x.is_cuda and x.shape[-1] == 256 and torch.is_grad_enabled()
+                and GF.BlockTailFn.enabled()):
+            GF.colocate([f.w1.weight, f.w3.weight])     # (no-op once done)
+            if GF.BlockTailFn.eligible(xres, self.attn.o_proj.weight, self.ffn_norm.weight, f.w1.weight, f.w3.weight, f.w2.weight):
+                # o_proj, the first residual, ffn_norm, the FFN and the second residual in ONE launch (bf16 mode, d_model 256)
+                o = self.attn(h, condition=condition, relative_positions=relative_positions, project=False)
+                b, s, d = x.shape
+                out = GF.BlockTailFn.apply(o, xres.reshape(b * s, d), self.attn.o_proj.weight, self.ffn_norm.weight, self.ffn_norm.eps,
+                                           f.w1.weight, f.w3.weight, f.w2.weight).view(b, s, d)
+                return (out, tap) if asked else out
+        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
         if self.ffn_norm is not None and f.correction is None and h.is_cuda and h.shape[-1] == 256 and torch.is_grad_enabled():
             GF.colocate([f.w1.weight, f.w3.weight])     # (no-op once done)
         if (self.ffn_norm is not None and f.correction is None
@@ -319,7 +335,8 @@ class Transformer(nn.Module):
             ffn = self._ffn_matrices()
             GF.precast_weights(mats, ffn if self.training else ())
             # fragment-ordered images for the fused FFN kernels, one launch (with the backward's images when it will run)
-            GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled())
+            blocks = list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
+            GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled(), wos=[blk.attn.o_proj.weight for blk in blocks])
         try:
             return self._forward(x, condition, relative_positions)
         finally:

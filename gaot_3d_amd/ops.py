@@ -867,6 +867,50 @@ def ffn_fwd(xb: Tensor, packed: Tensor, f: int, residual: Optional[Tensor] = Non
     return y, ag, u
 
 
+class _BlockPackItem(C.Structure):   # gaot_block_pack_t
+    _fields_ = [("w13", C.c_void_p), ("w2", C.c_void_p), ("wo", C.c_void_p), ("packed", C.c_void_p)]
+
+
+def block_pack_multi(triples, f: int) -> List[Tensor]:
+    """ffn_pack_multi with the backward images plus the fragment image of o_proj.weight, for every (w13, w2, wo) of a Transformer in ONE
+    launch (include/gaot3d_hip.h: gaot_block_pack_multi); the images are slices of one buffer"""
+    lib = _lib.load()
+    triples = list(triples)
+    if not triples:
+        return []
+    nb = int(lib.gaot_block_packed_bytes(int(f)))
+    buf = torch.empty(len(triples) * nb, dtype=torch.uint8, device=triples[0][0].device)
+    outs = [buf[i * nb:(i + 1) * nb] for i in range(len(triples))]
+    items = (_BlockPackItem * len(triples))()
+    for i, ((w13, w2, wo), o) in enumerate(zip(triples, outs)):
+        for t, shp in ((w13, (2 * f, 256)), (w2, (256, f)), (wo, (256, 256))):
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shp:
+                raise GaotError("block_pack_multi: contiguous fp32 [2F, 256] / [256, F] / [256, 256] weights expected")
+        items[i] = _BlockPackItem(w13.data_ptr(), w2.data_ptr(), wo.data_ptr(), o.data_ptr())
+    check(lib.gaot_block_pack_multi(items, len(triples), int(f), _stream()), "gaot_block_pack_multi")
+    return outs
+
+
+def block_tail_fwd(attn_out: Tensor, x: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, f: int):
+    """h = x + o_proj(attn_out); n = RMSNorm(h); y = n + ffn(n) in one launch (include/gaot3d_hip.h: gaot_block_tail_fwd) ->
+    (y fp32 [rows, 256], h fp32 [rows, 256], yb = bf16(n), rstd [rows]); ``packed`` from block_pack_multi"""
+    lib = _lib.load()
+    rows = attn_out.shape[0]
+    for t, nm in ((attn_out, "attn_out"), (x, "x")):
+        if t.dtype != torch.float32 or t.dim() != 2 or tuple(t.shape) != (rows, 256) or t.stride(1) != 1:
+            raise GaotError(f"block_tail_fwd: fp32 [rows, 256] {nm} expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    dev = attn_out.device
+    y = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    h = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    yb = torch.empty(rows, 256, dtype=torch.bfloat16, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    with _timed("block_tail_fwd"):
+        check(lib.gaot_block_tail_fwd(_ptr(attn_out), attn_out.stride(0), _ptr(x), x.stride(0), _ptr(nw), float(eps), _ptr(packed), _ptr(h),
+                                      _ptr(y), _ptr(yb), _ptr(rstd), rows, int(f), _stream()), "gaot_block_tail_fwd")
+    return y, h, yb, rstd
+
+
 def norm_ffn_fwd(h: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, f: int):
     """RMSNorm + FFN + residual in one launch (include/gaot3d_hip.h: gaot_norm_ffn_fwd): h fp32 [rows, 256] ->
     (y fp32 [rows, 256] = n + ffn(n), yb = bf16(n) [rows, 256], rstd [rows]) with n = RMSNorm(h)"""

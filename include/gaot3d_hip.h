@@ -322,6 +322,20 @@ int gaot_ffn_fwd(const void* x_bf16, const void* packed, const float* residual, 
  * (gaot_ffn_bwd on yb, then gaot_rmsnorm_bwd on its dx).  Values of gaot_rmsnorm_fwd followed by gaot_ffn_fwd. */
 int gaot_norm_ffn_fwd(const float* h, int64_t ldh, const float* norm_weight, float eps, const void* packed, float* y, void* yb,
                       float* rstd, int64_t rows, int F, gaot_stream_t stream);
+/* the whole tail of a Transformer block in one launch (attn.py:127, 226-229): h = x + o_proj(attn_out); n = ffn_norm(h);
+ * y = n + w2(silu(w1 n) * w3 n).  gaot_block_pack_multi = gaot_ffn_pack_multi with the backward images plus the fragment image of
+ * o_proj.weight ([256][256]); gaot_block_packed_bytes(F) bytes per block.  h (fp32 [rows][256]), yb = bf16(n) and rstd are written
+ * for the backward (gaot_ffn_bwd on yb, gaot_rmsnorm_bwd on its dx, then the o_proj products on dh). */
+typedef struct {
+    const float* w13; /* [2F][256] */
+    const float* w2;  /* [256][F] */
+    const float* wo;  /* [256][256] */
+    void* packed;     /* gaot_block_packed_bytes(F) bytes, 16-byte aligned */
+} gaot_block_pack_t;
+int64_t gaot_block_packed_bytes(int F);
+int gaot_block_pack_multi(const gaot_block_pack_t* items, int num, int F, gaot_stream_t stream);
+int gaot_block_tail_fwd(const float* attn_out, int64_t ldo, const float* x, int64_t ldx, const float* norm_weight, float eps,
+                        const void* packed, float* h, float* y, void* yb, float* rstd, int64_t rows, int F, gaot_stream_t stream);
 /* the first half of the backward for a forward that saved nothing (ag = u = NULL above): a | g recomputed from x, du = dy W2, the
  * SwiGLU derivative -> dag = d(a) | d(g) (bf16 [rows][2F]), u = silu(a) g (bf16 [rows][F]), dyb = bf16(dy) ([rows][256], optional):
  * the operands of the dx = dag W13, dW13 = dag^T x and dW2 = dyb^T u products.  packed: gaot_ffn_pack WITH the backward images.
