@@ -58,6 +58,7 @@ SIGNATURES = {
     "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _i, _p]),
     "gaot_attn_dropout_mask": (_i, [_p, _f, _i, _i, _i, _p, _p]),
     "gaot_dropout_seed_next": (_i, [_p, C.c_uint64, _p, _p]),
+    "gaot_dropout_seed_block": (_i, [_p, C.c_uint64, _i, _p, _p]),
     "gaot_attn_bf16_image_bytes": (_sz, [_i, _i, _i, _i]),
     "gaot_rope_table": (_i, [_p, _i, _i, _p, _p]),
     "gaot_qkv_image": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p, _f, _p]),

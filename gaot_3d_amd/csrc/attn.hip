@@ -420,6 +420,15 @@ __global__ void k_seed_next(unsigned long long* __restrict__ state, unsigned lon
     }
 }
 
+// out[i] = state + i * stride (i < n); state += n * stride: the words of the next n dropout calls in ONE launch
+__global__ void k_seed_block(unsigned long long* __restrict__ state, unsigned long long stride, int n, unsigned long long* __restrict__ out) {
+    const unsigned long long v = *state;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = v + (unsigned long long)i * stride;
+    __syncthreads();
+    if (threadIdx.x == 0) *state = v + (unsigned long long)n * stride;
+}
+
 bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
 
 }  // namespace
@@ -490,6 +499,16 @@ extern "C" int gaot_dropout_seed_next(unsigned long long* state, unsigned long l
     GAOT_ENTER();
     GAOT_CHECK_ARG(state && out, "null pointer");
     GAOT_KLAUNCH(k_seed_next, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, out);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// the seed words of the next n dropout calls at once (ABI 11): out[i] = *state + i * stride, *state += n * stride -- the values n calls
+// of gaot_dropout_seed_next would hand out (a Transformer of L blocks draws its L attention seeds with one launch instead of L)
+extern "C" int gaot_dropout_seed_block(unsigned long long* state, unsigned long long stride, int n, unsigned long long* out, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(state && out && n > 0, "bad argument");
+    GAOT_KLAUNCH(k_seed_block, dim3(1), dim3(64), 0, (hipStream_t)stream, state, stride, n, out);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

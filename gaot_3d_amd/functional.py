@@ -281,10 +281,13 @@ def set_dropout_seed(seed: int, device) -> None:
     v = int(seed) & 0xFFFFFFFFFFFFFFFF
     v = v - (1 << 64) if v >= (1 << 63) else v
     _DROP_STATE[dev] = (torch.tensor([v], dtype=torch.int64, device=dev), torch.initial_seed())
+    _DROP_RESERVED.pop(dev, None)
 
 
-def next_dropout_seed(device) -> Tensor:
-    """the seed word for one dropout call (a fresh one-element int64 device tensor); advances the device state"""
+_DROP_RESERVED: dict = {}       # device -> list of one-element views of a reserved block of seed words, next first
+
+
+def _drop_state(device):
     dev = torch.device(device)
     if dev.index is None and dev.type == "cuda":
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -292,6 +295,33 @@ def next_dropout_seed(device) -> Tensor:
     if st is None or st[1] != torch.initial_seed():
         set_dropout_seed(torch.initial_seed() * 0x2545F4914F6CDD1D + 0x632BE59BD9B4E019, dev)
         st = _DROP_STATE[dev]
+    return dev, st
+
+
+def reserve_dropout_seeds(device, n: int) -> None:
+    """draw the seed words of the next ``n`` dropout calls on ``device`` with ONE launch (a Transformer's L attention layers: L launches
+    of ~4 us otherwise); next_dropout_seed hands them out in order -- the same words the unreserved calls would read.  Words left
+    over at release_dropout_seeds are skipped (the stream has advanced past them)."""
+    if n <= 0:
+        return
+    dev, st = _drop_state(device)
+    block = ops.dropout_seed_block(st[0], _DROP_STRIDE, n)
+    _DROP_RESERVED[dev] = [block[i:i + 1] for i in range(n)]
+
+
+def release_dropout_seeds(device) -> None:
+    dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    _DROP_RESERVED.pop(dev, None)
+
+
+def next_dropout_seed(device) -> Tensor:
+    """the seed word for one dropout call (a one-element int64 device tensor); advances the device state"""
+    dev, st = _drop_state(device)
+    res = _DROP_RESERVED.get(dev)
+    if res:
+        return res.pop(0)
     return ops.dropout_seed_next(st[0], _DROP_STRIDE)
 
 

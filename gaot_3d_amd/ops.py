@@ -537,6 +537,14 @@ def dropout_seed_next(state: Tensor, stride: int) -> Tensor:
     return out
 
 
+def dropout_seed_block(state: Tensor, stride: int, n: int) -> Tensor:
+    """-> int64 [n]: the seed words of the next n dropout calls; ``state`` advances by n * stride (one launch)"""
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.int64, device=state.device)
+    check(lib.gaot_dropout_seed_block(_ptr(state), stride & 0xFFFFFFFFFFFFFFFF, int(n), _ptr(out), _stream()), "gaot_dropout_seed_block")
+    return out
+
+
 def dropout(x: Tensor, seed: Tensor, p: float) -> Tensor:
     """x .* keep / (1 - p) with keep(i) = hash(seed, i) >= round(p 2^32)  (include/gaot3d_hip.h: gaot_dropout)"""
     lib = _lib.load()

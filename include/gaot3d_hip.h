@@ -167,6 +167,8 @@ int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout
 /* the seed stream: *out = *state; *state += stride -- the word one dropout call uses, and the advance, in one launch */
 int gaot_dropout_seed_next(unsigned long long* state, unsigned long long stride, unsigned long long* out,
                            gaot_stream_t stream);
+/* the words of the next n calls in one launch (ABI 11): out[i] = *state + i * stride, *state += n * stride */
+int gaot_dropout_seed_block(unsigned long long* state, unsigned long long stride, int n, unsigned long long* out, gaot_stream_t stream);
 
 /* bf16 matrix-core path of the same operator (precision 1).  qkv is the fused fp32 projection
  * [B*S][(H+2*HKV)*32] (q | k | v column blocks).  Forward first writes a bf16 image of it (RoPE applied when
