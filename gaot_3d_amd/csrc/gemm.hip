@@ -341,6 +341,10 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int bk = BK) {
             s = 4;
             while (s * 2 <= want && s < 32) s *= 2;
             s = std::min<int64_t>(s, std::max<int64_t>(1, K / 512));
+            if (const char* e = getenv("GAOT_DW_SPLITS")) {      // lab switch: force the split count of the Transformer weight gradients
+                const int64_t f = atoll(e);
+                if (f > 0) s = std::min<int64_t>(f, std::max<int64_t>(1, K / 512));
+            }
         }
     }
     p.kps = ceil_div(ceil_div(K, s), bk) * bk;

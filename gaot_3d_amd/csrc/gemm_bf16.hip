@@ -380,6 +380,11 @@ int launch_bm(const GArgs& g, int a_vec, int b_vec, int splits, hipStream_t st) 
     return GAOT_OK;
 }
 
+static bool dw_bm128() {
+    static const bool on = getenv("GAOT_DW_BM128") && atoi(getenv("GAOT_DW_BM128")) != 0;
+    return on;
+}
+
 template <bool A_KS, bool B_KS>
 int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t st) {
     // fewer than two 128x128 workgroups per CU: halve the tile height so that twice as many workgroups hide latency
@@ -398,7 +403,11 @@ int launch(const GArgs& g, int a_vec, int b_vec, int splits, int dt, hipStream_t
         switch (dt) {
             case 1: return launch_bm<A_KS, B_KS, 64, true, 2, true, false, false>(g, a_vec, b_vec, splits, st);
             case 2: return launch_bm<A_KS, B_KS, 64, true, 2, false, true, false>(g, a_vec, b_vec, splits, st);
-            case 3: return launch_bm<A_KS, B_KS, 64, true, 2, true, true, false>(g, a_vec, b_vec, splits, st);
+            case 3:
+                // lab switch (GAOT_DW_BM128=1): 128-row tiles for the split-K weight gradients with both operands bf16 -- the B panel
+                // (x: [K][N]) is re-read once per row block of the output, so twice the tile height halves that share of the L2 traffic
+                if (A_KS && B_KS && g.M >= 256 && dw_bm128()) return launch_bm<A_KS, B_KS, 128, true, 2, true, true, false>(g, a_vec, b_vec, splits, st);
+                return launch_bm<A_KS, B_KS, 64, true, 2, true, true, false>(g, a_vec, b_vec, splits, st);
             case 4: return launch_bm<A_KS, B_KS, 64, true, 2, false, false, true>(g, a_vec, b_vec, splits, st);
             case 5: return launch_bm<A_KS, B_KS, 64, true, 2, true, false, true>(g, a_vec, b_vec, splits, st);
             case 6: return launch_bm<A_KS, B_KS, 64, true, 2, false, true, true>(g, a_vec, b_vec, splits, st);

@@ -51,6 +51,7 @@ class TransformerConfig:
 
 
 SKIP_TAPS = {"on": os.environ.get("GAOT_SKIP_TAPS", "1") != "0"}      # A/B switch of Transformer._forward's skip taps (tests)
+SEED_BLOCK = {"on": os.environ.get("GAOT_SEED_BLOCK", "1") != "0"}    # A/B switch: the blocks' attention seeds by one launch
 
 
 class RotaryEmbedding(nn.Module):
@@ -337,7 +338,7 @@ class Transformer(nn.Module):
             # fragment-ordered images for the fused FFN kernels, one launch (with the backward's images when it will run)
             blocks = list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
             GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled(), wos=[blk.attn.o_proj.weight for blk in blocks])
-            if self.training and getattr(self, "_seq_group", None) is None:
+            if self.training and getattr(self, "_seq_group", None) is None and SEED_BLOCK["on"]:
                 # the attention seeds of all blocks with ONE launch (each block draws its own otherwise)
                 n_drop = sum(1 for blk in blocks if float(blk.attn.atten_dropout) > 0.0 and blk.attn.head_dim == 32)
                 GF.reserve_dropout_seeds(x.device, n_drop)
