@@ -108,6 +108,10 @@ __global__ void k_ffn_pack(PackTable t, int F, int with_backward) {
             const int lane = id & 63, s2 = (id >> 6) & 15, jt = (id >> 10) & 1, w = id >> 11;
             const float* src = wo + (int64_t)(w * 64 + jt * 32 + (lane & 31)) * D + 16 * s2 + 8 * (lane >> 5);
             *reinterpret_cast<u32x4*>(wop + (int64_t)id * 8) = u32x4{pack2(src[0], src[1]), pack2(src[2], src[3]), pack2(src[4], src[5]), pack2(src[6], src[7])};
+            // the same blocks of o_proj.weight^T (the backward's d_o = dh Wo: "row" j = 64 w + 32 jt + l31, k = 16 s + 8 hf + e -> wo[k][j])
+            const float* st = wo + (int64_t)(16 * s2 + 8 * (lane >> 5)) * D + (w * 64 + jt * 32 + (lane & 31));
+            *reinterpret_cast<u32x4*>(wop + (int64_t)D * D + (int64_t)id * 8) =
+                u32x4{pack2(st[0], st[D]), pack2(st[2 * D], st[3 * D]), pack2(st[4 * D], st[5 * D]), pack2(st[6 * D], st[7 * D])};
         }
     }
 }
@@ -1311,7 +1315,7 @@ extern "C" int gaot_norm_ffn_fwd(const float* h, int64_t ldh, const float* norm_
 // ---- the whole tail of a Transformer block in one launch (reference attn.py:127, 226-229): h = x + o_proj(attn_out); n = ffn_norm(h);
 // y = n + w2(silu(w1 n) * w3 n).  gaot_block_pack_multi: gaot_ffn_pack_multi WITH the backward images plus the fragment image of
 // o_proj.weight ([256][256]) behind them (gaot_block_packed_bytes(F) bytes per block).
-extern "C" int64_t gaot_block_packed_bytes(int F) { return gaot_ffn_packed_bytes(F, 1) + (int64_t)D * D * 2; }
+extern "C" int64_t gaot_block_packed_bytes(int F) { return gaot_ffn_packed_bytes(F, 1) + 2 * (int64_t)D * D * 2; }      // + o_proj, o_proj^T
 
 extern "C" int gaot_block_pack_multi(const gaot_block_pack_t* items, int num, int F, gaot_stream_t stream) {
     GAOT_ENTER();
@@ -1351,6 +1355,137 @@ extern "C" int gaot_block_tail_fwd(const float* attn_out, int64_t ldo, const flo
     const TailArgs ta{norm_weight, eps, (bf16_t*)yb, rstd, attn_out, (int)ldo, (const u32x4*)wop, h};
     const int rc = launch_ffn_fwd<false, true, true>(nullptr, p, p + (int64_t)2 * F * D, x, y, nullptr, nullptr, (int)rows, F, (int)ldx, ta, (hipStream_t)stream);
     if (rc != GAOT_OK) return rc;
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// ---- the o_proj backward's input gradient written straight as the attention backward's operands (reference attn.py:127 autograd, in
+// front of F.scaled_dot_product_attention's: attn.py:122-126): d_o = dh Wo never exists in fp32 -- a workgroup's 64 rows leave as the
+// bf16 dO image (row-major [rows][H*32]) and as delta[b][head][s] = sum over the head's 32 columns of d_o * o (the row constants of the
+// flash backward), formed from the fp32 accumulators.  Stands in for gaot_gemm_ex (d_o) + the preparation pass of gaot_attn_bwd_bf16
+// (phase 1: a read of d_o and o, a write of the image).
+namespace {
+__global__ __launch_bounds__(256, 2) void k_oproj_bwd(const float* __restrict__ DH, const float* __restrict__ O, const u32x4* __restrict__ WoTp,
+                                                       bf16_t* __restrict__ DOB, float* __restrict__ DELTA, int M, int S, int H) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB;
+    const int64_t fbytes = (int64_t)M * D * 4, ibytes = (int64_t)M * D * 2;
+    const __amdgpu_buffer_rsrc_t dhrs = __builtin_amdgcn_make_buffer_rsrc((void*)DH, 0, (int)(fbytes > 0x7fffffff ? 0x7fffffff : fbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)O, 0, (int)(fbytes > 0x7fffffff ? 0x7fffffff : fbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dobrs = __builtin_amdgcn_make_buffer_rsrc((void*)DOB, 0, (int)(ibytes > 0x7fffffff ? 0x7fffffff : ibytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)WoTp, 0, D * D * 2, 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    u32x4 wo[2][8];
+    auto woload = [&](u32x4 (&dst)[8], int st) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (((wv * 2 + jt) * 16) + 4 * st + s2) * 1024, 0));
+    };
+    woload(wo[0], 0);
+    woload(wo[1], 1);
+    {       // the dh rows fp32 -> bf16 -> LDS tile (row 8 i + tid >> 5, 16-byte bf16 chunk tid & 31 = 8 floats)
+        f32x4 d0[8], d1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+            const unsigned off = m < M ? (unsigned)m * (unsigned)D * 4u + (unsigned)(threadIdx.x & 31) * 32u : 0x80000000u;
+            d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dhrs, off, 0, 0));
+            d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dhrs, off, 16, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31;
+            const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+            *reinterpret_cast<u32x4*>(lds + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+        }
+    }
+    // the attention output at this lane's positions (column 64 wave + 32 jt + 8 q + 4 hf .., row m0 + 32 i + l31): requested now
+    f32x4 ov[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const unsigned roff = m < M ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ov[i][jt][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, roff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0));
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+    __builtin_amdgcn_s_barrier();
+    const int sw = l31 & 15;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int slot = ((2 * (4 * st + s2) + hf) ^ sw) << 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(lds + l31 * 512 + slot), a1 = *reinterpret_cast<const bf16x8*>(lds + (32 + l31) * 512 + slot);
+            const bf16x8 w0 = __builtin_bit_cast(bf16x8, wo[st & 1][s2]), w1 = __builtin_bit_cast(bf16x8, wo[st & 1][4 + s2]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+        }
+        if (st + 2 < 4) woload(wo[st & 1], st + 2);
+    }
+    // acc[jt][i][r]: head 2 wave + jt, its column mfma32_row(r, hf), row m0 + 32 i + l31
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31;
+        const unsigned rowoff = m < M ? (unsigned)m * (unsigned)D * 2u : 0x80000000u;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            float dl = 0.f;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 o4 = ov[i][jt][q];
+                dl += acc[jt][i][4 * q] * o4[0] + acc[jt][i][4 * q + 1] * o4[1] + acc[jt][i][4 * q + 2] * o4[2] + acc[jt][i][4 * q + 3] * o4[3];
+                pk[q][0] = pack2(acc[jt][i][4 * q], acc[jt][i][4 * q + 1]);
+                pk[q][1] = pack2(acc[jt][i][4 * q + 2], acc[jt][i][4 * q + 3]);
+            }
+            dl += __shfl_xor(dl, 32, 64);
+            if (hf == 0 && m < M) DELTA[((int64_t)(m / S) * H + 2 * wave + jt) * S + (m % S)] = dl;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {   // runs (q, q+2): lower lanes end with columns 8q..8q+7, upper lanes with 16+8q..
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 2][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 2][1], false, false);
+                const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, dobrs, rowoff + (wave * 64 + 32 * jt + 8 * q + 16 * hf) * 2, 0, 0);
+            }
+        }
+    }
+}
+}  // namespace
+
+// dh fp32 [rows][256] (gradient of h = x + o_proj(attn_out)), attn_out fp32 [rows][256] (H = 8 heads of 32), packed = the block image of
+// gaot_block_pack_multi -> do_image bf16 [rows][256] and delta fp32 [rows / S][8][S] for gaot_attn_bwd_bf16 (phases 16 | 32 without 1 / 8)
+extern "C" int gaot_oproj_bwd_image(const float* dh, const float* attn_out, const void* packed, int F, void* do_image, float* delta,
+                                    int64_t rows, int S, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(dh && attn_out && packed && do_image && delta && rows > 0 && S > 0 && rows % S == 0 && F > 0 && F % FC == 0, "bad argument");
+    GAOT_CHECK_ARG(((uintptr_t)dh % 16) == 0 && ((uintptr_t)attn_out % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)do_image % 16) == 0,
+                   "16-byte alignment");
+    if (rows * (int64_t)D * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_oproj_bwd_image: too many rows for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    const bf16_t* wotp = (const bf16_t*)packed + ((int64_t)2 * F * D + (int64_t)D * F) * 2 + (int64_t)D * D;
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_oproj_bwd, dim3((unsigned)(8 * per)), dim3(256), H_BYTES, (hipStream_t)stream, dh, attn_out, (const u32x4*)wotp, (bf16_t*)do_image,
+                 delta, (int)rows, S, D / 32);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

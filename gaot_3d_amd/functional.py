@@ -64,6 +64,7 @@ _FFN_PACK_CACHE: dict = {}
 _WO_PACKED: dict = {}      # key of a block image that carries the o_proj fragment image -> address of that o_proj weight
 _FFN_FUSED = os.environ.get("GAOT_FFN_FUSED", "1") != "0"
 _BLOCK_TAIL = os.environ.get("GAOT_BLOCK_TAIL", "1") != "0"    # o_proj + residual + ffn_norm + FFN + residual in one forward launch (A/B switch)
+_OPROJ_BWD_IMAGE = os.environ.get("GAOT_OPROJ_BWD_IMAGE", "1") != "0"   # BlockTailFn.backward hands dO over as the flash backward's image (A/B switch)
 _NORM_FFN = os.environ.get("GAOT_NORM_FFN", "1") != "0"        # the block's ffn_norm inside the fused FFN forward (A/B switch)
 _FFN_BWD_DX = os.environ.get("GAOT_FFN_BWD_DX", "1") != "0"      # the input gradient inside the fused backward launch (A/B switch)
 
@@ -427,6 +428,13 @@ class AttentionFn(Function):
         if ctx.hp is not None:       # this rank's heads of the (replicated) output gradient
             grk = ctx.hp[2]
             d_o = d_o[:, grk * h * 32:(grk + 1) * h * 32]
+        pre = getattr(d_o, "_gaot_do_image", None)     # BlockTailFn.backward: dO already is the kernels' bf16 image, delta is formed
+        if pre is not None and not (bf16 and ctx.hp is None):
+            raise GaotError("a dO image placeholder reached an attention backward that needs the fp32 gradient")
+        if pre is not None:
+            dqkv = ops.attn_bwd_bf16(keep, o, None, lse, b, s, h, hkv, scale, dropout_p, seed, freqs if rope else None,
+                                     do_image=pre[0], delta=pre[1], head0=ctx.heads[0], heads_total=ctx.heads[1])
+            return dqkv, None, None, None, None, None, None, None, None, None
         d = d_o if d_o.is_contiguous() else d_o.contiguous()
         if bf16:   # inverse RoPE of dq / dk happens in the kernels' epilogues (-0.15 ms per step against a separate pass)
             dqkv = ops.attn_bwd_bf16(keep, o, d, lse, b, s, h, hkv, scale, dropout_p, seed, freqs if rope else None,
@@ -764,7 +772,11 @@ class BlockTailFn(Function):
                 and NormFFNFn.eligible(x, norm_w, w1, w3, w2))
 
     @staticmethod
-    def forward(ctx, o: Tensor, x: Tensor, wo: Tensor, norm_w: Tensor, eps: float, w1: Tensor, w3: Tensor, w2: Tensor):
+    def forward(ctx, o: Tensor, x: Tensor, wo: Tensor, norm_w: Tensor, eps: float, w1: Tensor, w3: Tensor, w2: Tensor, attn_dims=None):
+        """``attn_dims`` = (b, s, heads, kv heads) when ``o`` comes straight out of AttentionFn's bf16 kernels (8 heads of 32, unsharded):
+        the backward then hands its gradient over as the flash backward's bf16 dO image + row constants (gaot_oproj_bwd_image) on a
+        shape-only placeholder -- the fp32 d_o and the preparation pass over it never exist"""
+        ctx.attn_dims = attn_dims if (attn_dims is not None and _OPROJ_BWD_IMAGE and attn_dims[2] == 8 and attn_dims[0] * attn_dims[1] == o.shape[0]) else None
         f, d = w1.shape
         o2 = o if o.is_contiguous() else o.contiguous()
         x2 = x if x.is_contiguous() else x.contiguous()
@@ -791,9 +803,17 @@ class BlockTailFn(Function):
         dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
         dh, dnw = ops.rmsnorm_bwd(h, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
-        d_o = ops.gemm(dh, wob, m, d, d, d, d, False, False, precision=1) if ctx.needs_input_grad[0] else None
+        d_o = None
+        if ctx.needs_input_grad[0]:
+            if ctx.attn_dims is not None:
+                b_, s_, h_, hkv_ = ctx.attn_dims
+                img, delta = ops.oproj_bwd_image(dh, o2, packed, f, b_, s_, h_, hkv_)
+                d_o = torch.empty(1, dtype=torch.float32, device=dh.device).expand(m, d)      # shape only
+                d_o._gaot_do_image = (img, delta)
+            else:
+                d_o = ops.gemm(dh, wob, m, d, d, d, d, False, False, precision=1)
         dwo = _dw_gemm(dh, o2, d, d, m, d, d, 1, (ctx.oparam,)).view(woshape)
-        return d_o, (dh if ctx.needs_input_grad[1] else None), dwo, dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
+        return d_o, (dh if ctx.needs_input_grad[1] else None), dwo, dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2, None
 
 
 class Mlp2Fn(Function):

@@ -157,6 +157,11 @@ class GroupQueryFlashAttention(nn.Module):
             o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp,
                                      getattr(self, "_head_group", None))
         if not project:
+            if (self.head_dim == 32 and seq_group is None and getattr(self, "_head_group", None) is None and o.dim() == 2
+                    and o.shape[0] == b * s):
+                # straight out of AttentionFn: its backward can take dO as the kernels' bf16 image (functional.BlockTailFn)
+                o._gaot_attn_dims = (b, s, self.num_heads, self.num_kv_heads)
+                return o
             return o.reshape(b * s, -1)
         y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
         return y.view(b, s, -1)
@@ -263,7 +268,7 @@ class TransformerBlock(nn.Module):
                 o = self.attn(h, condition=condition, relative_positions=relative_positions, project=False)
                 b, s, d = x.shape
                 out = GF.BlockTailFn.apply(o, xres.reshape(b * s, d), self.attn.o_proj.weight, self.ffn_norm.weight, self.ffn_norm.eps,
-                                           f.w1.weight, f.w3.weight, f.w2.weight).view(b, s, d)
+                                           f.w1.weight, f.w3.weight, f.w2.weight, getattr(o, "_gaot_attn_dims", None)).view(b, s, d)
                 return (out, tap) if asked else out
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
         if self.ffn_norm is not None and f.correction is None and h.is_cuda and h.shape[-1] == 256 and torch.is_grad_enabled():

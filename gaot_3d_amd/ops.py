@@ -663,7 +663,8 @@ def attn_bwd_scratch(b: int, s: int, h: int, hkv: int, device) -> Tensor:
 
 def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b: int, s: int, h: int, hkv: int, scale: float,
                   dropout_p: float = 0.0, seed: Optional[Tensor] = None, freqs: Optional[Tensor] = None,
-                  do_image: Optional[Tensor] = None, fused: Optional[bool] = None, head0: int = 0, heads_total: int = 0) -> Tensor:
+                  do_image: Optional[Tensor] = None, fused: Optional[bool] = None, head0: int = 0, heads_total: int = 0,
+                  delta: Optional[Tensor] = None) -> Tensor:
     """``freqs``: the forward's RoPE frequencies -> the returned dq / dk are w.r.t. the UNrotated projection.
     ``do_image`` (instead of d_o): an attn_bwd_scratch buffer whose head already holds the bf16 dO (sequence-parallel
     exchange): only delta is computed from it.
@@ -673,7 +674,11 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b:
     dp, sp = _drop_args(dropout_p, seed)
     dev = o.device
     dqkv = torch.empty(b * s, (h + 2 * hkv) * 32, dtype=torch.float32, device=dev)
-    delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
+    have_delta = delta is not None      # ``delta`` (with do_image): the row constants are already there too (oproj_bwd_image): no first phase
+    if have_delta and (do_image is None or tuple(delta.shape) != (b, h, s) or delta.dtype != torch.float32):
+        raise GaotError("attn_bwd_bf16: delta needs do_image and the shape [b, h, s]")
+    if not have_delta:
+        delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     doimg = do_image if do_image is not None else attn_bwd_scratch(b, s, h, hkv, dev)
     can_fuse = bool(lib.gaot_attn_bwd_bf16_fused_eligible(b, s, h, hkv))
     if fused and not can_fuse:
@@ -681,7 +686,8 @@ def attn_bwd_bf16(img: Tensor, o: Tensor, d_o: Optional[Tensor], lse: Tensor, b:
                         "parts of >= 1024 rows) and <= 1 GiB of dQ slab partials")
     phases = ((("attn_bwd", 16), ("attn_bwd_dq_reduce", 32)) if (can_fuse if fused is None else fused)
               else (("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)))
-    for name, mask in (("attn_bwd_delta", 8 if do_image is not None else 1),) + phases:
+    first = () if have_delta else (("attn_bwd_delta", 8 if do_image is not None else 1),)
+    for name, mask in first + phases:
         with _timed(name):
             check(lib.gaot_attn_bwd_bf16(_ptr(img), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(doimg), _ptr(delta), _ptr(dqkv),
                                          _ptr(freqs), b, s, h, hkv, 32, float(scale), dp, sp, int(head0), int(heads_total), mask,
@@ -917,6 +923,21 @@ def block_tail_fwd(attn_out: Tensor, x: Tensor, norm_weight: Tensor, eps: float,
         check(lib.gaot_block_tail_fwd(_ptr(attn_out), attn_out.stride(0), _ptr(x), x.stride(0), _ptr(nw), float(eps), _ptr(packed), _ptr(h),
                                       _ptr(y), _ptr(yb), _ptr(rstd), rows, int(f), _stream()), "gaot_block_tail_fwd")
     return y, h, yb, rstd
+
+
+def oproj_bwd_image(dh: Tensor, attn_out: Tensor, packed: Tensor, f: int, b: int, s: int, h: int, hkv: int):
+    """d_o = dh Wo as the flash backward's operands (include/gaot3d_hip.h: gaot_oproj_bwd_image): -> (an attn_bwd_scratch buffer whose head
+    holds the bf16 dO image, delta fp32 [b, h, s]) for attn_bwd_bf16(do_image=..., delta=...)"""
+    lib = _lib.load()
+    rows = dh.shape[0]
+    if h != 8 or rows != b * s or any(t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (rows, 256) for t in (dh, attn_out)):
+        raise GaotError("oproj_bwd_image: contiguous fp32 [b * s, 256] tensors and 8 heads of 32 expected")
+    scratch = attn_bwd_scratch(b, s, h, hkv, dh.device)
+    delta = torch.empty(b, h, s, dtype=torch.float32, device=dh.device)
+    with _timed("oproj_bwd_image"):
+        check(lib.gaot_oproj_bwd_image(_ptr(dh), _ptr(attn_out), _ptr(packed), int(f), _ptr(scratch), _ptr(delta), rows, int(s), _stream()),
+              "gaot_oproj_bwd_image")
+    return scratch, delta
 
 
 def norm_ffn_fwd(h: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, f: int):

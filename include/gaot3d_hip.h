@@ -338,6 +338,11 @@ int64_t gaot_block_packed_bytes(int F);
 int gaot_block_pack_multi(const gaot_block_pack_t* items, int num, int F, gaot_stream_t stream);
 int gaot_block_tail_fwd(const float* attn_out, int64_t ldo, const float* x, int64_t ldx, const float* norm_weight, float eps,
                         const void* packed, float* h, float* y, void* yb, float* rstd, int64_t rows, int F, gaot_stream_t stream);
+/* the o_proj backward's input gradient d_o = dh Wo written straight as the flash backward's operands (attn.py:122-127 autograd): the
+ * bf16 dO image [rows][256] and delta[rows / S][8][S] = sum over a head's 32 columns of d_o * attn_out -- stands in for gaot_gemm_ex and
+ * phase 1 of gaot_attn_bwd_bf16 (call it with phases 16 | 32 only).  packed: a block image of gaot_block_pack_multi. */
+int gaot_oproj_bwd_image(const float* dh, const float* attn_out, const void* packed, int F, void* do_image, float* delta, int64_t rows,
+                         int S, gaot_stream_t stream);
 /* the first half of the backward for a forward that saved nothing (ag = u = NULL above): a | g recomputed from x, du = dy W2, the
  * SwiGLU derivative -> dag = d(a) | d(g) (bf16 [rows][2F]), u = silu(a) g (bf16 [rows][F]), dyb = bf16(dy) ([rows][256], optional):
  * the operands of the dx = dag W13, dW13 = dag^T x and dW2 = dyb^T u products.  packed: gaot_ffn_pack WITH the backward images.
