@@ -1489,3 +1489,257 @@ extern "C" int gaot_oproj_bwd_image(const float* dh, const float* attn_out, cons
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
+
+// ---- the head of a Transformer block in one launch (reference attn.py:104-109, 118-120, 226: q / k / v projections of attn_norm(x), rotary
+// embedding of q and k): x fp32 [rows][ldx] -> the attention kernels' bf16 image [rows][N] (N = (H + 2 HKV) * 32, a multiple of 256; RoPE
+// from the [S][16] (cos, sin) table, q pre-scaled), yb = bf16(attn_norm(x)) (the weight-gradient product's operand) and rstd.  Stands in
+// for gaot_rmsnorm_fwd + gaot_qkv_image (a read and two writes of [rows][256] less, one launch instead of two).  Row blocks of 64; the
+// weights (N x 256) stream from L2 as fragment blocks (((p*4 + w)*2 + jt)*16 + s: row 256 p + 64 w + 32 jt + l31, k = 16 s + 8 hf + e):
+// panel p = 256 output columns, wave w its heads 8 p + 2 w, + 1.  Arithmetic: the norm as in k_rmsnorm_fwd, the product and the epilogue as
+// in k_gemm_k256<OUT_QKV_IMAGE> -- same values.
+namespace {
+struct QkvTable {
+    const float* w[PACK_MAX];
+    bf16_t* packed[PACK_MAX];
+};
+// blockIdx.y = the block; N x 256 weights -> fragment image (and, with_backward, the image of the transpose for the input gradient:
+// block ((w*2 + jt)*(N/16) + s): "row" j = 64 w + 32 jt + l31 (the norm's column), k = 16 s + 8 hf + e over the N output columns -> w[k][j])
+__global__ void k_qkv_pack(QkvTable t, int N, int with_backward) {
+    const float* w = t.w[blockIdx.y];
+    bf16_t* p = t.packed[blockIdx.y];
+    const int nfr = N * D / 8;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < nfr * (with_backward ? 2 : 1); id += gridDim.x * blockDim.x) {
+        if (id < nfr) {
+            const int lane = id & 63, s2 = (id >> 6) & 15, jt = (id >> 10) & 1, wv = (id >> 11) & 3, pn = id >> 13;
+            const float* src = w + (int64_t)(256 * pn + 64 * wv + 32 * jt + (lane & 31)) * D + 16 * s2 + 8 * (lane >> 5);
+            *reinterpret_cast<u32x4*>(p + (int64_t)id * 8) = u32x4{pack2(src[0], src[1]), pack2(src[2], src[3]), pack2(src[4], src[5]), pack2(src[6], src[7])};
+        } else {
+            const int i2 = id - nfr, ns = N / 16;
+            const int lane = i2 & 63, rest = i2 >> 6, s2 = rest % ns, jt = (rest / ns) & 1, wv = rest / (2 * ns);
+            const float* st = w + (int64_t)(16 * s2 + 8 * (lane >> 5)) * D + (wv * 64 + jt * 32 + (lane & 31));
+            *reinterpret_cast<u32x4*>(p + (int64_t)id * 8) =
+                u32x4{pack2(st[0], st[D]), pack2(st[2 * D], st[3 * D]), pack2(st[4 * D], st[5 * D]), pack2(st[6 * D], st[7 * D])};
+        }
+    }
+}
+
+struct QkvArgs {
+    const float* X; int ldx; const float* NW; float eps; const u32x4* Wp; bf16_t* IMG; bf16_t* YB; float* RSTD;
+    const float* table; int S, nq, nk; float qscale; int M, N;
+};
+constexpr int QKV_LDS = H_BYTES + 256;
+__global__ __launch_bounds__(256, 1) void k_norm_qkv(QkvArgs a) {
+    constexpr int RD = 3, LA = 2;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int M = a.M, N = a.N, NP = N / 256;
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wp, 0, N * D * 2, 0x00020000);
+    // step g = 4 p + st of this wave: the k-slice st (64 deep) of panel p, 8 blocks (tiles jt 0, 1 x 4 k-steps); past the last: zeros
+    u32x4 wr[RD][8];
+    auto wload = [&](u32x4 (&dst)[8], int g) {
+        const int pn = g >> 2, st = g & 3;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, ((((pn * 4 + wv) * 2 + jt) * 16) + 4 * st + s2) * 1024, 0));
+    };
+    wload(wr[0], 0);
+    wload(wr[1], 1);
+    float* rstd_l = reinterpret_cast<float*>(lds + H_BYTES);
+    {   // attn_norm: rows 16 wave .. + 15, a lane per float4 (the arithmetic and summation order of k_rmsnorm_fwd, rowops.hip)
+        const int64_t xbytes = (int64_t)M * a.ldx * 4, ybbytes = (int64_t)M * D * 2;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.YB, 0, (int)(ybbytes > 0x7fffffff ? 0x7fffffff : ybbytes), 0x00020000);
+        const float4 g = reinterpret_cast<const float4*>(a.NW)[lane];
+        float4 v[16];
+        float ss[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = m0 + wave * 16 + j;
+            v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, m < M ? (unsigned)m * (unsigned)a.ldx * 4u + lane * 16u : 0x80000000u, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            ss[j] = 0.f;
+            ss[j] += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ss[j] += __shfl_xor(ss[j], o, 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int rl = wave * 16 + j, m = m0 + rl;
+            const float r = rsqrtf(ss[j] / (float)D + a.eps);
+            const float4 o = make_float4(v[j].x * r * g.x, v[j].y * r * g.y, v[j].z * r * g.z, v[j].w * r * g.w);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 pk = {pack2(o.x, o.y), pack2(o.z, o.w)};
+            *reinterpret_cast<u32x2*>(lds + rl * 512 + ((((lane >> 1) ^ (rl & 15))) << 4) + 8 * (lane & 1)) = pk;
+            __builtin_amdgcn_raw_buffer_store_b64(pk, ybrs, m < M ? (unsigned)m * (unsigned)D * 2u + lane * 8u : 0x80000000u, 0, 0);
+            if (lane == 0) {
+                rstd_l[rl] = r;
+                if (m < M) a.RSTD[m] = r;
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    const int64_t ibytes = (int64_t)M * N * 2;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)a.IMG, 0, (int)(ibytes > 0x7fffffff ? 0x7fffffff : ibytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table ? a.S * 128 : 0, 0x00020000);
+    const int sw = l31 & 15;
+    const char* hb = lds + l31 * 512;
+    // the (cos, sin) pairs of this lane's rows and column runs: the same for every head -- requested once, here (in the panel epilogues
+    // every one of these 16-byte loads sat in front of its use: an exposed L2 round trip per batch)
+    f32x4 tab[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31, mm = m < M ? m : M - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tab[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, (mm % a.S) * 128 + 16 * hf + 32 * q, 0, 0));
+    }
+    // the product of panel pn + 1 (MFMAs) carries the epilogue of panel pn (vector instructions, stores) between its k-steps: two
+    // accumulator sets; a panel past the last reads zero weights (buffer range check) -- one product too many instead of a second copy
+    // of the loop body
+    f32x16 accc[2][2], accn[2][2];
+    bf16x8 hn0 = *reinterpret_cast<const bf16x8*>(hb + ((hf ^ sw) << 4)), hn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + ((hf ^ sw) << 4));
+    // one 64-deep step (four k-steps) of panel pn into acc; epi(k-step) after each k-step's MFMAs
+    auto panel_step = [&](f32x16 (&acc)[2][2], int pn, int st, auto epi) {
+        const int g = 4 * pn + st;
+        auto run = [&](auto rot) {
+            constexpr int R = decltype(rot)::value;        // R = (4 pn) % 3: the ring slot of step g is (R + st) % 3
+            wload(wr[(R + st + LA) % RD], g + LA);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 h0 = hn0, h1 = hn1;
+                const int slot = ((2 * ((4 * st + s2 + 1) & 15) + hf) ^ sw) << 4;
+                hn0 = *reinterpret_cast<const bf16x8*>(hb + slot);
+                hn1 = *reinterpret_cast<const bf16x8*>(hb + 32 * 512 + slot);
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wr[(R + st) % RD][s2]), w1 = __builtin_bit_cast(bf16x8, wr[(R + st) % RD][4 + s2]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, h0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, h0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, h1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, h1, acc[1][1], 0, 0, 0);
+                epi(4 * st + s2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+            }
+        };
+        const int rot = (4 * pn) % 3;
+        if (rot == 0) run(std::integral_constant<int, 0>{});
+        else if (rot == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    };
+    auto zero4 = [&](f32x16 (&acc)[2][2]) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+    };
+    zero4(accc);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) panel_step(accc, 0, st, [](int) {});
+    for (int pn = 0; pn < NP; ++pn) {
+        // epilogue of panel pn in eight pieces (k-steps 0, 2, .., 14 of the next panel's product): piece e = (row tile i = e >> 2, head tile
+        // jt = (e >> 1) & 1, run pair q = e & 1 with q + 2).  accc[jt][i][r] = head 8 pn + 2 wave + jt, its column mfma32_row(r, hf), row
+        // m0 + 32 i + l31; the lane holds runs of 4 consecutive columns 8q + 4hf .. +3 = two rotation pairs (frequencies 4q + 2hf, + 1)
+        auto piece = [&](int e) {
+            const int i = e >> 2, jt = (e >> 1) & 1, q0 = e & 1;
+            const int m = m0 + 32 * i + l31;
+            const unsigned rowoff = m < M ? (unsigned)m * (unsigned)N * 2u : 0x80000000u;
+            const int head = 8 * pn + 2 * wave + jt;
+            const bool rope = a.table && head < a.nq + a.nk;
+            const float sc = head < a.nq ? a.qscale : 1.0f;
+            unsigned pk[2][2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int q = q0 + 2 * h2;
+                float v0 = accc[jt][i][4 * q], v1 = accc[jt][i][4 * q + 1], v2 = accc[jt][i][4 * q + 2], v3 = accc[jt][i][4 * q + 3];
+                if (rope) {
+                    const f32x4 tb = tab[i][q];   // cos, sin, cos, sin
+                    const float r0 = v0 * tb[0] - v1 * tb[1], r1 = v1 * tb[0] + v0 * tb[1];
+                    const float r2 = v2 * tb[2] - v3 * tb[3], r3 = v3 * tb[2] + v2 * tb[3];
+                    v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+                }
+                pk[h2][0] = pack2(v0 * sc, v1 * sc);
+                pk[h2][1] = pack2(v2 * sc, v3 * sc);
+            }
+            // runs (q, q+2): lower lanes end with columns 8q..8q+7, upper lanes with 16+8q..
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(v, irs, rowoff + (head * 32 + 8 * q0 + 16 * hf) * 2, 0, 0);
+        };
+        zero4(accn);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            panel_step(accn, pn + 1, st, [&](int ks) { if ((ks & 1) == 0) piece(ks >> 1); });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accc[jt][i] = accn[jt][i];
+    }
+}
+}  // namespace
+
+extern "C" int64_t gaot_qkv_packed_bytes(int64_t N, int with_backward) { return N * D * 2 * (with_backward ? 2 : 1); }
+
+// fp32 co-located q | k | v weights ([N][256], N = (H + 2 HKV) * 32, a multiple of 256) of every block -> fragment images, one launch
+extern "C" int gaot_qkv_pack_multi(const gaot_qkv_pack_t* items, int num, int64_t N, int with_backward, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(items && num > 0 && N > 0 && N % 256 == 0, "bad argument (N must be a multiple of 256)");
+    for (int i0 = 0; i0 < num; i0 += PACK_MAX) {
+        QkvTable t{};
+        const int n = std::min(PACK_MAX, num - i0);
+        for (int i = 0; i < n; ++i) {
+            GAOT_CHECK_ARG(items[i0 + i].w && items[i0 + i].packed && ((uintptr_t)items[i0 + i].packed % 16) == 0, "null or misaligned pointer in the table");
+            t.w[i] = items[i0 + i].w; t.packed[i] = (bf16_t*)items[i0 + i].packed;
+        }
+        GAOT_KLAUNCH(k_qkv_pack, dim3((unsigned)std::min<int64_t>(ceil_div(N * D / 8 * (with_backward ? 2 : 1), 256), 256), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, t, (int)N, with_backward);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+extern "C" int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* norm_weight, float eps, const void* packed, void* image, void* yb,
+                                   float* rstd, int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream) {
+    GAOT_ENTER();
+    const int64_t N = (int64_t)(H + 2 * HKV) * 32;
+    GAOT_CHECK_ARG(x && norm_weight && packed && image && yb && rstd && rows > 0 && S > 0 && H > 0 && HKV > 0 && N % 256 == 0,
+                   "bad argument ((H + 2 HKV) * 32 must be a multiple of 256)");
+    GAOT_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)image % 16) == 0 &&
+                   ((uintptr_t)yb % 16) == 0 && ldx % 4 == 0 && ldx >= D, "16-byte alignment");
+    if (rows * N * 2 >= 0x7fffffff || rows * ldx * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_norm_qkv_image: too many rows for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_norm_qkv, hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("norm_qkv: cannot set dynamic LDS %d: %s", QKV_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const QkvArgs a{x, (int)ldx, norm_weight, eps, (const u32x4*)packed, (bf16_t*)image, (bf16_t*)yb, rstd, rope_table, S, H, HKV, qscale, (int)rows, (int)N};
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_norm_qkv, dim3((unsigned)(8 * per)), dim3(256), QKV_LDS, (hipStream_t)stream, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}

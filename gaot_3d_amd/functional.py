@@ -103,10 +103,31 @@ def prepack_ffn(pairs, with_backward: bool, wos=None) -> None:
                 _WO_PACKED[(w13.data_ptr(), tuple(w13.shape))] = wo.data_ptr()
 
 
+_QKV_PACK_CACHE: dict = {}       # (address, shape) of the co-located fp32 q | k | v weight -> its fragment image (prepack_qkv)
+_NORM_QKV = os.environ.get("GAOT_NORM_QKV", "1") != "0"      # attn_norm + q | k | v image in one launch (A/B switch)
+
+
+def prepack_qkv(wcats) -> None:
+    """``wcats``: the co-located [q; k; v] weight views of the blocks about to run; those the fused head kernel takes (bf16 mode,
+    [N, 256] with N a multiple of 256) are packed by one launch"""
+    _QKV_PACK_CACHE.clear()
+    if not (_NORM_QKV and ops.get_precision() == "bf16"):
+        return
+    by_n: dict = {}
+    for w in wcats:
+        w = _w2d(w)
+        if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == 256 and w.shape[0] % 256 == 0:
+            by_n.setdefault(w.shape[0], []).append(w)
+    for _n, ws in by_n.items():
+        for w, packed in zip(ws, ops.qkv_pack_multi(ws, False)):
+            _QKV_PACK_CACHE[(w.data_ptr(), tuple(w.shape))] = packed
+
+
 def release_precast() -> None:
     _WB_CACHE.clear()
     _WBT_CACHE.clear()
     _FFN_PACK_CACHE.clear()
+    _QKV_PACK_CACHE.clear()
 
 
 def _wbt(w: Tensor) -> Optional[Tensor]:
@@ -753,6 +774,59 @@ class NormFFNFn(Function):
         dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
         dh, dnw = ops.rmsnorm_bwd(h2, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         return dh.view(hshape), dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
+
+
+class NormQKVFn(Function):
+    """attn_norm -> q | k | v projections -> RoPE, written straight as the attention kernels' bf16 image: the HEAD of a Transformer block
+    (reference attn.py:104-109, 118-120, 226) as ONE forward launch (csrc/ffn_fused.hip: k_norm_qkv).  Outputs: the storage-less q | k | v
+    placeholder that carries the image (as MultiLinearFn's), the residual alias of x and, with ``tap``, the skip alias (as RMSNormResFn's).
+    Backward: the input-gradient and weight-gradient products on d(q | k | v), then gaot_rmsnorm_bwd(2) with the residual's and the
+    skip's gradients as addends.  Values: those of RMSNormResFn + MultiLinearFn(image_spec)."""
+
+    @staticmethod
+    def eligible(x: Tensor, norm_w: Tensor, weights, image_spec) -> bool:
+        ws = [_w2d(w) for w in weights]
+        return (_NORM_QKV and ops.get_precision() == "bf16" and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256
+                and image_spec is not None and norm_w.numel() == 256 and torch.is_grad_enabled() and _adjacent(ws)
+                and sum(w.shape[0] for w in ws) % 256 == 0 and all(w.requires_grad for w in weights))
+
+    @staticmethod
+    def forward(ctx, x: Tensor, norm_w: Tensor, eps: float, tap: bool, image_spec, *weights: Tensor):
+        ws = [_w2d(w) for w in weights]
+        ntot = sum(w.shape[0] for w in ws)
+        xc = x if x.is_contiguous() else x.contiguous()
+        x2 = xc.reshape(-1, 256)
+        m = x2.shape[0]
+        wcat32 = ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, 256), (256, 1))
+        packed = _QKV_PACK_CACHE.get((wcat32.data_ptr(), tuple(wcat32.shape)))
+        if packed is None:
+            packed = ops.qkv_pack_multi([wcat32], False)[0]
+        freqs, b, s, h, hkv, scale = image_spec
+        img, yb, rstd = ops.norm_qkv_image(x2, norm_w, eps, packed, b, s, h, hkv, freqs, scale)
+        out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only: no [m, ntot] buffer
+        out._gaot_qkv_image = img
+        ctx.save_for_backward(x2, norm_w, rstd, yb, _wb(wcat32, 1))
+        ctx.wparams, ctx.nparam = tuple(weights), norm_w
+        ctx.meta = (x.shape, [w.shape for w in weights], ntot)
+        ctx.set_materialize_grads(False)
+        ctx.ntap = bool(tap)
+        return (out, xc.detach(), xc.detach()) if tap else (out, xc.detach())
+
+    @staticmethod
+    def backward(ctx, dqkv: Tensor, dres: Optional[Tensor] = None, dtap: Optional[Tensor] = None):
+        x2, norm_w, rstd, yb, wcat = ctx.saved_tensors
+        xshape, wshapes, ntot = ctx.meta
+        m = x2.shape[0]
+        d = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
+        dn = ops.gemm(d, wcat, m, 256, ntot, ntot, 256, False, False, precision=1)
+        dwcat = _dw_gemm(d, yb, ntot, 256, m, ntot, 256, 1, ctx.wparams)
+        dx, dnw = ops.rmsnorm_bwd(x2, norm_w, dn, rstd, None if dres is None else dres.reshape(x2.shape), defer=ops.defer_ok((ctx.nparam,)),
+                                  dx_add2=None if dtap is None else dtap.reshape(x2.shape))
+        dws, col = [], 0
+        for shp in wshapes:
+            dws.append(dwcat[col:col + shp[0]].view(shp))
+            col += shp[0]
+        return (dx.view(xshape), dnw, None, None, None, *dws)
 
 
 class BlockTailFn(Function):

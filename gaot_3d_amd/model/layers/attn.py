@@ -88,11 +88,22 @@ class GroupQueryFlashAttention(nn.Module):
             self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
 
     def forward(self, x, condition: Optional[float] = None, relative_positions: Optional[torch.Tensor] = None,
-                residual: Optional[torch.Tensor] = None, project: bool = True):
+                residual: Optional[torch.Tensor] = None, project: bool = True, qkv: Optional[torch.Tensor] = None):
         """``residual`` (extension): added to the output inside the o_proj GEMM epilogue (the block's `x + attn(...)`).
         ``project=False`` (extension, TransformerBlock): return the heads' outputs [B*S, heads * head_dim] WITHOUT o_proj -- the caller
         applies it (functional.BlockTailFn: o_proj, the residual, ffn_norm and the FFN in one launch)."""
         dp = float(self.atten_dropout) if self.training else 0.0     # reference attn.py:122-126
+        if qkv is not None:
+            # (extension, TransformerBlock) the q | k | v projection already exists as the kernels' image (functional.NormQKVFn): x is only
+            # consulted for its shape; unsharded, head_dim 32
+            b, s, _ = x.shape
+            freqs = self.rotary_emb.freqs if (relative_positions is not None and hasattr(self, "rotary_emb")) else None
+            o = GF.AttentionFn.apply(qkv, freqs, b, s, self.num_heads, self.num_kv_heads, dp, None)
+            if not project:
+                o._gaot_attn_dims = (b, s, self.num_heads, self.num_kv_heads)
+                return o
+            y = GF.linear(o, self.o_proj.weight, None, residual=None if residual is None else residual.reshape(b * s, -1))
+            return y.view(b, s, -1)
         if self.correction is not None:                               # attn.py:101-102
             x = self.correction(c=condition, x=x)
         b, s, _ = x.shape
@@ -253,7 +264,24 @@ class TransformerBlock(nn.Module):
             x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
                               self.skip_proj.bias).view(b, s, -1)
             want_input_tap = False
-        if self.attn_norm is None:
+        qkv = None
+        a = self.attn
+        if (self.attn_norm is not None and x.is_cuda and x.shape[-1] == 256 and torch.is_grad_enabled() and a.correction is None
+                and a.head_dim == 32 and getattr(a, "_seq_group", None) is None and getattr(a, "_head_group", None) is None):
+            GF.colocate([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight])   # (no-op once done)
+            b_, s_, _d = x.shape
+            freqs = a.rotary_emb.freqs if (relative_positions is not None and hasattr(a, "rotary_emb")) else None
+            spec = (freqs, b_, s_, a.num_heads, a.num_kv_heads, 1.0 / (32 ** 0.5))
+            wts = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+            if GF.NormQKVFn.eligible(x, self.attn_norm.weight, wts, spec):
+                # attn_norm, the three projections and RoPE in ONE launch, written as the attention kernels' image
+                outs = GF.NormQKVFn.apply(x, self.attn_norm.weight, self.attn_norm.eps, bool(want_input_tap), spec, *wts)
+                qkv, xres = outs[0], outs[1]
+                tap = outs[2] if want_input_tap else None
+                h = x      # (shape only: the attention module reads the image)
+        if qkv is not None:
+            pass
+        elif self.attn_norm is None:
             h, xres = x, x
         elif want_input_tap and x.is_cuda:
             h, xres, tap = self.attn_norm.forward_with_residual(x, tap=True)
@@ -265,12 +293,12 @@ class TransformerBlock(nn.Module):
             GF.colocate([f.w1.weight, f.w3.weight])     # (no-op once done)
             if GF.BlockTailFn.eligible(xres, self.attn.o_proj.weight, self.ffn_norm.weight, f.w1.weight, f.w3.weight, f.w2.weight):
                 # o_proj, the first residual, ffn_norm, the FFN and the second residual in ONE launch (bf16 mode, d_model 256)
-                o = self.attn(h, condition=condition, relative_positions=relative_positions, project=False)
+                o = self.attn(h, condition=condition, relative_positions=relative_positions, project=False, qkv=qkv)
                 b, s, d = x.shape
                 out = GF.BlockTailFn.apply(o, xres.reshape(b * s, d), self.attn.o_proj.weight, self.ffn_norm.weight, self.ffn_norm.eps,
                                            f.w1.weight, f.w3.weight, f.w2.weight, getattr(o, "_gaot_attn_dims", None)).view(b, s, d)
                 return (out, tap) if asked else out
-        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres)   # x + attn(norm(x))
+        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=xres, qkv=qkv)   # x + attn(norm(x))
         if self.ffn_norm is not None and f.correction is None and h.is_cuda and h.shape[-1] == 256 and torch.is_grad_enabled():
             GF.colocate([f.w1.weight, f.w3.weight])     # (no-op once done)
         if (self.ffn_norm is not None and f.correction is None
@@ -343,6 +371,8 @@ class Transformer(nn.Module):
             # fragment-ordered images for the fused FFN kernels, one launch (with the backward's images when it will run)
             blocks = list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
             GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled(), wos=[blk.attn.o_proj.weight for blk in blocks])
+            GF.prepack_qkv([GF.fused_view([blk.attn.q_proj.weight, blk.attn.k_proj.weight, blk.attn.v_proj.weight]) for blk in blocks]
+                           if torch.is_grad_enabled() else [])
             if self.training and getattr(self, "_seq_group", None) is None and SEED_BLOCK["on"]:
                 # the attention seeds of all blocks with ONE launch (each block draws its own otherwise)
                 n_drop = sum(1 for blk in blocks if float(blk.attn.atten_dropout) > 0.0 and blk.attn.head_dim == 32)

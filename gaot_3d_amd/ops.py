@@ -925,6 +925,48 @@ def block_tail_fwd(attn_out: Tensor, x: Tensor, norm_weight: Tensor, eps: float,
     return y, h, yb, rstd
 
 
+class _QkvPackItem(C.Structure):   # gaot_qkv_pack_t
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p)]
+
+
+def qkv_pack_multi(ws, with_backward: bool) -> List[Tensor]:
+    """the co-located fp32 q | k | v weights ([N, 256]) of every block as fragment images in ONE launch (gaot_qkv_pack_multi)"""
+    lib = _lib.load()
+    ws = list(ws)
+    if not ws:
+        return []
+    n = ws[0].shape[0]
+    nb = int(lib.gaot_qkv_packed_bytes(n, int(with_backward)))
+    buf = torch.empty(len(ws) * nb, dtype=torch.uint8, device=ws[0].device)
+    outs = [buf[i * nb:(i + 1) * nb] for i in range(len(ws))]
+    items = (_QkvPackItem * len(ws))()
+    for i, (w, o) in enumerate(zip(ws, outs)):
+        if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (n, 256):
+            raise GaotError("qkv_pack_multi: contiguous fp32 [N, 256] weights of one N expected")
+        items[i] = _QkvPackItem(w.data_ptr(), o.data_ptr())
+    check(lib.gaot_qkv_pack_multi(items, len(ws), n, int(with_backward), _stream()), "gaot_qkv_pack_multi")
+    return outs
+
+
+def norm_qkv_image(x: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, b: int, s: int, h: int, hkv: int, freqs: Optional[Tensor],
+                   scale: float):
+    """attn_norm + q | k | v projection written as the attention kernels' bf16 image in one launch (gaot_norm_qkv_image) ->
+    (image, yb = bf16(norm(x)) [rows, 256], rstd [rows])"""
+    lib = _lib.load()
+    rows = x.shape[0]
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 256 or x.stride(1) != 1 or rows != b * s:
+        raise GaotError("norm_qkv_image: fp32 [b * s, 256] input expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), x.device)
+    yb = torch.empty(rows, 256, dtype=torch.bfloat16, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    table = rope_table(freqs, s) if freqs is not None else None
+    with _timed("norm_qkv_image"):
+        check(lib.gaot_norm_qkv_image(_ptr(x), x.stride(0), _ptr(nw), float(eps), _ptr(packed), _ptr(img), _ptr(yb), _ptr(rstd), rows, s, h, hkv,
+                                      _ptr(table), _qscale(scale), _stream()), "gaot_norm_qkv_image")
+    return img, yb, rstd
+
+
 def oproj_bwd_image(dh: Tensor, attn_out: Tensor, packed: Tensor, f: int, b: int, s: int, h: int, hkv: int):
     """d_o = dh Wo as the flash backward's operands (include/gaot3d_hip.h: gaot_oproj_bwd_image): -> (an attn_bwd_scratch buffer whose head
     holds the bf16 dO image, delta fp32 [b, h, s]) for attn_bwd_bf16(do_image=..., delta=...)"""

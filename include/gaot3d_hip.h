@@ -338,6 +338,18 @@ int64_t gaot_block_packed_bytes(int F);
 int gaot_block_pack_multi(const gaot_block_pack_t* items, int num, int F, gaot_stream_t stream);
 int gaot_block_tail_fwd(const float* attn_out, int64_t ldo, const float* x, int64_t ldx, const float* norm_weight, float eps,
                         const void* packed, float* h, float* y, void* yb, float* rstd, int64_t rows, int F, gaot_stream_t stream);
+/* the head of a Transformer block in one launch (attn.py:104-109, 118-120, 226): q | k | v projections of attn_norm(x) written as the
+ * attention kernels' bf16 image (RoPE, q pre-scaled) -- gaot_rmsnorm_fwd + gaot_qkv_image without the fp32 / bf16 round trip of the
+ * normalised rows; yb = bf16(attn_norm(x)) and rstd are written for the backward.  gaot_qkv_pack_multi: the co-located fp32 weights
+ * ([N][256], N = (H + 2 HKV) * 32 a multiple of 256) of all blocks as fragment images (with_backward: + the transposed image). */
+typedef struct {
+    const float* w; /* [N][256] */
+    void* packed;   /* gaot_qkv_packed_bytes(N, with_backward) bytes, 16-byte aligned */
+} gaot_qkv_pack_t;
+int64_t gaot_qkv_packed_bytes(int64_t N, int with_backward);
+int gaot_qkv_pack_multi(const gaot_qkv_pack_t* items, int num, int64_t N, int with_backward, gaot_stream_t stream);
+int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* norm_weight, float eps, const void* packed, void* image, void* yb,
+                        float* rstd, int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
 /* the o_proj backward's input gradient d_o = dh Wo written straight as the flash backward's operands (attn.py:122-127 autograd): the
  * bf16 dO image [rows][256] and delta[rows / S][8][S] = sum over a head's 32 columns of d_o * attn_out -- stands in for gaot_gemm_ex and
  * phase 1 of gaot_attn_bwd_bf16 (call it with phases 16 | 32 only).  packed: a block image of gaot_block_pack_multi. */

@@ -135,7 +135,7 @@ def test_fused_backward_with_input_gradient(rows, f, add_dy):
     assert e_gemm < 1e-5 and e_ref < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["norm_ffn", "block_tail", "oproj_image"])
+@pytest.mark.parametrize("mode", ["norm_ffn", "block_tail", "oproj_image", "norm_qkv", "norm_qkv_rope"])
 @pytest.mark.parametrize("rows,f", [(16384, 1024), (1000, 256)])
 def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
     """NormFFNFn (ffn_norm + FFN + residual in one forward launch, reference attn.py:227-229) and BlockTailFn (o_proj and the first
@@ -145,10 +145,13 @@ def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
     from gaot_3d_amd import functional as GF
     from gaot_3d_amd.model.layers import attn as A
     torch.manual_seed(4)
-    blk = A.TransformerBlock(256, 256, attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0),
+    pe = "rope" if mode == "norm_qkv_rope" else "absolute"
+    blk = A.TransformerBlock(256, 256, attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0,
+                                                                      positional_embedding=pe),
                              ffn_config=A.FFNConfig(hidden_size=f)).to(DEV).train()
     with torch.no_grad():
         blk.ffn_norm.weight.add_(0.1 * torch.randn(256, device=DEV))
+        blk.attn_norm.weight.add_(0.1 * torch.randn(256, device=DEV))
     x = torch.randn(1, rows, 256, device=DEV, requires_grad=True)
     gaot_3d_amd.set_precision("bf16")
     out = {}
@@ -157,17 +160,18 @@ def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
             GF._NORM_FFN = on if mode == "norm_ffn" else True
             GF._BLOCK_TAIL = on if mode == "block_tail" else (mode == "oproj_image")
             GF._OPROJ_BWD_IMAGE = on if mode == "oproj_image" else False
+            GF._NORM_QKV = on if mode.startswith("norm_qkv") else False
             for p in blk.parameters():
                 p.grad = None
             x.grad = None
-            y = blk(x)
+            y = blk(x, relative_positions=True if pe == "rope" else None)
             y.square().mean().backward()
             torch.cuda.synchronize()
-            out[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+            out[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
     finally:
-        GF._NORM_FFN = GF._BLOCK_TAIL = GF._OPROJ_BWD_IMAGE = True
+        GF._NORM_FFN = GF._BLOCK_TAIL = GF._OPROJ_BWD_IMAGE = GF._NORM_QKV = True
         gaot_3d_amd.set_precision("fp32")
-    names = ["y", "dx"] + [n for n, _ in blk.named_parameters()]
+    names = ["y", "dx"] + [n for n, p in blk.named_parameters() if p.requires_grad]
     # the row sum of squares is contracted in another order than in k_rmsnorm_fwd: 1/rms differs in its last bit for some rows and the bf16
     # rounding of a normalised element flips now and then -- the two paths agree to bf16 rounding noise, not bit for bit
     worst = 0.0
