@@ -849,6 +849,71 @@ __global__ __launch_bounds__(256, 1) void k_ffn_bwd(const bf16_t* __restrict__ X
     }
 }
 
+// ---- RMSNorm backward as the epilogue of a product that leaves d(norm(x)) in the accumulators (reference attn.py:167-178 autograd) ----
+// dn[jt][i][r] = gradient w.r.t. the normalised rows: column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31.  Writes
+//   dx = r w dn - x r^3 mean(x w dn) (+ dres) (+ dtap)   (fp32 [M][256]; dres / dtap: gradients reaching x through its other consumers)
+//   dwp[blk][256] = sum over the block's 64 rows of dn x r   (one partial row per workgroup, summed later in fixed order)
+// A row's dot product is the sum of the four waves' 64-column partials (through LDS, wave order); the column sums walk the block's
+// rows in order through a [64][260] fp32 LDS image (pitch 1 040 B: the 16-byte stores of eight consecutive rows cover all banks).
+// `lds` must be free for 64 * 1040 + 1024 bytes; every wave of the workgroup calls this (two barriers inside).
+constexpr int NB_PITCH = 260, NB_LDS = 64 * NB_PITCH * 4 + 1024;
+__device__ __forceinline__ void norm_bwd_epilogue(f32x16 (&dn)[2][2], char* lds, const float* __restrict__ X, int ldx, const float* __restrict__ NW,
+                                                  const float* __restrict__ RSTD, const float* __restrict__ DRES, const float* __restrict__ DTAP,
+                                                  float* __restrict__ DX, float* __restrict__ DWP, int M, int m0, int blk) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    float* T = reinterpret_cast<float*>(lds);
+    float* part = reinterpret_cast<float*>(lds + 64 * NB_PITCH * 4);      // [4 waves][64 rows]
+    f32x4 xv[2][2][4];
+    float rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * i + l31, mm = m < M ? m : M - 1;
+        rs[i] = RSTD[mm];
+        float dot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = wave * 64 + 32 * jt + 8 * q + 4 * hf;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(X + (int64_t)mm * ldx + col), g = *reinterpret_cast<const f32x4*>(NW + col);
+                xv[i][jt][q] = v;
+                const f32x4 d = {dn[jt][i][4 * q], dn[jt][i][4 * q + 1], dn[jt][i][4 * q + 2], dn[jt][i][4 * q + 3]};
+                dot += v[0] * d[0] * g[0] + v[1] * d[1] * g[1] + v[2] * d[2] * g[2] + v[3] * d[3] * g[3];
+                const f32x4 tt = {d[0] * v[0] * rs[i], d[1] * v[1] * rs[i], d[2] * v[2] * rs[i], d[3] * v[3] * rs[i]};
+                *reinterpret_cast<f32x4*>(T + (32 * i + l31) * NB_PITCH + col) = tt;
+            }
+        dot += __shfl_xor(dot, 32, 64);
+        if (hf == 0) part[wave * 64 + 32 * i + l31] = dot;
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = 32 * i + l31, m = m0 + ml;
+        const float dot = ((part[ml] + part[64 + ml]) + part[128 + ml]) + part[192 + ml];
+        const float r = rs[i], c = dot * r * r * r / (float)D;
+        if (m < M) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = wave * 64 + 32 * jt + 8 * q + 4 * hf;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(NW + col), v = xv[i][jt][q];
+                    f32x4 o = {r * g[0] * dn[jt][i][4 * q] - v[0] * c, r * g[1] * dn[jt][i][4 * q + 1] - v[1] * c,
+                               r * g[2] * dn[jt][i][4 * q + 2] - v[2] * c, r * g[3] * dn[jt][i][4 * q + 3] - v[3] * c};
+                    if (DRES) o += *reinterpret_cast<const f32x4*>(DRES + (int64_t)m * D + col);
+                    if (DTAP) o += *reinterpret_cast<const f32x4*>(DTAP + (int64_t)m * D + col);
+                    *reinterpret_cast<f32x4*>(DX + (int64_t)m * D + col) = o;
+                }
+        }
+    }
+    {   // column sums of dn x r over the block's rows, row order (rows past M hold zeros: their dn is a product of zero-filled loads)
+        float sum = 0.f;
+#pragma unroll 8
+        for (int row = 0; row < 64; ++row) sum += T[row * NB_PITCH + threadIdx.x];
+        DWP[(int64_t)blk * D + threadIdx.x] = sum;
+    }
+}
+
 // The same pass WITH the input gradient: dx = dag W13 (+ dy when the block's residual is the FFN's own input, attn.py:229) accumulated
 // chunk by chunk from the dag chunk in LDS -- the dag tensor is written for the dW13 product but not read back for dx, and the
 // stand-alone dx GEMM (K = 2F) is gone.  Per chunk a wave issues 64 (a | g) + 32 (du) + 64 (dx) MFMAs; ten steps, ring of five.
@@ -857,10 +922,13 @@ __global__ __launch_bounds__(256, 1) void k_ffn_bwd(const bf16_t* __restrict__ X
 constexpr int UST_ROW = 80;                // a wave's staged u row: 64 B + 16 B (16 rows -> 16 bank groups)
 constexpr int BWDX_LDS = 2 * H_BYTES + 2 * AG_BYTES + 4 * 64 * UST_ROW;
 
+// NB: ffn_norm's backward in the epilogue (norm_bwd_epilogue): DX receives dh = d(un-normalised rows), DWP the norm weight's partials
+struct NormBwdArgs { const float* H; int ldh; const float* NW; const float* RSTD; float* DWP; };
+template <bool NB>
 __global__ __launch_bounds__(256, 1) void k_ffn_bwd_dx(const bf16_t* __restrict__ X, const float* __restrict__ DY, const u32x4* __restrict__ W13p,
                                                         const u32x4* __restrict__ W2tp, const u32x4* __restrict__ W13tp, bf16_t* __restrict__ DAG,
                                                         bf16_t* __restrict__ U, bf16_t* __restrict__ DYB, float* __restrict__ DX, int M, int F,
-                                                        int add_dy) {
+                                                        int add_dy, NormBwdArgs nb) {
     constexpr int RD = 5, LA = 3;      // five static slots, four live at a time (three steps in flight + the one in use)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
@@ -1143,6 +1211,11 @@ __global__ __launch_bounds__(256, 1) void k_ffn_bwd_dx(const bf16_t* __restrict_
             agc[0][i] = agn[0][i]; agc[1][i] = agn[1][i];
         }
     }
+    if constexpr (NB) {
+        __builtin_amdgcn_s_barrier();       // every wave is done with the tiles: the LDS is the epilogue's
+        norm_bwd_epilogue(dx, lds, nb.H, nb.ldh, nb.NW, nb.RSTD, nullptr, nullptr, DX, nb.DWP, M, m0, t);
+        return;
+    }
     // ---- dx (+ dy): column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31 ----
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1273,7 +1346,7 @@ extern "C" int gaot_ffn_bwd(const void* x_bf16, const float* dy, const void* pac
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_bwd_dx, hipFuncAttributeMaxDynamicSharedMemorySize, BWDX_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_bwd_dx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWDX_LDS);
         if (e != hipSuccess) {
             gaot_set_error("ffn_bwd: cannot set dynamic LDS %d: %s", BWDX_LDS, hipGetErrorString(e));
             return GAOT_ERR_LAUNCH;
@@ -1284,8 +1357,8 @@ extern "C" int gaot_ffn_bwd(const void* x_bf16, const float* dy, const void* pac
     const bf16_t* w2tp = p + (int64_t)2 * F * D + (int64_t)D * F;
     const bf16_t* w13tp = w2tp + (int64_t)D * F;
     const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
-    GAOT_KLAUNCH(k_ffn_bwd_dx, dim3((unsigned)(8 * per)), dim3(256), BWDX_LDS, (hipStream_t)stream, (const bf16_t*)x_bf16, dy, (const u32x4*)p,
-                 (const u32x4*)w2tp, (const u32x4*)w13tp, (bf16_t*)dag, (bf16_t*)u, (bf16_t*)dyb, dx, (int)rows, F, add_dy);
+    GAOT_KLAUNCH(k_ffn_bwd_dx<false>, dim3((unsigned)(8 * per)), dim3(256), BWDX_LDS, (hipStream_t)stream, (const bf16_t*)x_bf16, dy, (const u32x4*)p,
+                 (const u32x4*)w2tp, (const u32x4*)w13tp, (bf16_t*)dag, (bf16_t*)u, (bf16_t*)dyb, dx, (int)rows, F, add_dy, NormBwdArgs{});
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
@@ -1740,6 +1813,169 @@ extern "C" int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* nor
     const QkvArgs a{x, (int)ldx, norm_weight, eps, (const u32x4*)packed, (bf16_t*)image, (bf16_t*)yb, rstd, rope_table, S, H, HKV, qscale, (int)rows, (int)N};
     const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
     GAOT_KLAUNCH(k_norm_qkv, dim3((unsigned)(8 * per)), dim3(256), QKV_LDS, (hipStream_t)stream, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// gaot_ffn_bwd with ffn_norm's backward in its epilogue (reference attn.py:227-229 autograd): yb = bf16(ffn_norm(h)) as saved by
+// gaot_norm_ffn_fwd / gaot_block_tail_fwd, h fp32 [rows][ldh], rstd; the residual's gradient dy is part of d(norm) (add_dy = 1 always).
+// -> dh fp32 [rows][256], dag, u, dyb as gaot_ffn_bwd, and dw_part fp32 [ceil(rows / 64)][256]: the norm weight's gradient is the sum of
+// its rows (gaot_reduce_multi, parts = gaot_norm_bwd_parts(rows)).  Stands in for gaot_ffn_bwd + gaot_rmsnorm_bwd.
+extern "C" int64_t gaot_norm_bwd_parts(int64_t rows) { return (rows + RB - 1) / RB; }
+
+extern "C" int gaot_ffn_bwd_norm(const void* yb, const float* dy, const void* packed, const float* h, int64_t ldh, const float* norm_weight,
+                                 const float* rstd, void* dag, void* u, void* dyb, float* dh, float* dw_part, int64_t rows, int F,
+                                 gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(yb && dy && packed && h && norm_weight && rstd && dag && u && dh && dw_part && rows > 0 && F > 0 && F % FC == 0,
+                   "bad argument (F must be a multiple of 128)");
+    GAOT_CHECK_ARG(((uintptr_t)yb % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dag % 16) == 0 &&
+                   ((uintptr_t)u % 16) == 0 && ((uintptr_t)dyb % 16) == 0 && ((uintptr_t)dh % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
+                   ((uintptr_t)norm_weight % 16) == 0 && ldh % 4 == 0 && ldh >= D, "16-byte alignment");
+    if (rows * (int64_t)F * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_ffn_bwd_norm: rows * F too large for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static_assert(BWDX_LDS >= NB_LDS, "the epilogue reuses the kernel's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ffn_bwd_dx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWDX_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("ffn_bwd_norm: cannot set dynamic LDS %d: %s", BWDX_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const bf16_t* p = (const bf16_t*)packed;
+    const bf16_t* w2tp = p + (int64_t)2 * F * D + (int64_t)D * F;
+    const bf16_t* w13tp = w2tp + (int64_t)D * F;
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_ffn_bwd_dx<true>, dim3((unsigned)(8 * per)), dim3(256), BWDX_LDS, (hipStream_t)stream, (const bf16_t*)yb, dy, (const u32x4*)p,
+                 (const u32x4*)w2tp, (const u32x4*)w13tp, (bf16_t*)dag, (bf16_t*)u, (bf16_t*)dyb, dh, (int)rows, F, 1,
+                 NormBwdArgs{h, (int)ldh, norm_weight, rstd, dw_part});
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// ---- the q | k | v projections' input gradient with attn_norm's backward in its epilogue (reference attn.py:104-106, 226 autograd):
+// dqkv fp32 [rows][N] (N a multiple of 256), packed = gaot_qkv_pack_multi's image WITH the backward image, x fp32 [rows][ldx] (the
+// block's input), rstd; dres / dtap (may be NULL): the gradients reaching x through the block's residual and through the long-range
+// skip tap -> dx fp32 [rows][256], dw_part [ceil(rows / 64)][256].  Stands in for gaot_gemm_ex (d(norm x) = dqkv Wqkv) + gaot_rmsnorm_bwd2.
+namespace {
+struct QkvBwdArgs {
+    const float* DQKV; const u32x4* WTp; const float* X; int ldx; const float* NW; const float* RSTD; const float* DRES; const float* DTAP;
+    float* DX; float* DWP; int M, N;
+};
+constexpr int QKVB_LDS = NB_LDS > 2 * H_BYTES ? NB_LDS : 2 * H_BYTES;
+__global__ __launch_bounds__(256, 1) void k_qkv_bwd_norm(QkvBwdArgs a) {
+    constexpr int RD = 3, LA = 2;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+    const int M = a.M, N = a.N, NS = N / 256;
+    const int nblk = (M + RB - 1) / RB, per = (nblk + 7) / 8;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= nblk) return;
+    const int m0 = t * RB;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.WTp, 0, N * D * 2, 0x00020000);
+    const int64_t gbytes = (int64_t)M * N * 4;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)a.DQKV, 0, (int)(gbytes > 0x7fffffff ? 0x7fffffff : gbytes), 0x00020000);
+    // step g = 4 sl + st: k-steps 16 sl + 4 st .. + 3 of this wave's two column tiles: blocks ((w*2 + jt)*(N/16) + k-step)
+    const int ns16 = N / 16;
+    u32x4 wr[RD][8];
+    auto wload = [&](u32x4 (&dst)[8], int g) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (((wv * 2 + jt) * ns16) + 4 * g + s2) * 1024, 0));
+    };
+    wload(wr[0], 0);
+    wload(wr[1], 1);
+    // K-slice sl of the dqkv rows (256 columns) fp32 -> registers (row 8 i + tid >> 5, 8 floats at column 8 (tid & 31))
+    f32x4 d0[8], d1[8];
+    auto gload = [&](int sl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+            const unsigned off = m < M ? (unsigned)m * (unsigned)N * 4u + (unsigned)(sl * 256 + (threadIdx.x & 31) * 8) * 4u : 0x80000000u;
+            d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 0));
+            d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, 16, 0));
+        }
+    };
+    auto gstore = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31;
+            const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+            *reinterpret_cast<u32x4*>(buf + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+        }
+    };
+    gload(0);
+    gstore(lds);
+    __builtin_amdgcn_s_barrier();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+    const int sw = l31 & 15;
+    for (int sl = 0; sl < NS; ++sl) {
+        const char* tb = lds + (sl & 1) * H_BYTES + l31 * 512;
+        if (sl + 1 < NS) gload(sl + 1);
+        auto run = [&](auto rot) {
+            constexpr int R = decltype(rot)::value;        // (4 sl) % 3
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                wload(wr[(R + st + LA) % RD], 4 * sl + st + LA);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int slot = ((2 * (4 * st + s2) + hf) ^ sw) << 4;
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(tb + slot), a1 = *reinterpret_cast<const bf16x8*>(tb + 32 * 512 + slot);
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wr[(R + st) % RD][s2]), w1 = __builtin_bit_cast(bf16x8, wr[(R + st) % RD][4 + s2]);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+                }
+            }
+        };
+        const int rot = (4 * sl) % 3;
+        if (rot == 0) run(std::integral_constant<int, 0>{});
+        else if (rot == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+        if (sl + 1 < NS) gstore(lds + ((sl + 1) & 1) * H_BYTES);
+        __builtin_amdgcn_s_barrier();
+    }
+    norm_bwd_epilogue(acc, lds, a.X, a.ldx, a.NW, a.RSTD, a.DRES, a.DTAP, a.DX, a.DWP, M, m0, t);
+}
+}  // namespace
+
+extern "C" int gaot_qkv_bwd_norm(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
+                                 const float* rstd, const float* dres, const float* dtap, float* dx, float* dw_part, int64_t rows,
+                                 gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(dqkv && packed && x && norm_weight && rstd && dx && dw_part && rows > 0 && N > 0 && N % 256 == 0, "bad argument (N must be a multiple of 256)");
+    GAOT_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 &&
+                   ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dtap % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ldx % 4 == 0 && ldx >= D, "16-byte alignment");
+    if (rows * N * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_qkv_bwd_norm: too many rows for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_bwd_norm, hipFuncAttributeMaxDynamicSharedMemorySize, QKVB_LDS);
+        if (e != hipSuccess) {
+            gaot_set_error("qkv_bwd_norm: cannot set dynamic LDS %d: %s", QKVB_LDS, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const QkvBwdArgs a{dqkv, (const u32x4*)((const bf16_t*)packed + N * D), x, (int)ldx, norm_weight, rstd, dres, dtap, dx, dw_part, (int)rows, (int)N};
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_qkv_bwd_norm, dim3((unsigned)(8 * per)), dim3(256), QKVB_LDS, (hipStream_t)stream, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -105,6 +105,7 @@ def prepack_ffn(pairs, with_backward: bool, wos=None) -> None:
 
 _QKV_PACK_CACHE: dict = {}       # (address, shape) of the co-located fp32 q | k | v weight -> its fragment image (prepack_qkv)
 _NORM_QKV = os.environ.get("GAOT_NORM_QKV", "1") != "0"      # attn_norm + q | k | v image in one launch (A/B switch)
+_NORM_BWD_FUSED = os.environ.get("GAOT_NORM_BWD_FUSED", "1") != "0"    # RMSNorm backward in the epilogue of the product in front of it (A/B switch)
 
 
 def prepack_qkv(wcats) -> None:
@@ -119,7 +120,7 @@ def prepack_qkv(wcats) -> None:
         if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == 256 and w.shape[0] % 256 == 0:
             by_n.setdefault(w.shape[0], []).append(w)
     for _n, ws in by_n.items():
-        for w, packed in zip(ws, ops.qkv_pack_multi(ws, False)):
+        for w, packed in zip(ws, ops.qkv_pack_multi(ws, True)):
             _QKV_PACK_CACHE[(w.data_ptr(), tuple(w.shape))] = packed
 
 
@@ -769,10 +770,13 @@ class NormFFNFn(Function):
         dy2 = dy.reshape(m, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)       # dn: gradient w.r.t. the normalised rows (FFN input + residual)
+        if _NORM_BWD_FUSED:
+            dh, dag, u, dyb, dnw = ops.ffn_bwd_norm(yb, dy2, packed, f, h2, norm_w, rstd, defer=ops.defer_ok((ctx.nparam,)))
+        else:
+            dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)       # dn: gradient w.r.t. the normalised rows (FFN input + residual)
+            dh, dnw = ops.rmsnorm_bwd(h2, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
-        dh, dnw = ops.rmsnorm_bwd(h2, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         return dh.view(hshape), dnw, None, dwcat[:f].view(w1shape), dwcat[f:].view(w1shape), dw2
 
 
@@ -800,12 +804,12 @@ class NormQKVFn(Function):
         wcat32 = ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, 256), (256, 1))
         packed = _QKV_PACK_CACHE.get((wcat32.data_ptr(), tuple(wcat32.shape)))
         if packed is None:
-            packed = ops.qkv_pack_multi([wcat32], False)[0]
+            packed = ops.qkv_pack_multi([wcat32], True)[0]
         freqs, b, s, h, hkv, scale = image_spec
         img, yb, rstd = ops.norm_qkv_image(x2, norm_w, eps, packed, b, s, h, hkv, freqs, scale)
         out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only: no [m, ntot] buffer
         out._gaot_qkv_image = img
-        ctx.save_for_backward(x2, norm_w, rstd, yb, _wb(wcat32, 1))
+        ctx.save_for_backward(x2, norm_w, rstd, yb, _wb(wcat32, 1), packed)
         ctx.wparams, ctx.nparam = tuple(weights), norm_w
         ctx.meta = (x.shape, [w.shape for w in weights], ntot)
         ctx.set_materialize_grads(False)
@@ -814,14 +818,19 @@ class NormQKVFn(Function):
 
     @staticmethod
     def backward(ctx, dqkv: Tensor, dres: Optional[Tensor] = None, dtap: Optional[Tensor] = None):
-        x2, norm_w, rstd, yb, wcat = ctx.saved_tensors
+        x2, norm_w, rstd, yb, wcat, packed = ctx.saved_tensors
         xshape, wshapes, ntot = ctx.meta
         m = x2.shape[0]
         d = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
-        dn = ops.gemm(d, wcat, m, 256, ntot, ntot, 256, False, False, precision=1)
         dwcat = _dw_gemm(d, yb, ntot, 256, m, ntot, 256, 1, ctx.wparams)
-        dx, dnw = ops.rmsnorm_bwd(x2, norm_w, dn, rstd, None if dres is None else dres.reshape(x2.shape), defer=ops.defer_ok((ctx.nparam,)),
-                                  dx_add2=None if dtap is None else dtap.reshape(x2.shape))
+        dres2 = None if dres is None else dres.reshape(x2.shape)
+        dtap2 = None if dtap is None else dtap.reshape(x2.shape)
+        if _NORM_BWD_FUSED:
+            # d(norm x) = dqkv Wqkv with attn_norm's backward (and the residual's / the skip's addends) in its epilogue: one launch
+            dx, dnw = ops.qkv_bwd_norm(d, packed, x2, norm_w, rstd, dres2, dtap2, defer=ops.defer_ok((ctx.nparam,)))
+        else:
+            dn = ops.gemm(d, wcat, m, 256, ntot, ntot, 256, False, False, precision=1)
+            dx, dnw = ops.rmsnorm_bwd(x2, norm_w, dn, rstd, dres2, defer=ops.defer_ok((ctx.nparam,)), dx_add2=dtap2)
         dws, col = [], 0
         for shp in wshapes:
             dws.append(dwcat[col:col + shp[0]].view(shp))
@@ -873,10 +882,13 @@ class BlockTailFn(Function):
         f, d, w1shape, w2shape, woshape = ctx.meta
         m = h.shape[0]
         dy2 = dy if dy.is_contiguous() else dy.contiguous()
-        dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)
+        if _NORM_BWD_FUSED:
+            dh, dag, u, dyb, dnw = ops.ffn_bwd_norm(yb, dy2, packed, f, h, norm_w, rstd, defer=ops.defer_ok((ctx.nparam,)))
+        else:
+            dn, dag, u, dyb = ops.ffn_bwd(yb, dy2, packed, f, True)
+            dh, dnw = ops.rmsnorm_bwd(h, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         dw2 = _dw_gemm(dyb, u, d, f, m, d, f, 1, ctx.wparams[2:]).view(w2shape)
         dwcat = _dw_gemm(dag, yb, 2 * f, d, m, 2 * f, d, 1, ctx.wparams[:2])
-        dh, dnw = ops.rmsnorm_bwd(h, norm_w, dn, rstd, defer=ops.defer_ok((ctx.nparam,)))
         d_o = None
         if ctx.needs_input_grad[0]:
             if ctx.attn_dims is not None:

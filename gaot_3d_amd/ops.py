@@ -967,6 +967,66 @@ def norm_qkv_image(x: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, b
     return img, yb, rstd
 
 
+def _finish_parts(part: Tensor, n: int, parts: int, lanes: int, defer: bool) -> Tensor:
+    """out[n] = the fixed-order sum of ``parts`` partial rows: left to flush_deferred (defer) or one gaot_reduce_multi launch now"""
+    out = torch.empty(n, dtype=torch.float32, device=part.device)
+    if defer:
+        _defer(part, out, n, parts, lanes)
+        return out
+    arr = (_ReduceDesc * 1)()
+    arr[0].part, arr[0].out, arr[0].n, arr[0].parts, arr[0].lanes = part.data_ptr(), out.data_ptr(), n, parts, lanes
+    check(_lib.load().gaot_reduce_multi(arr, 1, _stream()), "gaot_reduce_multi")
+    return out
+
+
+def ffn_bwd_norm(yb: Tensor, dy: Tensor, packed: Tensor, f: int, h: Tensor, norm_weight: Tensor, rstd: Tensor, defer: bool = False):
+    """ffn_bwd with ffn_norm's backward in its epilogue (include/gaot3d_hip.h: gaot_ffn_bwd_norm) -> (dh fp32 [rows, 256], dag, u, dyb,
+    d(norm weight) [256])"""
+    lib = _lib.load()
+    rows = yb.shape[0]
+    if yb.dtype != torch.bfloat16 or not yb.is_contiguous() or yb.shape[1] != 256:
+        raise GaotError("ffn_bwd_norm: contiguous bf16 [rows, 256] input expected")
+    if dy.dtype != torch.float32 or not dy.is_contiguous() or tuple(dy.shape) != (rows, 256):
+        raise GaotError("ffn_bwd_norm: contiguous fp32 [rows, 256] gradient expected")
+    if h.dtype != torch.float32 or tuple(h.shape) != (rows, 256) or h.stride(1) != 1:
+        raise GaotError("ffn_bwd_norm: fp32 [rows, 256] norm input expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    dev = yb.device
+    dag = torch.empty(rows, 2 * f, dtype=torch.bfloat16, device=dev)
+    u = torch.empty(rows, f, dtype=torch.bfloat16, device=dev)
+    dyb = torch.empty(rows, 256, dtype=torch.bfloat16, device=dev)
+    dh = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    parts = int(lib.gaot_norm_bwd_parts(rows))
+    part = torch.empty(parts, 256, dtype=torch.float32, device=dev)
+    with _timed("ffn_bwd_norm"):
+        check(lib.gaot_ffn_bwd_norm(_ptr(yb), _ptr(dy), _ptr(packed), _ptr(h), h.stride(0), _ptr(nw), _ptr(rstd), _ptr(dag), _ptr(u), _ptr(dyb),
+                                    _ptr(dh), _ptr(part), rows, int(f), _stream()), "gaot_ffn_bwd_norm")
+    return dh, dag, u, dyb, _finish_parts(part, 256, parts, 32, defer)
+
+
+def qkv_bwd_norm(dqkv: Tensor, packed: Tensor, x: Tensor, norm_weight: Tensor, rstd: Tensor, dres: Optional[Tensor] = None,
+                 dtap: Optional[Tensor] = None, defer: bool = False):
+    """d(norm x) = dqkv Wqkv with attn_norm's backward in its epilogue (include/gaot3d_hip.h: gaot_qkv_bwd_norm; ``packed`` from
+    qkv_pack_multi(..., with_backward=True)) -> (dx fp32 [rows, 256], d(norm weight) [256])"""
+    lib = _lib.load()
+    rows, n = dqkv.shape
+    if dqkv.dtype != torch.float32 or not dqkv.is_contiguous() or n % 256:
+        raise GaotError("qkv_bwd_norm: contiguous fp32 [rows, N] gradient with N a multiple of 256 expected")
+    if x.dtype != torch.float32 or tuple(x.shape) != (rows, 256) or x.stride(1) != 1:
+        raise GaotError("qkv_bwd_norm: fp32 [rows, 256] norm input expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    dres = None if dres is None else _req(dres, torch.float32, "dres")
+    dtap = None if dtap is None else _req(dtap, torch.float32, "dtap")
+    dev = dqkv.device
+    dx = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    parts = int(lib.gaot_norm_bwd_parts(rows))
+    part = torch.empty(parts, 256, dtype=torch.float32, device=dev)
+    with _timed("qkv_bwd_norm"):
+        check(lib.gaot_qkv_bwd_norm(_ptr(dqkv), n, _ptr(packed), _ptr(x), x.stride(0), _ptr(nw), _ptr(rstd), _ptr(dres), _ptr(dtap), _ptr(dx),
+                                    _ptr(part), rows, _stream()), "gaot_qkv_bwd_norm")
+    return dx, _finish_parts(part, 256, parts, 32, defer)
+
+
 def oproj_bwd_image(dh: Tensor, attn_out: Tensor, packed: Tensor, f: int, b: int, s: int, h: int, hkv: int):
     """d_o = dh Wo as the flash backward's operands (include/gaot3d_hip.h: gaot_oproj_bwd_image): -> (an attn_bwd_scratch buffer whose head
     holds the bf16 dO image, delta fp32 [b, h, s]) for attn_bwd_bf16(do_image=..., delta=...)"""

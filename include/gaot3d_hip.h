@@ -350,6 +350,16 @@ int64_t gaot_qkv_packed_bytes(int64_t N, int with_backward);
 int gaot_qkv_pack_multi(const gaot_qkv_pack_t* items, int num, int64_t N, int with_backward, gaot_stream_t stream);
 int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* norm_weight, float eps, const void* packed, void* image, void* yb,
                         float* rstd, int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
+/* RMSNorm backward as the epilogue of the product that forms d(norm(x)) (ABI 11; reference attn.py:167-178 autograd):
+ *  gaot_ffn_bwd_norm  = gaot_ffn_bwd + gaot_rmsnorm_bwd(ffn_norm): dh instead of d(norm(h)); h, rstd as saved by the forward
+ *  gaot_qkv_bwd_norm  = gaot_gemm_ex (d(norm x) = dqkv Wqkv, packed WITH the backward image) + gaot_rmsnorm_bwd2(attn_norm): dx, with the
+ *                       residual's (dres) and the skip tap's (dtap) gradients as addends (either may be NULL)
+ * Both leave the norm weight's gradient as gaot_norm_bwd_parts(rows) partial rows of 256 (one per 64-row block) for gaot_reduce_multi. */
+int64_t gaot_norm_bwd_parts(int64_t rows);
+int gaot_ffn_bwd_norm(const void* yb, const float* dy, const void* packed, const float* h, int64_t ldh, const float* norm_weight,
+                      const float* rstd, void* dag, void* u, void* dyb, float* dh, float* dw_part, int64_t rows, int F, gaot_stream_t stream);
+int gaot_qkv_bwd_norm(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
+                      const float* rstd, const float* dres, const float* dtap, float* dx, float* dw_part, int64_t rows, gaot_stream_t stream);
 /* the o_proj backward's input gradient d_o = dh Wo written straight as the flash backward's operands (attn.py:122-127 autograd): the
  * bf16 dO image [rows][256] and delta[rows / S][8][S] = sum over a head's 32 columns of d_o * attn_out -- stands in for gaot_gemm_ex and
  * phase 1 of gaot_attn_bwd_bf16 (call it with phases 16 | 32 only).  packed: a block image of gaot_block_pack_multi. */

@@ -135,7 +135,7 @@ def test_fused_backward_with_input_gradient(rows, f, add_dy):
     assert e_gemm < 1e-5 and e_ref < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["norm_ffn", "block_tail", "oproj_image", "norm_qkv", "norm_qkv_rope"])
+@pytest.mark.parametrize("mode", ["norm_ffn", "block_tail", "oproj_image", "norm_qkv", "norm_qkv_rope", "norm_bwd"])
 @pytest.mark.parametrize("rows,f", [(16384, 1024), (1000, 256)])
 def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
     """NormFFNFn (ffn_norm + FFN + residual in one forward launch, reference attn.py:227-229) and BlockTailFn (o_proj and the first
@@ -160,7 +160,10 @@ def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
             GF._NORM_FFN = on if mode == "norm_ffn" else True
             GF._BLOCK_TAIL = on if mode == "block_tail" else (mode == "oproj_image")
             GF._OPROJ_BWD_IMAGE = on if mode == "oproj_image" else False
-            GF._NORM_QKV = on if mode.startswith("norm_qkv") else False
+            GF._NORM_QKV = on if mode.startswith("norm_qkv") else (mode == "norm_bwd")
+            GF._NORM_BWD_FUSED = on if mode == "norm_bwd" else False
+            if mode == "norm_bwd":
+                GF._BLOCK_TAIL = True
             for p in blk.parameters():
                 p.grad = None
             x.grad = None
@@ -169,7 +172,7 @@ def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
             torch.cuda.synchronize()
             out[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
     finally:
-        GF._NORM_FFN = GF._BLOCK_TAIL = GF._OPROJ_BWD_IMAGE = GF._NORM_QKV = True
+        GF._NORM_FFN = GF._BLOCK_TAIL = GF._OPROJ_BWD_IMAGE = GF._NORM_QKV = GF._NORM_BWD_FUSED = True
         gaot_3d_amd.set_precision("fp32")
     names = ["y", "dx"] + [n for n, p in blk.named_parameters() if p.requires_grad]
     # the row sum of squares is contracted in another order than in k_rmsnorm_fwd: 1/rms differs in its last bit for some rows and the bf16
