@@ -117,6 +117,9 @@ SIGNATURES = {
     "gaot_qkv_packed_bytes": (_i64, [_i64, _i]),
     "gaot_qkv_pack_multi": (_i, [_p, _i, _i64, _i, _p]),
     "gaot_norm_qkv_image": (_i, [_p, _i64, _p, _f, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _f, _p]),
+    "gaot_skip_packed_bytes": (_i64, []),
+    "gaot_skip_pack_multi": (_i, [_p, _i, _p]),
+    "gaot_cat_norm_qkv_image": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _f, _p]),
     "gaot_norm_bwd_parts": (_i64, [_i64]),
     "gaot_ffn_bwd_norm": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_qkv_bwd_norm": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p]),

@@ -1596,11 +1596,27 @@ __global__ void k_qkv_pack(QkvTable t, int N, int with_backward) {
     }
 }
 
+// blockIdx.y = the block; skip_proj.weight [256][512] -> blocks ((w*2 + jt)*32 + s): row 64 w + 32 jt + l31, k = 16 s + 8 hf + e
+__global__ void k_skip_pack(QkvTable t) {
+    const float* w = t.w[blockIdx.y];
+    bf16_t* p = t.packed[blockIdx.y];
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < D * 2 * D / 8; id += gridDim.x * blockDim.x) {
+        const int lane = id & 63, s2 = (id >> 6) & 31, jt = (id >> 11) & 1, wv = id >> 12;
+        const float* src = w + (int64_t)(64 * wv + 32 * jt + (lane & 31)) * (2 * D) + 16 * s2 + 8 * (lane >> 5);
+        *reinterpret_cast<u32x4*>(p + (int64_t)id * 8) = u32x4{pack2(src[0], src[1]), pack2(src[2], src[3]), pack2(src[4], src[5]), pack2(src[6], src[7])};
+    }
+}
+
 struct QkvArgs {
     const float* X; int ldx; const float* NW; float eps; const u32x4* Wp; bf16_t* IMG; bf16_t* YB; float* RSTD;
     const float* table; int S, nq, nk; float qscale; int M, N;
+    // CAT: the decoder block's skip projection in front (reference attn.py:222-225: x = skip_proj(cat([x, skip]))): X, XB = the two inputs,
+    // WSp = skip_proj.weight ([256][512]) as fragment blocks ((w*2 + jt)*32 + s), BS its bias, XO receives the projected rows (fp32
+    // [M][256]: the block's residual and the norm's input for the backward)
+    const float* XB; int ldxb; const u32x4* WSp; const float* BS; float* XO;
 };
-constexpr int QKV_LDS = H_BYTES + 256;
+constexpr int QKV_LDS = H_BYTES + 256 + 64 * 144, QKV_LDS_CAT = 2 * H_BYTES + 256 + 1024 + 64 * 144;
+template <bool CAT>
 __global__ __launch_bounds__(256, 1) void k_norm_qkv(QkvArgs a) {
     constexpr int RD = 3, LA = 2;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -1624,8 +1640,117 @@ __global__ __launch_bounds__(256, 1) void k_norm_qkv(QkvArgs a) {
     };
     wload(wr[0], 0);
     wload(wr[1], 1);
-    float* rstd_l = reinterpret_cast<float*>(lds + H_BYTES);
-    {   // attn_norm: rows 16 wave .. + 15, a lane per float4 (the arithmetic and summation order of k_rmsnorm_fwd, rowops.hip)
+    float* rstd_l = reinterpret_cast<float*>(lds + (CAT ? 2 * H_BYTES : H_BYTES));
+    if constexpr (CAT) {
+        const int sw0 = l31 & 15;
+        const int64_t xab = (int64_t)M * a.ldx * 4, xbb = (int64_t)M * a.ldxb * 4, xob = (int64_t)M * D * 4, ybbytes = (int64_t)M * D * 2;
+        const __amdgpu_buffer_rsrc_t xars = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)(xab > 0x7fffffff ? 0x7fffffff : xab), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xbrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.XB, 0, (int)(xbb > 0x7fffffff ? 0x7fffffff : xbb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xors = __builtin_amdgcn_make_buffer_rsrc((void*)a.XO, 0, (int)(xob > 0x7fffffff ? 0x7fffffff : xob), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.YB, 0, (int)(ybbytes > 0x7fffffff ? 0x7fffffff : ybbytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wsrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.WSp, 0, D * 2 * D * 2, 0x00020000);
+        u32x4 wo[2][8];
+        auto woload = [&](u32x4 (&dst)[8], int st) {      // st 0..7: k-steps 4 st .. + 3 of 32
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrs, lane * 16, (((wv * 2 + jt) * 32) + 4 * st + s2) * 1024, 0));
+        };
+        woload(wo[0], 0);
+        woload(wo[1], 1);
+        // the two inputs fp32 -> bf16 -> LDS tiles (x at 0, skip at H_BYTES): row 8 i + tid >> 5, 16-byte bf16 chunk tid & 31 = 8 floats
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 d0[8], d1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * i + (threadIdx.x >> 5), m = m0 + row;
+                const unsigned off = m < M ? (unsigned)m * (unsigned)(half ? a.ldxb : a.ldx) * 4u + (unsigned)(threadIdx.x & 31) * 32u : 0x80000000u;
+                d0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(half ? xbrs : xars, off, 0, 0));
+                d1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(half ? xbrs : xars, off, 16, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * i + (threadIdx.x >> 5), ch = threadIdx.x & 31;
+                const u32x4 v = {pack2(d0[i][0], d0[i][1]), pack2(d0[i][2], d0[i][3]), pack2(d1[i][0], d1[i][1]), pack2(d1[i][2], d1[i][3])};
+                *reinterpret_cast<u32x4*>(lds + half * H_BYTES + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+            }
+        }
+        // the projected rows start as the bias: column 64 wave + 32 jt + mfma32_row(r, hf), row m0 + 32 i + l31
+        f32x16 hacc[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = a.BS ? *reinterpret_cast<const f32x4*>(a.BS + wave * 64 + 32 * jt + 8 * q + 4 * hf) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    hacc[jt][i][4 * q] = bv[0]; hacc[jt][i][4 * q + 1] = bv[1]; hacc[jt][i][4 * q + 2] = bv[2]; hacc[jt][i][4 * q + 3] = bv[3];
+                }
+            }
+        __builtin_amdgcn_s_barrier();       // both bf16 tiles are complete
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const char* tb = lds + (st >> 2) * H_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int slot = ((2 * (4 * (st & 3) + s2) + hf) ^ sw0) << 4;
+                const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(tb + l31 * 512 + slot), o1 = *reinterpret_cast<const bf16x8*>(tb + (32 + l31) * 512 + slot);
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wo[st & 1][s2]), w1 = __builtin_bit_cast(bf16x8, wo[st & 1][4 + s2]);
+                hacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, o0, hacc[0][0], 0, 0, 0);
+                hacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, o0, hacc[1][0], 0, 0, 0);
+                hacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, o1, hacc[0][1], 0, 0, 0);
+                hacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, o1, hacc[1][1], 0, 0, 0);
+            }
+            if (st + 2 < 8) woload(wo[st & 1], st + 2);
+        }
+        float* part = rstd_l + 64;       // [4 waves][64 rows]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + 32 * i + l31;
+            const unsigned rowoff = m < M ? (unsigned)m * (unsigned)D * 4u : 0x80000000u;
+            float ssl = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {hacc[jt][i][4 * q], hacc[jt][i][4 * q + 1], hacc[jt][i][4 * q + 2], hacc[jt][i][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xors, rowoff + (wave * 64 + 32 * jt + 8 * q + 4 * hf) * 4, 0, 0);
+                    ssl += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                }
+            ssl += __shfl_xor(ssl, 32, 64);
+            if (hf == 0) part[wave * 64 + 32 * i + l31] = ssl;
+        }
+        __builtin_amdgcn_s_barrier();       // partials complete; every wave is done reading the input tiles
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = 32 * i + l31, m = m0 + ml;
+            const float ssr = ((part[ml] + part[64 + ml]) + part[128 + ml]) + part[192 + ml];
+            const float r = rsqrtf(ssr / (float)D + a.eps);
+            if (wave == 0 && hf == 0) {
+                rstd_l[ml] = r;
+                if (m < M) a.RSTD[m] = r;
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(a.NW + wave * 64 + 32 * jt + 8 * q + 4 * hf);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 pk = {pack2(hacc[jt][i][4 * q] * r * g[0], hacc[jt][i][4 * q + 1] * r * g[1]),
+                                      pack2(hacc[jt][i][4 * q + 2] * r * g[2], hacc[jt][i][4 * q + 3] * r * g[3])};
+                    *reinterpret_cast<u32x2*>(lds + ml * 512 + (((8 * wave + 4 * jt + q) ^ (ml & 15)) << 4) + 8 * hf) = pk;
+                }
+        }
+        __builtin_amdgcn_s_barrier();       // the normalised tile is complete
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {        // bf16(norm(x')) to HBM, this wave's 16 rows, two rows per instruction
+            const int row = 16 * wave + 2 * k + hf, ch = l31, m = m0 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * 512 + ((ch ^ (row & 15)) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(v, ybrs, m < M ? (unsigned)m * (unsigned)D * 2u + (unsigned)ch * 16u : 0x80000000u, 0, 0);
+        }
+    } else {   // attn_norm: rows 16 wave .. + 15, a lane per float4 (the arithmetic and summation order of k_rmsnorm_fwd, rowops.hip)
         const int64_t xbytes = (int64_t)M * a.ldx * 4, ybbytes = (int64_t)M * D * 2;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
         const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.YB, 0, (int)(ybbytes > 0x7fffffff ? 0x7fffffff : ybbytes), 0x00020000);
@@ -1667,16 +1792,18 @@ __global__ __launch_bounds__(256, 1) void k_norm_qkv(QkvArgs a) {
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table ? a.S * 128 : 0, 0x00020000);
     const int sw = l31 & 15;
     const char* hb = lds + l31 * 512;
-    // the (cos, sin) pairs of this lane's rows and column runs: the same for every head -- requested once, here (in the panel epilogues
-    // every one of these 16-byte loads sat in front of its use: an exposed L2 round trip per batch)
-    f32x4 tab[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 32 * i + l31, mm = m < M ? m : M - 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            tab[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, (mm % a.S) * 128 + 16 * hf + 32 * q, 0, 0));
+    // the (cos, sin) rows of the block's 64 positions (128 B each; the same for every head) are fetched ONCE into LDS (pitch 144 B: the
+    // 16-byte reads of 16 consecutive rows cover all banks) -- in the panel epilogues every one of these loads sat in front of its use,
+    // an exposed L2 round trip per batch; held in registers they cost the 32 that made the CAT form spill
+    char* tabl = lds + (CAT ? QKV_LDS_CAT : QKV_LDS) - 64 * 144;
+    {
+        const int row = threadIdx.x >> 2, pc = threadIdx.x & 3, m = m0 + row, mm = m < M ? m : M - 1;
+        const f32x4 t0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, (mm % a.S) * 128 + 32 * pc, 0, 0));
+        const f32x4 t1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, (mm % a.S) * 128 + 32 * pc + 16, 0, 0));
+        *reinterpret_cast<f32x4*>(tabl + row * 144 + 32 * pc) = t0;
+        *reinterpret_cast<f32x4*>(tabl + row * 144 + 32 * pc + 16) = t1;
     }
+    __builtin_amdgcn_s_barrier();
     // the product of panel pn + 1 (MFMAs) carries the epilogue of panel pn (vector instructions, stores) between its k-steps: two
     // accumulator sets; a panel past the last reads zero weights (buffer range check) -- one product too many instead of a second copy
     // of the loop body
@@ -1742,7 +1869,7 @@ __global__ __launch_bounds__(256, 1) void k_norm_qkv(QkvArgs a) {
                 const int q = q0 + 2 * h2;
                 float v0 = accc[jt][i][4 * q], v1 = accc[jt][i][4 * q + 1], v2 = accc[jt][i][4 * q + 2], v3 = accc[jt][i][4 * q + 3];
                 if (rope) {
-                    const f32x4 tb = tab[i][q];   // cos, sin, cos, sin
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(tabl + (32 * i + l31) * 144 + 16 * hf + 32 * q);   // cos, sin, cos, sin
                     const float r0 = v0 * tb[0] - v1 * tb[1], r1 = v1 * tb[0] + v0 * tb[1];
                     const float r2 = v2 * tb[2] - v3 * tb[3], r3 = v3 * tb[2] + v2 * tb[3];
                     v0 = r0; v1 = r1; v2 = r2; v3 = r3;
@@ -1803,16 +1930,67 @@ extern "C" int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* nor
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_norm_qkv, hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)k_norm_qkv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS);
         if (e != hipSuccess) {
             gaot_set_error("norm_qkv: cannot set dynamic LDS %d: %s", QKV_LDS, hipGetErrorString(e));
             return GAOT_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    const QkvArgs a{x, (int)ldx, norm_weight, eps, (const u32x4*)packed, (bf16_t*)image, (bf16_t*)yb, rstd, rope_table, S, H, HKV, qscale, (int)rows, (int)N};
+    const QkvArgs a{x, (int)ldx, norm_weight, eps, (const u32x4*)packed, (bf16_t*)image, (bf16_t*)yb, rstd, rope_table, S, H, HKV, qscale, (int)rows, (int)N,
+                    nullptr, 0, nullptr, nullptr, nullptr};
     const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
-    GAOT_KLAUNCH(k_norm_qkv, dim3((unsigned)(8 * per)), dim3(256), QKV_LDS, (hipStream_t)stream, a);
+    GAOT_KLAUNCH(k_norm_qkv<false>, dim3((unsigned)(8 * per)), dim3(256), QKV_LDS, (hipStream_t)stream, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// the same with the decoder block's skip projection in front (reference attn.py:222-225: x = skip_proj(cat([x, skip]))): xa, xb fp32
+// [rows][256] (ldxa, ldxb), skip_packed = gaot_skip_pack_multi's image of skip_proj.weight ([256][512]), skip_bias [256] or NULL;
+// x_out receives the projected rows (fp32 [rows][256]).  Stands in for two gaot_gemm launches + gaot_rmsnorm_fwd + gaot_qkv_image.
+extern "C" int64_t gaot_skip_packed_bytes(void) { return (int64_t)D * 2 * D * 2; }
+extern "C" int gaot_skip_pack_multi(const gaot_qkv_pack_t* items, int num, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(items && num > 0, "bad argument");
+    for (int i0 = 0; i0 < num; i0 += PACK_MAX) {
+        QkvTable t{};
+        const int n = std::min(PACK_MAX, num - i0);
+        for (int i = 0; i < n; ++i) {
+            GAOT_CHECK_ARG(items[i0 + i].w && items[i0 + i].packed && ((uintptr_t)items[i0 + i].packed % 16) == 0, "null or misaligned pointer in the table");
+            t.w[i] = items[i0 + i].w; t.packed[i] = (bf16_t*)items[i0 + i].packed;
+        }
+        GAOT_KLAUNCH(k_skip_pack, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+extern "C" int gaot_cat_norm_qkv_image(const float* xa, int64_t ldxa, const float* xb, int64_t ldxb, const void* skip_packed, const float* skip_bias,
+                                       float* x_out, const float* norm_weight, float eps, const void* packed, void* image, void* yb, float* rstd,
+                                       int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream) {
+    GAOT_ENTER();
+    const int64_t N = (int64_t)(H + 2 * HKV) * 32;
+    GAOT_CHECK_ARG(xa && xb && skip_packed && x_out && norm_weight && packed && image && yb && rstd && rows > 0 && S > 0 && H > 0 && HKV > 0 &&
+                   N % 256 == 0, "bad argument ((H + 2 HKV) * 32 must be a multiple of 256)");
+    GAOT_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)skip_packed % 16) == 0 && ((uintptr_t)skip_bias % 16) == 0 &&
+                   ((uintptr_t)x_out % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)image % 16) == 0 &&
+                   ((uintptr_t)yb % 16) == 0 && ldxa % 4 == 0 && ldxa >= D && ldxb % 4 == 0 && ldxb >= D, "16-byte alignment");
+    if (rows * N * 2 >= 0x7fffffff || rows * ldxa * 4 >= 0x7fffffff || rows * ldxb * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_cat_norm_qkv_image: too many rows for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_norm_qkv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, QKV_LDS_CAT);
+        if (e != hipSuccess) {
+            gaot_set_error("cat_norm_qkv: cannot set dynamic LDS %d: %s", QKV_LDS_CAT, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const QkvArgs a{xa, (int)ldxa, norm_weight, eps, (const u32x4*)packed, (bf16_t*)image, (bf16_t*)yb, rstd, rope_table, S, H, HKV, qscale, (int)rows, (int)N,
+                    xb, (int)ldxb, (const u32x4*)skip_packed, skip_bias, x_out};
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_norm_qkv<true>, dim3((unsigned)(8 * per)), dim3(256), QKV_LDS_CAT, (hipStream_t)stream, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

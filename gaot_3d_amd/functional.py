@@ -124,11 +124,25 @@ def prepack_qkv(wcats) -> None:
             _QKV_PACK_CACHE[(w.data_ptr(), tuple(w.shape))] = packed
 
 
+_SKIP_PACK_CACHE: dict = {}      # (address, shape) of a decoder block's fp32 skip_proj weight -> its fragment image (prepack_skip)
+_CAT_QKV = os.environ.get("GAOT_CAT_QKV", "1") != "0"        # the decoder block's skip projection inside the head kernel (A/B switch)
+
+
+def prepack_skip(ws) -> None:
+    _SKIP_PACK_CACHE.clear()
+    if not (_CAT_QKV and _NORM_QKV and ops.get_precision() == "bf16"):
+        return
+    ok = [w for w in (_w2d(w) for w in ws) if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (256, 512)]
+    for w, packed in zip(ok, ops.skip_pack_multi(ok)):
+        _SKIP_PACK_CACHE[(w.data_ptr(), tuple(w.shape))] = packed
+
+
 def release_precast() -> None:
     _WB_CACHE.clear()
     _WBT_CACHE.clear()
     _FFN_PACK_CACHE.clear()
     _QKV_PACK_CACHE.clear()
+    _SKIP_PACK_CACHE.clear()
 
 
 def _wbt(w: Tensor) -> Optional[Tensor]:
@@ -836,6 +850,78 @@ class NormQKVFn(Function):
             dws.append(dwcat[col:col + shp[0]].view(shp))
             col += shp[0]
         return (dx.view(xshape), dnw, None, None, None, *dws)
+
+
+class CatNormQKVFn(Function):
+    """NormQKVFn with the decoder block's skip projection in front (reference attn.py:222-225: ``x = skip_proj(cat([x, skip]))``): ONE
+    forward launch for the two projection GEMMs, attn_norm, q | k | v and RoPE (csrc/ffn_fused.hip: k_norm_qkv<CAT>).  Outputs: the
+    q | k | v placeholder carrying the image and the residual alias of the PROJECTED rows.  Backward: NormQKVFn's, then CatLinearFn's on
+    the projected rows' gradient (the same tensor given as x and as skip folds its two gradients in one GEMM epilogue)."""
+
+    @staticmethod
+    def eligible(x: Tensor, skip: Tensor, wskip: Tensor, norm_w: Tensor, weights, image_spec) -> bool:
+        return (_CAT_QKV and tuple(_w2d(wskip).shape) == (256, 512) and wskip.dtype == torch.float32 and wskip.requires_grad and skip.shape == x.shape
+                and skip.dtype == torch.float32 and NormQKVFn.eligible(x, norm_w, weights, image_spec))
+
+    @staticmethod
+    def forward(ctx, x: Tensor, skip: Tensor, wskip: Tensor, bskip: Optional[Tensor], norm_w: Tensor, eps: float, image_spec, *weights: Tensor):
+        ws = [_w2d(w) for w in weights]
+        ntot = sum(w.shape[0] for w in ws)
+        ctx.same = _same_view(x, skip)
+        xa = x.reshape(-1, 256)
+        xb = skip.reshape(-1, 256)
+        xa = xa if xa.is_contiguous() else xa.contiguous()
+        xb = xb if xb.is_contiguous() else xb.contiguous()
+        m = xa.shape[0]
+        wsk = _w2d(wskip)
+        wcat32 = ws[0].new_empty(0).set_(ws[0].untyped_storage(), ws[0].storage_offset(), (ntot, 256), (256, 1))
+        packed = _QKV_PACK_CACHE.get((wcat32.data_ptr(), tuple(wcat32.shape)))
+        if packed is None:
+            packed = ops.qkv_pack_multi([wcat32], True)[0]
+        spk = _SKIP_PACK_CACHE.get((wsk.data_ptr(), tuple(wsk.shape)))
+        if spk is None:
+            spk = ops.skip_pack_multi([wsk])[0]
+        freqs, b, s, h, hkv, scale = image_spec
+        img, xo, yb, rstd = ops.cat_norm_qkv_image(xa, xb, spk, bskip, norm_w, eps, packed, b, s, h, hkv, freqs, scale)
+        out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only
+        out._gaot_qkv_image = img
+        ctx.save_for_backward(xa, xb, xo, norm_w, rstd, yb, _wb(wcat32, 1), packed, _wb(wsk, 1))
+        ctx.wparams, ctx.nparam, ctx.sparams = tuple(weights), norm_w, (wskip, bskip)
+        ctx.meta = (x.shape, skip.shape, [w.shape for w in weights], ntot, wskip.shape)
+        ctx.set_materialize_grads(False)
+        return out, xo.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dqkv: Tensor, dres: Optional[Tensor] = None):
+        xa, xb, xo, norm_w, rstd, yb, wcat, packed, wskb = ctx.saved_tensors
+        xshape, sshape, wshapes, ntot, wsshape = ctx.meta
+        m = xa.shape[0]
+        d = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
+        dwcat = _dw_gemm(d, yb, ntot, 256, m, ntot, 256, 1, ctx.wparams)
+        dres2 = None if dres is None else dres.reshape(m, 256)
+        if _NORM_BWD_FUSED:
+            dxo, dnw = ops.qkv_bwd_norm(d, packed, xo, norm_w, rstd, dres2, None, defer=ops.defer_ok((ctx.nparam,)))
+        else:
+            dn = ops.gemm(d, wcat, m, 256, ntot, ntot, 256, False, False, precision=1)
+            dxo, dnw = ops.rmsnorm_bwd(xo, norm_w, dn, rstd, dres2, defer=ops.defer_ok((ctx.nparam,)))
+        # the skip projection's backward (CatLinearFn.backward on [xa | xb] W^T + b)
+        n, k = 256, 512
+        wsk, bsk = ctx.sparams
+        dxa = ops.gemm(dxo, wskb, m, 256, n, n, k, False, False, precision=1) if (ctx.needs_input_grad[0] or ctx.same) else None
+        if ctx.same and ctx.needs_input_grad[0]:
+            dxa = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, residual=dxa, ldr=256, precision=1)
+            dxb = None
+        else:
+            dxb = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, precision=1) if ctx.needs_input_grad[1] else None
+        dws = torch.empty(n, k, dtype=torch.float32, device=d.device)
+        ops.gemm(dxo, xa, n, 256, m, n, 256, True, False, out=dws, ldc=k, precision=1)
+        ops.gemm(dxo, xb, n, 256, m, n, 256, True, False, out=dws[:, 256:], ldc=k, precision=1)
+        dbs = ops.colsum(dxo, m, n, n) if (bsk is not None and ctx.needs_input_grad[3]) else None
+        dwl, col = [], 0
+        for shp in wshapes:
+            dwl.append(dwcat[col:col + shp[0]].view(shp))
+            col += shp[0]
+        return (None if dxa is None else dxa.view(xshape), None if dxb is None else dxb.view(sshape), dws.view(wsshape), dbs, dnw, None, None, *dwl)
 
 
 class BlockTailFn(Function):

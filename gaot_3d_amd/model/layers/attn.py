@@ -259,20 +259,28 @@ class TransformerBlock(nn.Module):
         (reference attn.py:282-288) instead of the input tensor, which then keeps a single consumer.  None when the block cannot
         provide one (no attention norm, or a skip projection in front of it)."""
         tap, asked = None, want_input_tap
-        if self.skip_connection and skip is not None:
-            b, s, d = x.shape
-            x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
-                              self.skip_proj.bias).view(b, s, -1)
-            want_input_tap = False
         qkv = None
         a = self.attn
-        if (self.attn_norm is not None and x.is_cuda and x.shape[-1] == 256 and torch.is_grad_enabled() and a.correction is None
-                and a.head_dim == 32 and getattr(a, "_seq_group", None) is None and getattr(a, "_head_group", None) is None):
+        head_ok = (self.attn_norm is not None and x.is_cuda and x.shape[-1] == 256 and torch.is_grad_enabled() and a.correction is None
+                   and a.head_dim == 32 and getattr(a, "_seq_group", None) is None and getattr(a, "_head_group", None) is None)
+        if head_ok:
             GF.colocate([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight])   # (no-op once done)
             b_, s_, _d = x.shape
             freqs = a.rotary_emb.freqs if (relative_positions is not None and hasattr(a, "rotary_emb")) else None
             spec = (freqs, b_, s_, a.num_heads, a.num_kv_heads, 1.0 / (32 ** 0.5))
             wts = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+        if self.skip_connection and skip is not None:
+            b, s, d = x.shape
+            want_input_tap = False
+            if head_ok and skip.shape == x.shape and GF.CatNormQKVFn.eligible(x, skip, self.skip_proj.weight, self.attn_norm.weight, wts, spec):
+                # the skip projection, attn_norm, the three projections and RoPE in ONE launch
+                qkv, xres = GF.CatNormQKVFn.apply(x, skip, self.skip_proj.weight, self.skip_proj.bias, self.attn_norm.weight, self.attn_norm.eps,
+                                                  spec, *wts)
+                x = h = xres
+            else:
+                x = GF.cat_linear([x.reshape(b * s, d), skip.reshape(b * s, -1)], self.skip_proj.weight,
+                                  self.skip_proj.bias).view(b, s, -1)
+        if head_ok and qkv is None:
             if GF.NormQKVFn.eligible(x, self.attn_norm.weight, wts, spec):
                 # attn_norm, the three projections and RoPE in ONE launch, written as the attention kernels' image
                 outs = GF.NormQKVFn.apply(x, self.attn_norm.weight, self.attn_norm.eps, bool(want_input_tap), spec, *wts)
@@ -373,6 +381,7 @@ class Transformer(nn.Module):
             GF.prepack_ffn(zip(ffn[0::2], ffn[1::2]), self.training and torch.is_grad_enabled(), wos=[blk.attn.o_proj.weight for blk in blocks])
             GF.prepack_qkv([GF.fused_view([blk.attn.q_proj.weight, blk.attn.k_proj.weight, blk.attn.v_proj.weight]) for blk in blocks]
                            if torch.is_grad_enabled() else [])
+            GF.prepack_skip([blk.skip_proj.weight for blk in blocks if blk.skip_connection] if torch.is_grad_enabled() else [])
             if self.training and getattr(self, "_seq_group", None) is None and SEED_BLOCK["on"]:
                 # the attention seeds of all blocks with ONE launch (each block draws its own otherwise)
                 n_drop = sum(1 for blk in blocks if float(blk.attn.atten_dropout) > 0.0 and blk.attn.head_dim == 32)

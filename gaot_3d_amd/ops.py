@@ -948,6 +948,47 @@ def qkv_pack_multi(ws, with_backward: bool) -> List[Tensor]:
     return outs
 
 
+def skip_pack_multi(ws) -> List[Tensor]:
+    """skip_proj weights ([256, 512] fp32) of the decoder blocks as fragment images in ONE launch (gaot_skip_pack_multi)"""
+    lib = _lib.load()
+    ws = list(ws)
+    if not ws:
+        return []
+    nb = int(lib.gaot_skip_packed_bytes())
+    buf = torch.empty(len(ws) * nb, dtype=torch.uint8, device=ws[0].device)
+    outs = [buf[i * nb:(i + 1) * nb] for i in range(len(ws))]
+    items = (_QkvPackItem * len(ws))()
+    for i, (w, o) in enumerate(zip(ws, outs)):
+        if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (256, 512):
+            raise GaotError("skip_pack_multi: contiguous fp32 [256, 512] weights expected")
+        items[i] = _QkvPackItem(w.data_ptr(), o.data_ptr())
+    check(lib.gaot_skip_pack_multi(items, len(ws), _stream()), "gaot_skip_pack_multi")
+    return outs
+
+
+def cat_norm_qkv_image(xa: Tensor, xb: Tensor, skip_packed: Tensor, skip_bias: Optional[Tensor], norm_weight: Tensor, eps: float, packed: Tensor,
+                       b: int, s: int, h: int, hkv: int, freqs: Optional[Tensor], scale: float):
+    """skip_proj(cat([xa, xb])) + attn_norm + q | k | v image in one launch (gaot_cat_norm_qkv_image) ->
+    (image, x_out fp32 [rows, 256], yb, rstd)"""
+    lib = _lib.load()
+    rows = xa.shape[0]
+    for t in (xa, xb):
+        if t.dtype != torch.float32 or t.dim() != 2 or tuple(t.shape) != (rows, 256) or t.stride(1) != 1 or rows != b * s:
+            raise GaotError("cat_norm_qkv_image: fp32 [b * s, 256] inputs expected")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    bs = None if skip_bias is None else _req(skip_bias, torch.float32, "skip_bias")
+    img = _ws(lib.gaot_attn_bf16_image_bytes(b, s, h, hkv), xa.device)
+    xo = torch.empty(rows, 256, dtype=torch.float32, device=xa.device)
+    yb = torch.empty(rows, 256, dtype=torch.bfloat16, device=xa.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=xa.device)
+    table = rope_table(freqs, s) if freqs is not None else None
+    with _timed("cat_norm_qkv_image"):
+        check(lib.gaot_cat_norm_qkv_image(_ptr(xa), xa.stride(0), _ptr(xb), xb.stride(0), _ptr(skip_packed), _ptr(bs), _ptr(xo), _ptr(nw), float(eps),
+                                          _ptr(packed), _ptr(img), _ptr(yb), _ptr(rstd), rows, s, h, hkv, _ptr(table), _qscale(scale), _stream()),
+              "gaot_cat_norm_qkv_image")
+    return img, xo, yb, rstd
+
+
 def norm_qkv_image(x: Tensor, norm_weight: Tensor, eps: float, packed: Tensor, b: int, s: int, h: int, hkv: int, freqs: Optional[Tensor],
                    scale: float):
     """attn_norm + q | k | v projection written as the attention kernels' bf16 image in one launch (gaot_norm_qkv_image) ->

@@ -350,6 +350,13 @@ int64_t gaot_qkv_packed_bytes(int64_t N, int with_backward);
 int gaot_qkv_pack_multi(const gaot_qkv_pack_t* items, int num, int64_t N, int with_backward, gaot_stream_t stream);
 int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* norm_weight, float eps, const void* packed, void* image, void* yb,
                         float* rstd, int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
+/* gaot_norm_qkv_image with the decoder block's skip projection in front (attn.py:222-225: x = skip_proj(cat([x, skip]))): xa, xb fp32
+ * [rows][256]; gaot_skip_pack_multi packs skip_proj.weight ([256][512], gaot_skip_packed_bytes() per block); x_out = the projected rows */
+int64_t gaot_skip_packed_bytes(void);
+int gaot_skip_pack_multi(const gaot_qkv_pack_t* items, int num, gaot_stream_t stream);
+int gaot_cat_norm_qkv_image(const float* xa, int64_t ldxa, const float* xb, int64_t ldxb, const void* skip_packed, const float* skip_bias,
+                            float* x_out, const float* norm_weight, float eps, const void* packed, void* image, void* yb, float* rstd,
+                            int64_t rows, int S, int H, int HKV, const float* rope_table, float qscale, gaot_stream_t stream);
 /* RMSNorm backward as the epilogue of the product that forms d(norm(x)) (ABI 11; reference attn.py:167-178 autograd):
  *  gaot_ffn_bwd_norm  = gaot_ffn_bwd + gaot_rmsnorm_bwd(ffn_norm): dh instead of d(norm(h)); h, rstd as saved by the forward
  *  gaot_qkv_bwd_norm  = gaot_gemm_ex (d(norm x) = dqkv Wqkv, packed WITH the backward image) + gaot_rmsnorm_bwd2(attn_norm): dx, with the

@@ -184,3 +184,43 @@ def test_norm_ffn_block_half_equals_norm_then_ffn(rows, f, mode):
         worst = max(worst, err)
         assert err < (5e-4 if n == "y" else 4e-3) and cos > 0.99999, f"{n}: max diff / peak {err:.3e}, cosine {cos:.7f}"
     print(f"[parity] {mode} rows={rows} F={f}: fused vs the unfused operators, worst max-diff / peak over y and {len(names) - 1} gradients {worst:.2e}")
+
+
+@pytest.mark.parametrize("same", [False, True])
+def test_decoder_block_with_skip_projection_in_the_head_kernel(same):
+    """CatNormQKVFn (skip_proj + attn_norm + q | k | v + RoPE in one forward launch, reference attn.py:222-229) against cat_linear followed by
+    the fused head, on a decoder block; ``same``: the block's input and its skip are one tensor (the first decoder block of the U-ViT)"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.model.layers import attn as A
+    torch.manual_seed(5)
+    rows = 4096
+    blk = A.TransformerBlock(256, 256, attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0,
+                                                                      positional_embedding="rope"),
+                             ffn_config=A.FFNConfig(hidden_size=512), skip_connection=True).to(DEV).train()
+    x = torch.randn(1, rows, 256, device=DEV, requires_grad=True)
+    sk = x if same else torch.randn(1, rows, 256, device=DEV, requires_grad=True)
+    gaot_3d_amd.set_precision("bf16")
+    out = {}
+    try:
+        for on in (False, True):
+            GF._CAT_QKV = on
+            for p in blk.parameters():
+                p.grad = None
+            x.grad = None
+            sk.grad = None
+            y = blk(x, relative_positions=True, skip=sk)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            out[on] = [y.detach().clone(), x.grad.clone(), sk.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
+    finally:
+        GF._CAT_QKV = True
+        gaot_3d_amd.set_precision("fp32")
+    names = ["y", "dx", "dskip"] + [n for n, p in blk.named_parameters() if p.requires_grad]
+    worst = 0.0
+    for n, a, b in zip(names, out[False], out[True]):
+        err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+        cos = torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+        worst = max(worst, err)
+        assert err < (5e-4 if n == "y" else 4e-3) and cos > 0.99999, f"{n}: max diff / peak {err:.3e}, cosine {cos:.7f}"
+    print(f"[parity] cat_qkv same={same}: fused vs cat_linear + head, worst max-diff / peak {worst:.2e}")
