@@ -857,9 +857,10 @@ __global__ __launch_bounds__(256, 1) void k_ffn_bwd(const bf16_t* __restrict__ X
 // rows in order through a [64][260] fp32 LDS image (pitch 1 040 B: the 16-byte stores of eight consecutive rows cover all banks).
 // `lds` must be free for 64 * 1040 + 1024 bytes; every wave of the workgroup calls this (two barriers inside).
 constexpr int NB_PITCH = 260, NB_LDS = 64 * NB_PITCH * 4 + 1024;
+// `dxtile` (may be null): the dx rows also leave as a bf16 [64][256] LDS tile (slot s of row r = chunk s ^ (r & 15)) for a product that follows.
 __device__ __forceinline__ void norm_bwd_epilogue(f32x16 (&dn)[2][2], char* lds, const float* __restrict__ X, int ldx, const float* __restrict__ NW,
                                                   const float* __restrict__ RSTD, const float* __restrict__ DRES, const float* __restrict__ DTAP,
-                                                  float* __restrict__ DX, float* __restrict__ DWP, int M, int m0, int blk) {
+                                                  float* __restrict__ DX, float* __restrict__ DWP, int M, int m0, int blk, char* dxtile = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
     float* T = reinterpret_cast<float*>(lds);
     float* part = reinterpret_cast<float*>(lds + 64 * NB_PITCH * 4);      // [4 waves][64 rows]
@@ -891,7 +892,8 @@ __device__ __forceinline__ void norm_bwd_epilogue(f32x16 (&dn)[2][2], char* lds,
         const int ml = 32 * i + l31, m = m0 + ml;
         const float dot = ((part[ml] + part[64 + ml]) + part[128 + ml]) + part[192 + ml];
         const float r = rs[i], c = dot * r * r * r / (float)D;
-        if (m < M) {
+        if (m < M || dxtile) {      // with a tile, rows past M go through as well (finite or not, a row of the product that follows depends on its own row only)
+            const bool live = m < M;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -900,9 +902,13 @@ __device__ __forceinline__ void norm_bwd_epilogue(f32x16 (&dn)[2][2], char* lds,
                     const f32x4 g = *reinterpret_cast<const f32x4*>(NW + col), v = xv[i][jt][q];
                     f32x4 o = {r * g[0] * dn[jt][i][4 * q] - v[0] * c, r * g[1] * dn[jt][i][4 * q + 1] - v[1] * c,
                                r * g[2] * dn[jt][i][4 * q + 2] - v[2] * c, r * g[3] * dn[jt][i][4 * q + 3] - v[3] * c};
-                    if (DRES) o += *reinterpret_cast<const f32x4*>(DRES + (int64_t)m * D + col);
-                    if (DTAP) o += *reinterpret_cast<const f32x4*>(DTAP + (int64_t)m * D + col);
-                    *reinterpret_cast<f32x4*>(DX + (int64_t)m * D + col) = o;
+                    if (DRES && live) o += *reinterpret_cast<const f32x4*>(DRES + (int64_t)m * D + col);
+                    if (DTAP && live) o += *reinterpret_cast<const f32x4*>(DTAP + (int64_t)m * D + col);
+                    if (live) *reinterpret_cast<f32x4*>(DX + (int64_t)m * D + col) = o;
+                    if (dxtile) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2*>(dxtile + ml * 512 + (((8 * wave + 4 * jt + q) ^ (ml & 15)) << 4) + 8 * hf) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                    }
                 }
         }
     }
@@ -1604,6 +1610,11 @@ __global__ void k_skip_pack(QkvTable t) {
         const int lane = id & 63, s2 = (id >> 6) & 31, jt = (id >> 11) & 1, wv = id >> 12;
         const float* src = w + (int64_t)(64 * wv + 32 * jt + (lane & 31)) * (2 * D) + 16 * s2 + 8 * (lane >> 5);
         *reinterpret_cast<u32x4*>(p + (int64_t)id * 8) = u32x4{pack2(src[0], src[1]), pack2(src[2], src[3]), pack2(src[4], src[5]), pack2(src[6], src[7])};
+        // the transposed image behind it: block ((half*4 + w)*2 + jt)*16 + s: "row" j = 256 half + 64 w + 32 jt + l31, k = 16 s + 8 hf + e -> w[k][j]
+        const int s3 = (id >> 6) & 15, jt3 = (id >> 10) & 1, w3 = (id >> 11) & 3, half = id >> 13;
+        const float* st = w + (int64_t)(16 * s3 + 8 * (lane >> 5)) * (2 * D) + (256 * half + 64 * w3 + 32 * jt3 + (lane & 31));
+        *reinterpret_cast<u32x4*>(p + (int64_t)D * 2 * D + (int64_t)id * 8) =
+            u32x4{pack2(st[0], st[2 * D]), pack2(st[4 * D], st[6 * D]), pack2(st[8 * D], st[10 * D]), pack2(st[12 * D], st[14 * D])};
     }
 }
 
@@ -1948,7 +1959,7 @@ extern "C" int gaot_norm_qkv_image(const float* x, int64_t ldx, const float* nor
 // the same with the decoder block's skip projection in front (reference attn.py:222-225: x = skip_proj(cat([x, skip]))): xa, xb fp32
 // [rows][256] (ldxa, ldxb), skip_packed = gaot_skip_pack_multi's image of skip_proj.weight ([256][512]), skip_bias [256] or NULL;
 // x_out receives the projected rows (fp32 [rows][256]).  Stands in for two gaot_gemm launches + gaot_rmsnorm_fwd + gaot_qkv_image.
-extern "C" int64_t gaot_skip_packed_bytes(void) { return (int64_t)D * 2 * D * 2; }
+extern "C" int64_t gaot_skip_packed_bytes(void) { return 2 * (int64_t)D * 2 * D * 2; }      // forward image + transposed image
 extern "C" int gaot_skip_pack_multi(const gaot_qkv_pack_t* items, int num, gaot_stream_t stream) {
     GAOT_ENTER();
     GAOT_CHECK_ARG(items && num > 0, "bad argument");
@@ -2043,8 +2054,13 @@ namespace {
 struct QkvBwdArgs {
     const float* DQKV; const u32x4* WTp; const float* X; int ldx; const float* NW; const float* RSTD; const float* DRES; const float* DTAP;
     float* DX; float* DWP; int M, N;
+    // CATB: the decoder block's skip projection behind x (x = skip_proj(cat([xa, xb])), attn.py:222-225): its two input gradients
+    // dxa = dx Ws[:, :256], dxb = dx Ws[:, 256:] from the dx rows on chip (bf16 tile); WSTp = fragments of Ws^T: blocks
+    // ((half*4 + w)*2 + jt)*16 + s: "row" 256 half + 64 w + 32 jt + l31, k = 16 s + 8 hf + e -> ws[k][row]; same: xa is xb, one sum
+    const u32x4* WSTp; float* DXA; float* DXB; int same;
 };
-constexpr int QKVB_LDS = NB_LDS > 2 * H_BYTES ? NB_LDS : 2 * H_BYTES;
+constexpr int QKVB_LDS = NB_LDS > 2 * H_BYTES ? NB_LDS : 2 * H_BYTES, QKVB_LDS_CAT = NB_LDS + H_BYTES;
+template <bool CATB>
 __global__ __launch_bounds__(256, 1) void k_qkv_bwd_norm(QkvBwdArgs a) {
     constexpr int RD = 3, LA = 2;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -2127,7 +2143,69 @@ __global__ __launch_bounds__(256, 1) void k_qkv_bwd_norm(QkvBwdArgs a) {
         if (sl + 1 < NS) gstore(lds + ((sl + 1) & 1) * H_BYTES);
         __builtin_amdgcn_s_barrier();
     }
-    norm_bwd_epilogue(acc, lds, a.X, a.ldx, a.NW, a.RSTD, a.DRES, a.DTAP, a.DX, a.DWP, M, m0, t);
+    if constexpr (!CATB) {
+        norm_bwd_epilogue(acc, lds, a.X, a.ldx, a.NW, a.RSTD, a.DRES, a.DTAP, a.DX, a.DWP, M, m0, t);
+    } else {
+        char* dxt = lds + NB_LDS;
+        norm_bwd_epilogue(acc, lds, a.X, a.ldx, a.NW, a.RSTD, a.DRES, a.DTAP, a.DX, a.DWP, M, m0, t, dxt);
+        __builtin_amdgcn_s_barrier();       // the bf16 dx tile is complete
+        int sw2 = l31 & 15;
+        asm volatile("" : "+v"(sw2));       // keeps the tile addresses below from being formed (and held) at the top of the kernel
+        const __amdgpu_buffer_rsrc_t wsrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.WSTp, 0, D * 2 * D * 2, 0x00020000);
+        u32x4 wo[2][8];
+        auto woload = [&](u32x4 (&dst)[8], int g) {      // g = 4 half + st: k-steps 4 st .. + 3 of the half's product
+            const int half = g >> 2, st = g & 3;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    dst[jt * 4 + s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrs, lane * 16, (((((half * 4 + wv) * 2 + jt) * 16) + 4 * st + s2)) * 1024, 0));
+        };
+        woload(wo[0], 0);
+        woload(wo[1], 1);
+        f32x16 ga[2][2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 0 || !a.same) {
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ga[jt][i][r] = 0.f;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int g = 4 * half + st;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int slot = ((2 * (4 * st + s2) + hf) ^ sw2) << 4;
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(dxt + l31 * 512 + slot), a1 = *reinterpret_cast<const bf16x8*>(dxt + (32 + l31) * 512 + slot);
+                    const bf16x8 w0 = __builtin_bit_cast(bf16x8, wo[g & 1][s2]), w1 = __builtin_bit_cast(bf16x8, wo[g & 1][4 + s2]);
+                    ga[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, ga[0][0], 0, 0, 0);
+                    ga[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, ga[1][0], 0, 0, 0);
+                    ga[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, ga[0][1], 0, 0, 0);
+                    ga[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, ga[1][1], 0, 0, 0);
+                }
+                if (g + 2 < 8) woload(wo[g & 1], g + 2);
+            }
+            if (half == 1 || !a.same) {       // same: both halves' products accumulate into ONE gradient, written after the second
+                float* out = (half == 0 || a.same) ? a.DXA : a.DXB;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + 32 * i + l31;
+                    if (m < M) {
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                *reinterpret_cast<f32x4*>(out + (int64_t)m * D + wave * 64 + 32 * jt + 8 * q + 4 * hf) =
+                                    f32x4{ga[jt][i][4 * q], ga[jt][i][4 * q + 1], ga[jt][i][4 * q + 2], ga[jt][i][4 * q + 3]};
+                    }
+                }
+            }
+        }
+    }
 }
 }  // namespace
 
@@ -2144,16 +2222,50 @@ extern "C" int gaot_qkv_bwd_norm(const float* dqkv, int64_t N, const void* packe
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_bwd_norm, hipFuncAttributeMaxDynamicSharedMemorySize, QKVB_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_bwd_norm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, QKVB_LDS);
         if (e != hipSuccess) {
             gaot_set_error("qkv_bwd_norm: cannot set dynamic LDS %d: %s", QKVB_LDS, hipGetErrorString(e));
             return GAOT_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    const QkvBwdArgs a{dqkv, (const u32x4*)((const bf16_t*)packed + N * D), x, (int)ldx, norm_weight, rstd, dres, dtap, dx, dw_part, (int)rows, (int)N};
+    const QkvBwdArgs a{dqkv, (const u32x4*)((const bf16_t*)packed + N * D), x, (int)ldx, norm_weight, rstd, dres, dtap, dx, dw_part, (int)rows, (int)N,
+                       nullptr, nullptr, nullptr, 0};
     const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
-    GAOT_KLAUNCH(k_qkv_bwd_norm, dim3((unsigned)(8 * per)), dim3(256), QKVB_LDS, (hipStream_t)stream, a);
+    GAOT_KLAUNCH(k_qkv_bwd_norm<false>, dim3((unsigned)(8 * per)), dim3(256), QKVB_LDS, (hipStream_t)stream, a);
+    GAOT_LAUNCH_CHECK();
+    return GAOT_OK;
+}
+
+// the same for a decoder block (x = skip_proj(cat([xa, xb]))): also the skip projection's two input gradients dxa = dx Ws[:, :256],
+// dxb = dx Ws[:, 256:] (fp32 [rows][256] each; same != 0: xa is xb -- one gradient, the sum, in dxa; dxb unused) from the dx rows on chip.
+// skip_packed: gaot_skip_pack_multi's image WITH the transposed image behind it (gaot_skip_packed_bytes() covers both).
+extern "C" int gaot_qkv_bwd_norm_cat(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
+                                     const float* rstd, const float* dres, const void* skip_packed, float* dx, float* dxa, float* dxb, int same,
+                                     float* dw_part, int64_t rows, gaot_stream_t stream) {
+    GAOT_ENTER();
+    GAOT_CHECK_ARG(dqkv && packed && x && norm_weight && rstd && skip_packed && dx && dxa && (dxb || same) && dw_part && rows > 0 && N > 0 && N % 256 == 0,
+                   "bad argument (N must be a multiple of 256)");
+    GAOT_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 &&
+                   ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dxa % 16) == 0 && ((uintptr_t)dxb % 16) == 0 &&
+                   ((uintptr_t)skip_packed % 16) == 0 && ldx % 4 == 0 && ldx >= D, "16-byte alignment");
+    if (rows * N * 4 >= 0x7fffffff) {
+        gaot_set_error("gaot_qkv_bwd_norm_cat: too many rows for 32-bit buffer offsets");
+        return GAOT_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_qkv_bwd_norm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, QKVB_LDS_CAT);
+        if (e != hipSuccess) {
+            gaot_set_error("qkv_bwd_norm_cat: cannot set dynamic LDS %d: %s", QKVB_LDS_CAT, hipGetErrorString(e));
+            return GAOT_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const QkvBwdArgs a{dqkv, (const u32x4*)((const bf16_t*)packed + N * D), x, (int)ldx, norm_weight, rstd, dres, nullptr, dx, dw_part, (int)rows, (int)N,
+                       (const u32x4*)((const bf16_t*)skip_packed + (int64_t)D * 2 * D), dxa, dxb, same};
+    const int nblk = ((int)rows + RB - 1) / RB, per = (nblk + 7) / 8;
+    GAOT_KLAUNCH(k_qkv_bwd_norm<true>, dim3((unsigned)(8 * per)), dim3(256), QKVB_LDS_CAT, (hipStream_t)stream, a);
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }

@@ -125,6 +125,7 @@ def prepack_qkv(wcats) -> None:
 
 
 _SKIP_PACK_CACHE: dict = {}      # (address, shape) of a decoder block's fp32 skip_proj weight -> its fragment image (prepack_skip)
+_CAT_BWD_DX = os.environ.get("GAOT_CAT_BWD_DX", "1") != "0"  # ... and its two input gradients inside the head's backward kernel (A/B switch)
 _CAT_QKV = os.environ.get("GAOT_CAT_QKV", "1") != "0"        # the decoder block's skip projection inside the head kernel (A/B switch)
 
 
@@ -885,7 +886,7 @@ class CatNormQKVFn(Function):
         img, xo, yb, rstd = ops.cat_norm_qkv_image(xa, xb, spk, bskip, norm_w, eps, packed, b, s, h, hkv, freqs, scale)
         out = torch.empty(1, dtype=torch.float32, device=x.device).expand(m, ntot)   # shape only
         out._gaot_qkv_image = img
-        ctx.save_for_backward(xa, xb, xo, norm_w, rstd, yb, _wb(wcat32, 1), packed, _wb(wsk, 1))
+        ctx.save_for_backward(xa, xb, xo, norm_w, rstd, yb, _wb(wcat32, 1), packed, _wb(wsk, 1), spk)
         ctx.wparams, ctx.nparam, ctx.sparams = tuple(weights), norm_w, (wskip, bskip)
         ctx.meta = (x.shape, skip.shape, [w.shape for w in weights], ntot, wskip.shape)
         ctx.set_materialize_grads(False)
@@ -893,13 +894,17 @@ class CatNormQKVFn(Function):
 
     @staticmethod
     def backward(ctx, dqkv: Tensor, dres: Optional[Tensor] = None):
-        xa, xb, xo, norm_w, rstd, yb, wcat, packed, wskb = ctx.saved_tensors
+        xa, xb, xo, norm_w, rstd, yb, wcat, packed, wskb, spk = ctx.saved_tensors
         xshape, sshape, wshapes, ntot, wsshape = ctx.meta
         m = xa.shape[0]
         d = dqkv if dqkv.is_contiguous() else dqkv.contiguous()
         dwcat = _dw_gemm(d, yb, ntot, 256, m, ntot, 256, 1, ctx.wparams)
         dres2 = None if dres is None else dres.reshape(m, 256)
-        if _NORM_BWD_FUSED:
+        dxa = dxb = None
+        fused_dx = _NORM_BWD_FUSED and _CAT_BWD_DX and ctx.needs_input_grad[0] and (ctx.same or ctx.needs_input_grad[1])
+        if fused_dx:    # the projection's two input gradients leave the same launch (k_qkv_bwd_norm<CATB>)
+            dxo, dxa, dxb, dnw = ops.qkv_bwd_norm_cat(d, packed, xo, norm_w, rstd, dres2, spk, ctx.same, defer=ops.defer_ok((ctx.nparam,)))
+        elif _NORM_BWD_FUSED:
             dxo, dnw = ops.qkv_bwd_norm(d, packed, xo, norm_w, rstd, dres2, None, defer=ops.defer_ok((ctx.nparam,)))
         else:
             dn = ops.gemm(d, wcat, m, 256, ntot, ntot, 256, False, False, precision=1)
@@ -907,12 +912,12 @@ class CatNormQKVFn(Function):
         # the skip projection's backward (CatLinearFn.backward on [xa | xb] W^T + b)
         n, k = 256, 512
         wsk, bsk = ctx.sparams
-        dxa = ops.gemm(dxo, wskb, m, 256, n, n, k, False, False, precision=1) if (ctx.needs_input_grad[0] or ctx.same) else None
-        if ctx.same and ctx.needs_input_grad[0]:
-            dxa = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, residual=dxa, ldr=256, precision=1)
-            dxb = None
-        else:
-            dxb = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, precision=1) if ctx.needs_input_grad[1] else None
+        if not fused_dx:
+            dxa = ops.gemm(dxo, wskb, m, 256, n, n, k, False, False, precision=1) if (ctx.needs_input_grad[0] or ctx.same) else None
+            if ctx.same and ctx.needs_input_grad[0]:
+                dxa = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, residual=dxa, ldr=256, precision=1)
+            else:
+                dxb = ops.gemm(dxo, wskb[:, 256:], m, 256, n, n, k, False, False, precision=1) if ctx.needs_input_grad[1] else None
         dws = torch.empty(n, k, dtype=torch.float32, device=d.device)
         ops.gemm(dxo, xa, n, 256, m, n, 256, True, False, out=dws, ldc=k, precision=1)
         ops.gemm(dxo, xb, n, 256, m, n, 256, True, False, out=dws[:, 256:], ldc=k, precision=1)

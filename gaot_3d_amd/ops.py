@@ -1068,6 +1068,32 @@ def qkv_bwd_norm(dqkv: Tensor, packed: Tensor, x: Tensor, norm_weight: Tensor, r
     return dx, _finish_parts(part, 256, parts, 32, defer)
 
 
+def qkv_bwd_norm_cat(dqkv: Tensor, packed: Tensor, x: Tensor, norm_weight: Tensor, rstd: Tensor, dres: Optional[Tensor], skip_packed: Tensor,
+                     same: bool, defer: bool = False):
+    """qkv_bwd_norm for a decoder block (include/gaot3d_hip.h: gaot_qkv_bwd_norm_cat): also the skip projection's two input gradients
+    from the dx rows on chip -> (dx, dxa, dxb or None when ``same`` (dxa then holds the sum), d(norm weight))"""
+    lib = _lib.load()
+    rows, n = dqkv.shape
+    if dqkv.dtype != torch.float32 or not dqkv.is_contiguous() or n % 256:
+        raise GaotError("qkv_bwd_norm_cat: contiguous fp32 [rows, N] gradient with N a multiple of 256 expected")
+    if x.dtype != torch.float32 or tuple(x.shape) != (rows, 256) or x.stride(1) != 1:
+        raise GaotError("qkv_bwd_norm_cat: fp32 [rows, 256] norm input expected")
+    if skip_packed.numel() != int(lib.gaot_skip_packed_bytes()):
+        raise GaotError("qkv_bwd_norm_cat: skip_packed is not a skip_pack_multi image")
+    nw = _req(norm_weight, torch.float32, "norm_weight")
+    dres = None if dres is None else _req(dres, torch.float32, "dres")
+    dev = dqkv.device
+    dx = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    dxa = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    dxb = None if same else torch.empty(rows, 256, dtype=torch.float32, device=dev)
+    parts = int(lib.gaot_norm_bwd_parts(rows))
+    part = torch.empty(parts, 256, dtype=torch.float32, device=dev)
+    with _timed("qkv_bwd_norm_cat"):
+        check(lib.gaot_qkv_bwd_norm_cat(_ptr(dqkv), n, _ptr(packed), _ptr(x), x.stride(0), _ptr(nw), _ptr(rstd), _ptr(dres), _ptr(skip_packed),
+                                        _ptr(dx), _ptr(dxa), _ptr(dxb), int(bool(same)), _ptr(part), rows, _stream()), "gaot_qkv_bwd_norm_cat")
+    return dx, dxa, dxb, _finish_parts(part, 256, parts, 32, defer)
+
+
 def oproj_bwd_image(dh: Tensor, attn_out: Tensor, packed: Tensor, f: int, b: int, s: int, h: int, hkv: int):
     """d_o = dh Wo as the flash backward's operands (include/gaot3d_hip.h: gaot_oproj_bwd_image): -> (an attn_bwd_scratch buffer whose head
     holds the bf16 dO image, delta fp32 [b, h, s]) for attn_bwd_bf16(do_image=..., delta=...)"""

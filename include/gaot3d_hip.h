@@ -367,6 +367,11 @@ int gaot_ffn_bwd_norm(const void* yb, const float* dy, const void* packed, const
                       const float* rstd, void* dag, void* u, void* dyb, float* dh, float* dw_part, int64_t rows, int F, gaot_stream_t stream);
 int gaot_qkv_bwd_norm(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
                       const float* rstd, const float* dres, const float* dtap, float* dx, float* dw_part, int64_t rows, gaot_stream_t stream);
+/* gaot_qkv_bwd_norm for a decoder block (x = skip_proj(cat([xa, xb]))): also dxa = dx Ws[:, :256] and dxb = dx Ws[:, 256:] from the dx
+ * rows on chip (same != 0: xa is xb -- their sum in dxa); skip_packed = gaot_skip_pack_multi's image (it carries Ws^T as well) */
+int gaot_qkv_bwd_norm_cat(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
+                          const float* rstd, const float* dres, const void* skip_packed, float* dx, float* dxa, float* dxb, int same,
+                          float* dw_part, int64_t rows, gaot_stream_t stream);
 /* the o_proj backward's input gradient d_o = dh Wo written straight as the flash backward's operands (attn.py:122-127 autograd): the
  * bf16 dO image [rows][256] and delta[rows / S][8][S] = sum over a head's 32 columns of d_o * attn_out -- stands in for gaot_gemm_ex and
  * phase 1 of gaot_attn_bwd_bf16 (call it with phases 16 | 32 only).  packed: a block image of gaot_block_pack_multi. */

@@ -224,3 +224,44 @@ def test_decoder_block_with_skip_projection_in_the_head_kernel(same):
         worst = max(worst, err)
         assert err < (5e-4 if n == "y" else 4e-3) and cos > 0.99999, f"{n}: max diff / peak {err:.3e}, cosine {cos:.7f}"
     print(f"[parity] cat_qkv same={same}: fused vs cat_linear + head, worst max-diff / peak {worst:.2e}")
+
+
+@pytest.mark.parametrize("same", [False, True])
+def test_skip_projection_input_gradients_inside_the_head_backward(same):
+    """gaot_qkv_bwd_norm_cat (the skip projection's two input gradients from the dx rows on chip) against the two stand-alone products on
+    the same dx, on a decoder block whose row count is not a multiple of the 64-row block"""
+    import gaot_3d_amd
+    from gaot_3d_amd import functional as GF
+    from gaot_3d_amd.model.layers import attn as A
+    torch.manual_seed(6)
+    rows = 4096 + 40
+    blk = A.TransformerBlock(256, 256, attn_config=A.AttentionConfig(hidden_size=256, num_heads=8, num_kv_heads=8, atten_dropout=0.0,
+                                                                      positional_embedding="rope"),
+                             ffn_config=A.FFNConfig(hidden_size=512), skip_connection=True).to(DEV).train()
+    x = torch.randn(1, rows, 256, device=DEV, requires_grad=True)
+    sk = x if same else torch.randn(1, rows, 256, device=DEV, requires_grad=True)
+    gaot_3d_amd.set_precision("bf16")
+    out = {}
+    try:
+        for on in (False, True):
+            GF._CAT_BWD_DX = on
+            for p in blk.parameters():
+                p.grad = None
+            x.grad = None
+            sk.grad = None
+            y = blk(x, relative_positions=True, skip=sk)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            out[on] = [x.grad.clone(), sk.grad.clone()] + [p.grad.clone() for p in blk.parameters() if p.requires_grad]
+    finally:
+        GF._CAT_BWD_DX = True
+        gaot_3d_amd.set_precision("fp32")
+    names = ["dx", "dskip"] + [n for n, p in blk.named_parameters() if p.requires_grad]
+    worst = 0.0
+    for n, a, b in zip(names, out[False], out[True]):
+        assert torch.isfinite(b).all(), n
+        err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+        worst = max(worst, err)
+        # same bf16 operands, fp32 accumulation in another order
+        assert err < 2e-5, f"{n}: max diff / peak {err:.3e}"
+    print(f"[parity] cat_bwd_dx same={same} rows={rows}: in-kernel vs stand-alone input gradients, worst max-diff / peak {worst:.2e}")
