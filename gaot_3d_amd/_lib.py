@@ -124,10 +124,6 @@ SIGNATURES = {
     "gaot_ffn_bwd_norm": (_i, [_p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_qkv_bwd_norm": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "gaot_qkv_bwd_norm_cat": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i64, _p]),
-    "gaot_timg_bytes": (_i64, [_i64, _i64]),
-    "gaot_timg_pack": (_i, [_p, _i, _i64, _i64, _i64, _p, _p]),
-    "gaot_dw_frag_splits": (_i, [_i64, _i64, _i64]),
-    "gaot_dw_frag": (_i, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "gaot_oproj_bwd_image": (_i, [_p, _p, _p, _i, _p, _p, _i64, _i, _p]),
     "gaot_ffn_bwd_dag": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "gaot_ffn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _p]),

@@ -1094,32 +1094,6 @@ def qkv_bwd_norm_cat(dqkv: Tensor, packed: Tensor, x: Tensor, norm_weight: Tenso
     return dx, dxa, dxb, _finish_parts(part, 256, parts, 32, defer)
 
 
-def timg_pack(x: Tensor) -> Tensor:
-    """row-major fp32 / bf16 [rows, cols] (cols % 128 == 0) -> its T-image (include/gaot3d_hip.h: gaot_timg_pack), the operand form of dw_frag"""
-    lib = _lib.load()
-    rows, cols = x.shape
-    if x.dtype not in (torch.float32, torch.bfloat16) or x.stride(1) != 1 or cols % 128:
-        raise GaotError("timg_pack: fp32 / bf16 [rows, cols] with unit column stride and cols a multiple of 128 expected")
-    img = torch.empty(int(lib.gaot_timg_bytes(rows, cols)), dtype=torch.uint8, device=x.device)
-    check(lib.gaot_timg_pack(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), rows, cols, _ptr(img), _stream()), "gaot_timg_pack")
-    return img
-
-
-def dw_frag(a_image: Tensor, b_image: Tensor, rows: int, n1: int, n2: int, defer: bool = False) -> Tensor:
-    """dW [n1, n2] = A^T B from the T-images of A [rows, n1] and B [rows, n2] (include/gaot3d_hip.h: gaot_dw_frag); ``defer``: the sum of
-    the split partials waits for flush_deferred (see defer_ok)"""
-    lib = _lib.load()
-    if a_image.numel() != int(lib.gaot_timg_bytes(rows, n1)) or b_image.numel() != int(lib.gaot_timg_bytes(rows, n2)):
-        raise GaotError("dw_frag: operand images do not match (rows, n1, n2)")
-    splits = int(lib.gaot_dw_frag_splits(rows, n1, n2))
-    if splits <= 0:
-        raise GaotError("dw_frag: n1 and n2 must be multiples of 128")
-    part = torch.empty(splits, n1 * n2, dtype=torch.float32, device=a_image.device)
-    with _timed("dw_frag"):
-        check(lib.gaot_dw_frag(_ptr(a_image), _ptr(b_image), rows, n1, n2, _ptr(part), _stream()), "gaot_dw_frag")
-    return _finish_parts(part, n1 * n2, splits, 4, defer).view(n1, n2)
-
-
 def oproj_bwd_image(dh: Tensor, attn_out: Tensor, packed: Tensor, f: int, b: int, s: int, h: int, hkv: int):
     """d_o = dh Wo as the flash backward's operands (include/gaot3d_hip.h: gaot_oproj_bwd_image): -> (an attn_bwd_scratch buffer whose head
     holds the bf16 dO image, delta fp32 [b, h, s]) for attn_bwd_bf16(do_image=..., delta=...)"""

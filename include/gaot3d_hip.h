@@ -372,15 +372,6 @@ int gaot_qkv_bwd_norm(const float* dqkv, int64_t N, const void* packed, const fl
 int gaot_qkv_bwd_norm_cat(const float* dqkv, int64_t N, const void* packed, const float* x, int64_t ldx, const float* norm_weight,
                           const float* rstd, const float* dres, const void* skip_packed, float* dx, float* dxa, float* dxb, int same,
                           float* dw_part, int64_t rows, gaot_stream_t stream);
-/* Weight gradients from operands in MFMA-fragment order (csrc/dw_frag.hip; reference attn.py:110-157, the .grad of the nn.Linear
- * weights).  T-image of X [rows][cols] bf16 (cols % 128 == 0): 1-KB blocks, block (g, ks, c) at ((g * KS + ks) * 4 + c) * 1024 with
- * KS = 4 * ceil(rows / 64); lane (l31, hf) holds X[16 ks + 8 (j >> 2) + 4 hf + (j & 3)][128 g + 32 c + l31], j = 0..7 (rows past the end: 0).
- * gaot_dw_frag writes gaot_dw_frag_splits(rows, n1, n2) partial products [n1][n2] fp32 whose fixed-order sum (gaot_reduce_multi) is
- * A^T B. */
-int64_t gaot_timg_bytes(int64_t rows, int64_t cols);
-int gaot_timg_pack(const void* x, int is_bf16, int64_t ld, int64_t rows, int64_t cols, void* image, gaot_stream_t stream);
-int gaot_dw_frag_splits(int64_t rows, int64_t n1, int64_t n2);
-int gaot_dw_frag(const void* a_image, const void* b_image, int64_t rows, int64_t n1, int64_t n2, float* part, gaot_stream_t stream);
 /* the o_proj backward's input gradient d_o = dh Wo written straight as the flash backward's operands (attn.py:122-127 autograd): the
  * bf16 dO image [rows][256] and delta[rows / S][8][S] = sum over a head's 32 columns of d_o * attn_out -- stands in for gaot_gemm_ex and
  * phase 1 of gaot_attn_bwd_bf16 (call it with phases 16 | 32 only).  packed: a block image of gaot_block_pack_multi. */

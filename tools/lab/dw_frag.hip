@@ -1,3 +1,4 @@
+// LAB (round 6; measured, not shipped -- DESIGN.md §8.3, profiles/r6_zg ... r6_zj; built by tools/lab/dw_frag_lab.py).
 // Weight-gradient products dW[n1][n2] = sum_m A[m][n1] B[m][n2] of the latent Transformer (reference attn.py:110-157: the autograd of
 // q | k | v, o_proj, w1 | w3, w2 -- nn.Linear.weight.grad) over operands that arrive ALREADY IN MFMA-FRAGMENT ORDER.
 //
@@ -51,11 +52,13 @@ __global__ void k_timg_pack(const T* __restrict__ X, int64_t ld, int M, int N, u
 struct DwArgs {
     const u32x4* A; const u32x4* B; float* part;
     int KS, n1g, n2g, splits;
+    int abl;      // lab only (GAOT_DW_FRAG_ABL): 1 = no cross-wave sum (wrong results: timing of the tail), 2 = no operand loads after the first
 };
 
-constexpr int RD = 3;                       // k-steps of operands in flight per wave (8 KB each)
 constexpr int DW_LDS = 2 * 65536;
 
+// RD - 1 = k-steps of operands in flight per wave (8 KB each)
+template <int RD>
 __global__ __launch_bounds__(256, 1) void k_dw_frag(DwArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_frag(DwArgs a) {
     for (int ks = k0; ks < k1; ks += RD) {
 #pragma unroll
         for (int s = 0; s < RD; ++s) {
-            load((s + RD - 1) % RD, ks + s + RD - 1);
+            if (!(a.abl & 2)) load((s + RD - 1) % RD, ks + s + RD - 1);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (RD - 1)) : "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -122,6 +125,10 @@ __global__ __launch_bounds__(256, 1) void k_dw_frag(DwArgs a) {
     };
     const char* mine = lds + (wv << 14) + lane * 16;      // quarter j = wv of region 0
     f32x4 sum[16];
+    if (a.abl & 1) {
+        if (wv == 0) put(0);
+        __syncthreads();
+    } else {
     if (wv < 2) put(wv);
     __syncthreads();
 #pragma unroll
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_frag(DwArgs a) {
     __syncthreads();
     if (wv >= 2) put(wv - 2);
     __syncthreads();
+    }
     const int N2 = a.n2g * 128;
     float* out = a.part + (int64_t)split * (a.n1g * 128) * N2 + (int64_t)(i1 * 128) * N2 + i2 * 128;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 128 * N2 * 4, 0x00020000);
@@ -165,7 +173,13 @@ extern "C" int gaot_timg_pack(const void* x, int is_bf16, int64_t ld, int64_t ro
 extern "C" int gaot_dw_frag_splits(int64_t rows, int64_t n1, int64_t n2) {
     if (rows <= 0 || n1 <= 0 || n2 <= 0 || n1 % 128 || n2 % 128) return 0;
     const int64_t tiles = (n1 / 128) * (n2 / 128), ks = ((rows + 63) / 64) * 4;
+    static int cap = -1;      // lab switch GAOT_DW_FRAG_MAXSPLITS
+    if (cap < 0) {
+        const char* e = getenv("GAOT_DW_FRAG_MAXSPLITS");
+        cap = e ? atoi(e) : 0;
+    }
     int64_t s = std::max<int64_t>(8, (256 / tiles) / 8 * 8);
+    if (cap >= 8) s = std::min<int64_t>(s, cap / 8 * 8);
     while (s > 8 && s * 4 > ks) s -= 8;      // at least one k-step per wave
     return (int)s;
 }
@@ -181,18 +195,38 @@ extern "C" int gaot_dw_frag(const void* a_image, const void* b_image, int64_t ro
         gaot_set_error("gaot_dw_frag: too many rows for 32-bit buffer offsets");
         return GAOT_ERR_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dw_frag, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
-        if (e != hipSuccess) {
-            gaot_set_error("dw_frag: cannot set dynamic LDS %d: %s", DW_LDS, hipGetErrorString(e));
+    static int rd = 0;      // lab switch GAOT_DW_RD (3..7), read once
+    if (!rd) {
+        const char* e = getenv("GAOT_DW_RD");
+        rd = e ? atoi(e) : 5;
+        if (rd < 3 || rd > 7) rd = 5;
+        hipError_t err = hipSuccess;
+        if (rd == 3) err = hipFuncSetAttribute((const void*)k_dw_frag<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (rd == 4) err = hipFuncSetAttribute((const void*)k_dw_frag<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (rd == 5) err = hipFuncSetAttribute((const void*)k_dw_frag<5>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (rd == 6) err = hipFuncSetAttribute((const void*)k_dw_frag<6>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (rd == 7) err = hipFuncSetAttribute((const void*)k_dw_frag<7>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (err != hipSuccess) {
+            rd = 0;
+            gaot_set_error("dw_frag: cannot set dynamic LDS %d: %s", DW_LDS, hipGetErrorString(err));
             return GAOT_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     const int splits = gaot_dw_frag_splits(rows, n1, n2);
-    const DwArgs a{(const u32x4*)a_image, (const u32x4*)b_image, part, (int)ks, (int)(n1 / 128), (int)(n2 / 128), splits};
-    GAOT_KLAUNCH(k_dw_frag, dim3((unsigned)(a.n1g * a.n2g * splits)), dim3(256), DW_LDS, (hipStream_t)stream, a);
+    static int abl = -1;
+    if (abl < 0) {
+        const char* e = getenv("GAOT_DW_FRAG_ABL");
+        abl = e ? atoi(e) : 0;
+    }
+    const DwArgs a{(const u32x4*)a_image, (const u32x4*)b_image, part, (int)ks, (int)(n1 / 128), (int)(n2 / 128), splits, abl};
+    const dim3 grid((unsigned)(a.n1g * a.n2g * splits));
+    switch (rd) {
+        case 3: GAOT_KLAUNCH(k_dw_frag<3>, grid, dim3(256), DW_LDS, (hipStream_t)stream, a); break;
+        case 4: GAOT_KLAUNCH(k_dw_frag<4>, grid, dim3(256), DW_LDS, (hipStream_t)stream, a); break;
+        case 5: GAOT_KLAUNCH(k_dw_frag<5>, grid, dim3(256), DW_LDS, (hipStream_t)stream, a); break;
+        case 6: GAOT_KLAUNCH(k_dw_frag<6>, grid, dim3(256), DW_LDS, (hipStream_t)stream, a); break;
+        default: GAOT_KLAUNCH(k_dw_frag<7>, grid, dim3(256), DW_LDS, (hipStream_t)stream, a); break;
+    }
     GAOT_LAUNCH_CHECK();
     return GAOT_OK;
 }
