@@ -529,6 +529,7 @@ class GradBuckets:
         self._hooks = []
         self._next = 0             # first bucket not launched yet: the only one a hook may launch
         self._unused = None        # ids of parameters NO rank produces a gradient for (refreshed at every eager finish())
+        self._late = set()         # ids of such parameters whose first gradient arrived behind their bucket's launch (this step)
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[id(p)] = bi
@@ -561,13 +562,20 @@ class GradBuckets:
 
     def _on_grad(self, p):
         b = self.buckets[self._index[id(p)]]
+        if id(p) in (self._unused or ()):
+            # a parameter no rank had a gradient for so far starts to receive one.  Its bucket does not wait for it: if the
+            # bucket has not left yet, _launch takes the gradient along; if it is in flight already, the gradient stays where
+            # autograd put it and the eager finish() of this step adds it to the bucket's sum on every rank (_find_unused).
+            # Either way the parameter counts towards its bucket from the next step on
+            if b["launched"]:
+                self._late.add(id(p))
+            return
         if b["launched"]:
             # a second backward before finish() (gradient accumulation) would accumulate in place into the flat buffer
             # while its all-reduce may still be in flight on the other communicator: refuse instead of racing
             raise RuntimeError("GradBuckets: a gradient arrived for a bucket whose all-reduce is already launched; call "
                                "finish() (or reset()) between two backward passes")
-        if id(p) not in (self._unused or ()):
-            b["pending"] -= 1
+        b["pending"] -= 1
         # index order: a complete bucket behind an incomplete one waits for it (finish() at the latest)
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] <= 0:
             self._launch(self.buckets[self._next])
@@ -624,6 +632,7 @@ class GradBuckets:
             self._launch(self.buckets[self._next])
         if eager:
             self._find_unused(had)         # AFTER the last bucket: the same position in every rank's sequence
+        self._late.clear()
         buckets = self.buckets
 
         def wait():
@@ -647,15 +656,32 @@ class GradBuckets:
         """one tiny all-reduce per eager step, issued behind the last bucket on every rank: which parameters got a gradient
         on NO rank.  Those keep ``grad = None`` as in an unsharded run (the optimizer skips them: reference semantics for
         ``skip_proj`` with ``use_long_range_skip=False``, attn.py:321); a parameter that only THIS rank has no gradient for
-        was zero-filled and now holds the other ranks' sum.  Refreshed every eager step, so a parameter that starts to
-        receive gradients later is picked up by every rank in the same step."""
+        was zero-filled and now holds the other ranks' sum.  Refreshed every eager step (every rank must take part, so no rank
+        can skip it on its own; the steady state is graph replay, where the set is frozen), so a parameter that starts to
+        receive gradients later is picked up by every rank in the same step: its gradient is summed over the ranks here,
+        outside its bucket, and it counts towards its bucket from the next step on."""
         ps = [p for b in self.buckets for p in b["params"]]
-        flags = torch.tensor(had, dtype=torch.float32, device=ps[0].device)
+        late = [1.0 if id(p) in self._late else 0.0 for p in ps]
+        flags = torch.tensor(list(had) + late, dtype=torch.float32, device=ps[0].device)
         dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
-        unused = {id(p) for p, f in zip(ps, flags.tolist()) if f == 0.0}
+        flags = flags.tolist()
+        unused = {id(p) for p, f in zip(ps, flags[:len(ps)]) if f == 0.0}
+        late_any = {id(p) for p, f in zip(ps, flags[len(ps):]) if f > 0.0}
         for b in self.buckets:
             for p, v in zip(b["params"], b["views"]):
-                if id(p) in unused:
+                if id(p) in late_any:
+                    # on some rank the first gradient of this parameter arrived behind its bucket's launch (the same decision
+                    # everywhere: it comes out of the all-reduce above).  The bucket's sum holds the ranks that were in time;
+                    # the late ranks' gradients are summed here and added to it, on every rank alike
+                    if b["handle"] is not None:
+                        b["handle"].wait()
+                        b["handle"] = None
+                    mine = p.grad if (id(p) in self._late and p.grad is not None) else torch.zeros_like(v)
+                    extra = mine.detach().clone()
+                    dist.all_reduce(extra, op=dist.ReduceOp.SUM, group=self.group)
+                    v.add_(extra)
+                    p.grad = v
+                elif id(p) in unused:
                     p.grad = None          # (a zero-filled view while the set was not known yet)
                 elif p.grad is None:
                     p.grad = v             # left None by an older set: the view holds the other ranks' sum

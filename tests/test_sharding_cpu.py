@@ -305,7 +305,26 @@ def _bucket_worker(rank, world, port, ret):
         except RuntimeError as e:
             refused = "already launched" in str(e)
         gb.reset()
-        ret[rank] = (grads_out, unused_none, launched, lonely_out, refused)
+        # `unused` starts to receive a gradient.  Step 0: on rank 0 only, in time for its bucket (which leaves in finish()
+        # there).  Then the set is re-learnt without it (two steps with no gradient).  Step 3: on both ranks, and on rank 1 -- which has
+        # `lonely` and therefore launches every bucket from its hooks -- it arrives BEHIND its bucket's launch: no error, the same sum
+        # on both ranks in that very step; step 4: an ordinary bucket member
+        late = []
+        for it in range(5):
+            for p in ps + [unused, lonely]:
+                p.grad = None
+            loss = 0.0
+            if it == 0 and rank == 0:
+                loss = loss + (unused * 3.0).sum()
+            if it >= 3:
+                loss = loss + (unused * (3.0 if rank == 0 else 5.0)).sum()      # created first: its gradient arrives last
+            loss = loss + sum(((p * (i + 1)) @ x).sum() for i, p in enumerate(ps))
+            if rank == 1:
+                loss = loss + (lonely @ x).sum()
+            loss.backward()
+            gb.finish()
+            late.append(None if unused.grad is None else unused.grad.clone())
+        ret[rank] = (grads_out, unused_none, launched, lonely_out, refused, late)
     finally:
         dist.destroy_process_group()
 
@@ -317,7 +336,7 @@ def test_grad_buckets_allreduce_from_hooks():
     mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
     xs = [torch.randn(7, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     for r in range(world):
-        grads, unused_none, in_bwd, lonely, refused = ret[r]
+        grads, unused_none, in_bwd, lonely, refused, late = ret[r]
         # complete buckets were launched while backward was still running, in index order: rank 1 has every gradient of
         # buckets 0 and 1, rank 0 only of bucket 0; once `unused` is known to be unused everywhere (after the first step) it
         # no longer holds the last bucket back on rank 1
@@ -325,6 +344,8 @@ def test_grad_buckets_allreduce_from_hooks():
         # the rank whose shard produced no gradient for `lonely` holds the other rank's gradient afterwards
         assert lonely is not None and torch.allclose(lonely, xs[1][None, :].expand(6, 7), rtol=1e-6, atol=1e-6)
         assert refused
+        assert torch.equal(late[0], torch.full((4, 4), 3.0)) and late[1] is None and late[2] is None, late
+        assert torch.equal(late[3], torch.full((4, 4), 8.0)) and torch.equal(late[4], torch.full((4, 4), 8.0)), late
         for i, gsum in enumerate(grads):
             ref = sum((i + 1) * x for x in xs)[None, :].expand_as(gsum)
             assert torch.allclose(gsum, ref, rtol=1e-6, atol=1e-6), i
