@@ -10,6 +10,13 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs torch's CPU kernels: on the pool's 256-thread hosts the default (all hardware threads) is several times SLOWER than
+    # 32 (profiles/r6_zm_attn_oracle_threads.txt: the eight S = 16 384 attention checks 2-5 s each on 32 threads, 5-6 s on 64, minutes on
+    # 256; bench.py's cpu_baseline measured 9x for the whole step).  Tests that know better set their own count.
+    import torch
+    n = os.cpu_count() or 1
+    if n > 32 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(int(os.environ.get("GAOT_ORACLE_THREADS", 32)))
 
 
 def pytest_collection_modifyitems(config, items):

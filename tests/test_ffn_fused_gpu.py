@@ -265,3 +265,46 @@ def test_skip_projection_input_gradients_inside_the_head_backward(same):
         # same bf16 operands, fp32 accumulation in another order
         assert err < 2e-5, f"{n}: max diff / peak {err:.3e}"
     print(f"[parity] cat_bwd_dx same={same} rows={rows}: in-kernel vs stand-alone input gradients, worst max-diff / peak {worst:.2e}")
+
+
+def test_row_block_entry_points_reject_bad_arguments():
+    """error behaviour of the ABI-11 entry points (include/gaot3d_hip.h): null / misaligned pointers, F or N outside the kernels' tiling and
+    a foreign pack image come back as GAOT_ERR_ARG with a message, nothing is launched"""
+    from gaot_3d_amd import _lib, ops
+    lib = _lib.load()
+    rows, f = 128, 256
+    xb = torch.zeros(rows, 256, device=DEV, dtype=torch.bfloat16)
+    x = torch.zeros(rows, 256, device=DEV)
+    y = torch.zeros(rows, 256, device=DEV)
+    w13 = torch.zeros(2 * f, 256, device=DEV)
+    w2 = torch.zeros(256, f, device=DEV)
+    packed = ops.ffn_pack(w13, w2, f, True)
+    st = ops._stream()
+    P = ops._ptr
+    ERR_ARG = 1
+    assert lib.gaot_ffn_fwd(None, P(packed), None, 0, P(y), None, None, rows, f, st) == ERR_ARG and b"gaot_ffn_fwd" in lib.gaot_last_error()
+    assert lib.gaot_ffn_fwd(P(xb), P(packed), None, 0, P(y), None, None, rows, 200, st) == ERR_ARG                 # F not a multiple of 128
+    assert lib.gaot_ffn_fwd(P(xb), P(packed), None, 0, P(y), None, None, 0, f, st) == ERR_ARG                      # no rows
+    assert lib.gaot_ffn_fwd(P(xb), packed.data_ptr() + 4, None, 0, P(y), None, None, rows, f, st) == ERR_ARG       # misaligned image
+    dag = torch.zeros(rows, 2 * f, device=DEV, dtype=torch.bfloat16)
+    u = torch.zeros(rows, f, device=DEV, dtype=torch.bfloat16)
+    assert lib.gaot_ffn_bwd(P(xb), P(y), P(packed), P(dag), P(u), None, None, 1, rows, f, st) == ERR_ARG            # no dx
+    rstd = torch.zeros(rows, device=DEV)
+    nw = torch.ones(256, device=DEV)
+    img = torch.zeros(rows * 768, device=DEV, dtype=torch.bfloat16)
+    wq = torch.zeros(768, 256, device=DEV)
+    qp = ops.qkv_pack_multi([wq], True)[0]
+    # (H + 2 HKV) * 32 must be a multiple of 256: 7 query heads are not
+    assert lib.gaot_norm_qkv_image(P(x), 256, P(nw), 1e-6, P(qp), P(img), P(xb), P(rstd), rows, rows, 7, 7, None, 1.0, st) == ERR_ARG
+    assert lib.gaot_norm_qkv_image(P(x), 250, P(nw), 1e-6, P(qp), P(img), P(xb), P(rstd), rows, rows, 8, 8, None, 1.0, st) == ERR_ARG   # ld < 256
+    dqkv = torch.zeros(rows, 768, device=DEV)
+    part = torch.zeros(int(lib.gaot_norm_bwd_parts(rows)), 256, device=DEV)
+    assert lib.gaot_qkv_bwd_norm(P(dqkv), 700, P(qp), P(x), 256, P(nw), P(rstd), None, None, P(y), P(part), rows, st) == ERR_ARG        # N % 256
+    assert lib.gaot_qkv_bwd_norm_cat(P(dqkv), 768, P(qp), P(x), 256, P(nw), P(rstd), None, None, P(y), P(y), None, 0, P(part), rows, st) == ERR_ARG
+    assert b"gaot_qkv_bwd_norm_cat" in lib.gaot_last_error()
+    # the Python wrappers refuse what the kernels cannot take before anything is called
+    with pytest.raises(_lib.GaotError):
+        ops.ffn_fwd(x, packed, f)                                    # fp32 rows where the bf16 input is expected
+    with pytest.raises(_lib.GaotError):
+        ops.qkv_bwd_norm_cat(dqkv, qp, x, nw, rstd, None, qp, False)    # a q|k|v image where the skip image is expected
+    torch.cuda.synchronize()

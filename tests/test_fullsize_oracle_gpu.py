@@ -36,6 +36,9 @@ def _attention_fp64(qkv, w, freqs, keep, p_eff, chunk=2048):
     """oracle.sdpa in fp64 on [1, 1, S, 32] operands, one query chunk at a time (S x S in fp64 is 2 GB): returns the
     output and the gradients of <out, w> with respect to the fused q | k | v projection"""
     s = qkv.shape[0]
+    # thread count as for the whole-step oracle below: all 256 hardware threads of the pool's hosts run torch's CPU kernels several
+    # times slower than 32-64 of them (bench.py's cpu_baseline measured 9x)
+    torch.set_num_threads(int(os.environ.get("GAOT_ORACLE_THREADS", min(os.cpu_count() or 1, 32))))
     x = qkv.double().requires_grad_(True)
     q, k, v = (t.view(1, s, 1, 32).transpose(1, 2) for t in x.split(32, dim=1))
     if freqs is not None:
@@ -251,19 +254,10 @@ def test_gno_full_graph_vs_oracle(sample, precision, side, nh):
     out = ops.gno_forward(ws, bs, y_pos, x_pos, f_y.to(DEV), graph, precision=prec)
     gf, gw, gb = ops.gno_backward(ws, bs, y_pos, x_pos, f_y.to(DEV), dout.to(DEV), graph, precision=prec)
     torch.cuda.synchronize()
-    # test plumbing on the device (round 6: the 64 M-edge index arithmetic took longer on the host than the oracle itself): degrees, and
-    # the edges of a set of sampled rows -- only those come to the host, where the oracle runs
-    src_d, dst_d = ei[0].long(), ei[1].long()
-    deg_dst = torch.bincount(dst_d, minlength=n_dst).cpu()
-    deg_src = torch.bincount(src_d, minlength=n_src).cpu()
-
-    def edges_of(rows, by_dst):
-        """(src, dst, row position in ``rows`` per edge) of the edges whose query (by_dst) / source row is in ``rows``, edge order kept"""
-        local = torch.full((n_dst if by_dst else n_src,), -1, dtype=torch.long, device=DEV)
-        local[rows.to(DEV)] = torch.arange(rows.numel(), device=DEV)
-        loc = local[dst_d if by_dst else src_d]
-        idx = (loc >= 0).nonzero().flatten()
-        return src_d[idx].cpu(), dst_d[idx].cpu(), loc[idx].cpu()
+    ei_c = ei.cpu().long()
+    src, dst = ei_c[0], ei_c[1]
+    deg_dst = torch.bincount(dst, minlength=n_dst)
+    deg_src = torch.bincount(src, minlength=n_src)
     y_c, x_c = y_pos.cpu(), x_pos.cpu()
     tag = f"gno_full_{side}_nh{nh}_{precision}"
     print(f"[parity] {tag}: E={ei.shape[1]} max query degree {int(deg_dst.max())}, empty query rows {int((deg_dst == 0).sum())}, "
@@ -352,19 +346,10 @@ def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
     f_d = f_y.to(DEV)
     out = ops.gno_forward(ws, bs, y_pos, x_pos, f_d, graph, precision=prec)
     gf, _, _ = ops.gno_backward(ws, bs, y_pos, x_pos, f_d, dout.to(DEV), graph, precision=prec)
-    # test plumbing on the device (round 6: the 64 M-edge index arithmetic took longer on the host than the oracle itself): degrees, and
-    # the edges of a set of sampled rows -- only those come to the host, where the oracle runs
-    src_d, dst_d = ei[0].long(), ei[1].long()
-    deg_dst = torch.bincount(dst_d, minlength=n_dst).cpu()
-    deg_src = torch.bincount(src_d, minlength=n_src).cpu()
-
-    def edges_of(rows, by_dst):
-        """(src, dst, row position in ``rows`` per edge) of the edges whose query (by_dst) / source row is in ``rows``, edge order kept"""
-        local = torch.full((n_dst if by_dst else n_src,), -1, dtype=torch.long, device=DEV)
-        local[rows.to(DEV)] = torch.arange(rows.numel(), device=DEV)
-        loc = local[dst_d if by_dst else src_d]
-        idx = (loc >= 0).nonzero().flatten()
-        return src_d[idx].cpu(), dst_d[idx].cpu(), loc[idx].cpu()
+    ei_c = ei.cpu().long()
+    src, dst = ei_c[0], ei_c[1]
+    deg_dst = torch.bincount(dst, minlength=n_dst)
+    deg_src = torch.bincount(src, minlength=n_src)
     # sampled row counts by degree: the encoder's query rows (latent tokens) have ~490 edges each, the decoder's 8 -- the oracle's cost
     # is the EDGES of the sampled rows (round 6: 49 s -> ~20 s per encoder case; same assertions)
     heavy = float(deg_dst.float().mean()) > 64
@@ -381,8 +366,10 @@ def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
     assert ei.shape[1] == 64_000_000
 
     qs = _sample_rows(deg_dst, n_s, gen)
-    es, _, lq = edges_of(qs, True)
-    ref = orc.integral_transform(sd, "", y_c, x_c[qs], torch.stack([es, lq]), f_y)
+    local = torch.full((n_dst,), -1, dtype=torch.long)
+    local[qs] = torch.arange(qs.numel())
+    sel = local[dst] >= 0
+    ref = orc.integral_transform(sd, "", y_c, x_c[qs], torch.stack([src[sel], local[dst[sel]]]), f_y)
     if precision == "fp32":
         PAR.close(f"{tag}/out[{qs.numel()} rows]", out[qs.to(DEV)], ref, 1e-4, 1e-5 * float(ref.abs().max()))
     else:
@@ -390,17 +377,23 @@ def test_gno_8m_point_graph_vs_oracle(sample8m, precision, side, nh):
 
     sd64 = {k: v.double() for k, v in sd.items()}
     ss = _sample_rows(deg_src, 1000, gen)
-    es, ed, ls = edges_of(ss, False)
+    local = torch.full((n_src,), -1, dtype=torch.long)
+    local[ss] = torch.arange(ss.numel())
+    sel = local[src] >= 0
+    es, ed = src[sel], dst[sel]
     fsub = f_y[ss].double().requires_grad_(True)
     kern = orc.channel_mlp(sd64, "channel_mlp.", torch.cat([y_c[es], x_c[ed]], dim=1).double())
-    (kern * fsub[ls] * (dout[ed].double() / deg_dst[ed].clamp(min=1)[:, None])).sum().backward()
+    (kern * fsub[local[es]] * (dout[ed].double() / deg_dst[ed].clamp(min=1)[:, None])).sum().backward()
     if precision == "fp32":
         PAR.close(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-3, 1e-5 * float(fsub.grad.abs().max()))
     else:
         PAR.cosine(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 0.999)
         PAR.close_peak(f"{tag}/grad_f_y[{ss.numel()} rows]", gf[ss.to(DEV)], fsub.grad, 1e-2)
 
-    es, ed, _ = edges_of(qw, True)
+    local = torch.full((n_dst,), -1, dtype=torch.long)
+    local[qw] = torch.arange(qw.numel())
+    sel = local[dst] >= 0
+    es, ed = src[sel], dst[sel]
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd64.items()}
     kern = orc.channel_mlp(leaves, "channel_mlp.", torch.cat([y_c[es], x_c[ed]], dim=1).double())
     (kern * f_y[es].double() * (dout[ed].double() / deg_dst[ed].clamp(min=1).double()[:, None])).sum().backward()
