@@ -186,6 +186,7 @@ def algorithmic_work(n_pts, m_lat, e_enc, e_dec, s_tok, layers, heads=8, dh=32, 
     return {
         "attn_fwd": dict(flops=2 * att, bytes=None, bound="mfma"),
         "attn_bwd": dict(flops=4 * att, bytes=None, bound="mfma"),       # fused backward: dP, dV, dK, dQ (S recompute not counted)
+        "attn_bwd_fused_f32": dict(flops=4 * att, bytes=None, bound="mfma"),   # fp32 mode, one pass: dP, dV, dK, dQ (S recompute not counted; the slab reduction launched behind it is inside the timed span)
         "attn_bwd_dkv": dict(flops=3 * att, bytes=None, bound="mfma"),   # dP, dV, dK (S recompute not counted)
         "attn_bwd_dq": dict(flops=1 * att, bytes=None, bound="mfma"),    # dQ (S, dP recompute not counted)
         "gno_fwd_nh3": dict(flops=e_enc * 21280, bytes=e_enc * (32 + c * b) + m_lat * c * b, bound="hbm"),

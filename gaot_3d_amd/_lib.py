@@ -56,6 +56,8 @@ SIGNATURES = {
                           _sz, _p]),
     "gaot_attn_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _p]),
     "gaot_attn_bwd": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _i, _p]),
+    "gaot_attn_bwd_fused_f32_scratch_bytes": (_i64, [_i, _i, _i]),
+    "gaot_attn_bwd_fused_f32": (_i, [_p] * 10 + [_i64] * 8 + [_i, _i, _i, _i, _i, _f, _f, _p, _i, _i, _i, _p, C.c_size_t, _p]),
     "gaot_attn_dropout_mask": (_i, [_p, _f, _i, _i, _i, _p, _p]),
     "gaot_dropout_seed_next": (_i, [_p, C.c_uint64, _p, _p]),
     "gaot_dropout_seed_block": (_i, [_p, C.c_uint64, _i, _p, _p]),

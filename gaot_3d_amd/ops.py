@@ -204,6 +204,7 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
 # fp32 accumulation for the dense GEMMs / attention (BASELINE config 1)
 # ------------------------------------------------------------------------------------------------
 _PRECISION = {"mode": 0}
+_ATTN_F32_FUSED = os.environ.get("GAOT_ATTN_F32_FUSED", "1") != "0"    # fp32 mode: the one-pass attention backward (A/B switch)
 
 
 def set_precision(mode: str):
@@ -590,6 +591,23 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     base, gbase = qkv.data_ptr(), dqkv.data_ptr()
     offk, offv = 4 * h * 32, 4 * (h + hkv) * 32
+    if _ATTN_F32_FUSED:
+        # dK, dV and dQ from one pass (5 S^2 d products instead of 7); its fp32 dQ slab partials live in a buffer of this call
+        nb = int(lib.gaot_attn_bwd_fused_f32_scratch_bytes(b, s, h))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with _timed("attn_bwd_delta"):
+            check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
+                                    _ptr(d_o), _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
+                                    C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
+                                    float(scale), dp, sp, int(head0), int(heads_total), _PRECISION["mode"], 1, _stream()),
+                  "gaot_attn_bwd")
+        with _timed("attn_bwd_fused_f32"):
+            check(lib.gaot_attn_bwd_fused_f32(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
+                                              _ptr(d_o), _ptr(lse), _ptr(delta), C.c_void_p(gbase), C.c_void_p(gbase + offk),
+                                              C.c_void_p(gbase + offv), ld, ld, ld, h * 32, h * 32, ld, ld, ld, b, s, h, hkv, 32,
+                                              float(scale), dp, sp, int(head0), int(heads_total), 0, _ptr(scratch), nb, _stream()),
+                  "gaot_attn_bwd_fused_f32")
+        return dqkv
     for name, mask in (("attn_bwd_delta", 1), ("attn_bwd_dkv", 2), ("attn_bwd_dq", 4)):
         with _timed(name):
             check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),

@@ -162,6 +162,16 @@ int gaot_attn_bwd(const float* q, const float* k, const float* v, const float* o
                   int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
                   float scale, float dropout_p, const unsigned long long* dropout_seed, int head0, int heads_total,
                   int precision, int phase_mask /* 1 delta | 2 dK,dV | 4 dQ ; 7 = all */, gaot_stream_t stream);
+/* fp32 mode: dK, dV and dQ from ONE pass over the (query tile, key block) pairs (the two-pass form above recomputes S and dP for dQ:
+ * 7 S^2 d products per layer, 5 here) -- dQ leaves as fp32 slab partials [B][H][ceil(S/256)][S][32] in `scratch`
+ * (gaot_attn_bwd_fused_f32_scratch_bytes(B, S, H)), summed in slab order by the reduction launched behind it: no atomics,
+ * bit-reproducible.  run_delta != 0: phase 1 of gaot_attn_bwd first.  Same arguments and results as gaot_attn_bwd(phase_mask 7). */
+int64_t gaot_attn_bwd_fused_f32_scratch_bytes(int B, int S, int H);
+int gaot_attn_bwd_fused_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                            float* delta, float* dq, float* dk, float* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                            int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int B, int S, int H, int HKV, int head_dim,
+                            float scale, float dropout_p, const unsigned long long* dropout_seed, int head0, int heads_total,
+                            int run_delta, void* scratch, size_t scratch_bytes, gaot_stream_t stream);
 int gaot_attn_dropout_mask(const unsigned long long* dropout_seed, float dropout_p, int B, int H, int S,
                            unsigned char* keep, gaot_stream_t stream);
 /* the seed stream: *out = *state; *state += stride -- the word one dropout call uses, and the advance, in one launch */
