@@ -205,6 +205,7 @@ def gno_backward(weights, biases, y_pos: Tensor, x_pos: Tensor, f_y: Tensor, gra
 # ------------------------------------------------------------------------------------------------
 _PRECISION = {"mode": 0}
 _ATTN_F32_FUSED = os.environ.get("GAOT_ATTN_F32_FUSED", "1") != "0"    # fp32 mode: the one-pass attention backward (A/B switch)
+_ATTN_F32_FUSED_CAP = int(os.environ.get("GAOT_ATTN_F32_FUSED_MAX_MB", "4096")) << 20     # ... while its slab partials fit in this
 
 
 def set_precision(mode: str):
@@ -591,9 +592,10 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     delta = torch.empty(b, h, s, dtype=torch.float32, device=dev)
     base, gbase = qkv.data_ptr(), dqkv.data_ptr()
     offk, offv = 4 * h * 32, 4 * (h + hkv) * 32
-    if _ATTN_F32_FUSED:
-        # dK, dV and dQ from one pass (5 S^2 d products instead of 7); its fp32 dQ slab partials live in a buffer of this call
-        nb = int(lib.gaot_attn_bwd_fused_f32_scratch_bytes(b, s, h))
+    # dK, dV and dQ from one pass (5 S^2 d products instead of 7); its fp32 dQ slab partials live in a buffer of this call -- b * h *
+    # ceil(s / 256) * s * 128 bytes (1.07 GB at S = 16 384, 8 heads; quadratic in S): past the cap the two-pass kernels run
+    nb = int(lib.gaot_attn_bwd_fused_f32_scratch_bytes(b, s, h)) if _ATTN_F32_FUSED else 0
+    if _ATTN_F32_FUSED and nb <= _ATTN_F32_FUSED_CAP:
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         with _timed("attn_bwd_delta"):
             check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),

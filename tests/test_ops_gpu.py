@@ -152,6 +152,13 @@ def test_attention_fp32_one_pass_backward_equals_two_pass(b, s, h, hkv, p):
     err = (dq1 - dq2).abs().max().item() / max(dq2.abs().max().item(), 1e-30)
     print(f"[parity] attn_fp32_one_pass b={b} S={s} H={h}/{hkv} p={p}: dK | dV bit-identical, dQ max diff / peak {err:.2e}")
     assert err < 1e-5        # fp32 sums over the keys in another order (achieved 2e-6 at S = 4 096)
+    if s == 1000:            # past the scratch cap the two-pass kernels run: same results as the switch off
+        cap = ops._ATTN_F32_FUSED_CAP
+        try:
+            ops._ATTN_F32_FUSED_CAP = 1 << 16
+            assert torch.equal(ops.attn_bwd(qkv, o, d_o, lse, b, s, h, hkv, 1.0 / math.sqrt(32), p, seed), two)
+        finally:
+            ops._ATTN_F32_FUSED_CAP = cap
 
 
 @pytest.mark.parametrize("b,s,h,hkv,rope", [(1, 64, 2, 2, False), (2, 100, 2, 1, True), (1, 333, 8, 8, True),
