@@ -595,7 +595,10 @@ def attn_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, b: int, s: int, h
     # dK, dV and dQ from one pass (5 S^2 d products instead of 7); its fp32 dQ slab partials live in a buffer of this call -- b * h *
     # ceil(s / 256) * s * 128 bytes (1.07 GB at S = 16 384, 8 heads; quadratic in S): past the cap the two-pass kernels run
     nb = int(lib.gaot_attn_bwd_fused_f32_scratch_bytes(b, s, h)) if _ATTN_F32_FUSED else 0
-    if _ATTN_F32_FUSED and nb <= _ATTN_F32_FUSED_CAP:
+    # (a long sequence with few kv heads per launch -- one rank's share of a sharded step -- leaves the one-pass kernel fewer than one
+    # workgroup per CU, 256 keys each; the two-pass kernels split twice as fine)
+    starved = s >= 4096 and b * hkv * ((s + 255) // 256) < 256
+    if _ATTN_F32_FUSED and nb <= _ATTN_F32_FUSED_CAP and not starved:
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         with _timed("attn_bwd_delta"):
             check(lib.gaot_attn_bwd(C.c_void_p(base), C.c_void_p(base + offk), C.c_void_p(base + offv), _ptr(o),
